@@ -1,0 +1,174 @@
+/*
+ * olsr.h — C-ABI of the MI355X-native language-Gaussian rasterizer ("olsr").
+ *
+ * This is the drop-in boundary for the one hot path of rpng/online_lang_splatting:
+ * the differentiable tile rasterizer behind `diff_gaussian_rasterization`.
+ * Every entry point takes plain device pointers, sizes and a HIP stream handle
+ * (no torch types).  The reference interface each entry point replaces is cited
+ * as file:line relative to
+ *   DGR = /root/reference/submodules/diff-gaussian-rasterization
+ *   CR  = DGR/cuda_rasterizer
+ *
+ * Conventions (identical to the reference):
+ *   - all float arrays are fp32, row-major, contiguous, resident on the GPU;
+ *   - viewmatrix / projmatrix / projmatrix_raw are the 16 floats the Python caller
+ *     holds (i.e. the transposes W2C^T, (P*W2C)^T, P^T) — column-major to the kernels;
+ *   - opacities are post-sigmoid, scales post-exp, rotations are NOT re-normalised;
+ *   - outputs are fully overwritten by the library (the caller need not zero them).
+ *
+ * Error behaviour: every function returns OLSR_OK (0) or a negative code and
+ * records a message retrievable with olsr_last_error() (thread-local).
+ */
+#ifndef OLSR_H_INCLUDED
+#define OLSR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OLSR_OK 0
+#define OLSR_ERR_ARG (-1)      /* bad argument (shape / exclusivity / unsupported F, tile) */
+#define OLSR_ERR_DEVICE (-2)   /* HIP runtime error (message holds hipGetErrorString) */
+#define OLSR_ERR_ALLOC (-3)    /* allocation callback returned NULL */
+#define OLSR_ERR_CAPACITY (-4) /* async mode: instance count exceeded caller capacity */
+
+/* Backward flavour.  REFERENCE reproduces what the shipped CUDA computes with its
+ * 15x15 tiles (CR/config.h:17-18): the 225-lane tree reduction of
+ * CR/backward.cu:684-702 keeps 128 of 225 pixel ranks, language gradients come from
+ * tile rank 0 only (CR/backward.cu:1137,1194-1197) and the language recursion is not
+ * skip-guarded (CR/backward.cu:1127-1139).  EXACT is the true gradient. */
+#define OLSR_BWD_REFERENCE 0
+#define OLSR_BWD_EXACT 1
+
+/* Allocation callback: must return a device pointer to >= nbytes (256-byte aligned),
+ * valid until the matching backward has run.  Mirrors the std::function<char*(size_t)>
+ * resize functionals of CR/rasterizer.h:34-36 and DGR/rasterize_points.cu:27-33. */
+typedef void *(*olsr_alloc_fn)(void *user, size_t nbytes);
+
+/* Per-call scene description shared by forward and backward.
+ * Replaces the positional argument lists of
+ *   CudaRasterizer::Rasterizer::forward / backward           CR/rasterizer.h:33-104
+ *   CudaRasterizer::LanguageRasterizer::forward / backward   CR/rasterizer.h:115-197
+ * F == 0 selects the RGB-only rasterizer (GaussianRasterizer), F > 0 the language one. */
+typedef struct olsr_scene {
+  int32_t P;           /* number of Gaussians */
+  int32_t D;           /* active SH degree 0..3 */
+  int32_t M;           /* SH coefficients per channel in `shs` (0 when shs == NULL) */
+  int32_t F;           /* language channels: 0, 3, 15, 16 or 32 */
+  int32_t width;
+  int32_t height;
+  int32_t tile;        /* logical tile edge in pixels: 15 (reference, CR/config.h) or 16 */
+  int32_t prefiltered; /* CR/auxiliary.h:154-161 */
+  int32_t debug;       /* synchronise + check after every stage (CR/auxiliary.h:166-173) */
+  int32_t bwd_mode;    /* OLSR_BWD_REFERENCE or OLSR_BWD_EXACT (used by backward only) */
+  float tan_fovx;
+  float tan_fovy;
+  float scale_modifier;
+  float _pad0;
+  const float *background;       /* [3] */
+  const float *means3D;          /* [P,3] */
+  const float *shs;              /* [P,M,3] or NULL */
+  const float *colors_precomp;   /* [P,3] or NULL (exactly one of shs / colors_precomp) */
+  const float *language_precomp; /* [P,F]; required when F > 0 (CR/rasterizer_impl.cu:500-502) */
+  const float *opacities;        /* [P] */
+  const float *scales;           /* [P,3] or NULL */
+  const float *rotations;        /* [P,4] or NULL */
+  const float *cov3D_precomp;    /* [P,6] or NULL (exactly one of scales+rotations / cov3D) */
+  const float *viewmatrix;       /* [16] */
+  const float *projmatrix;       /* [16] */
+  const float *projmatrix_raw;   /* [16] (backward only; may be NULL in forward) */
+  const float *cam_pos;          /* [3] */
+} olsr_scene;
+
+/* Sizes of the three opaque state buffers (bytes).  Replace
+ * CudaRasterizer::required<GeometryState|ImageState|BinningState>, CR/rasterizer_impl.h:84-90. */
+size_t olsr_geometry_bytes(int32_t P, int32_t F);
+size_t olsr_image_bytes(int32_t width, int32_t height, int32_t tile);
+size_t olsr_binning_bytes(int64_t num_rendered, int32_t F);
+
+/* Forward.  Replaces RasterizeGaussiansCUDA / RasterizeLanguageGaussiansCUDA ->
+ * Rasterizer::forward / LanguageRasterizer::forward
+ * (DGR/rasterize_points.cu:35-123,125-241; CR/rasterizer_impl.cu:216-362,364-525).
+ * The three callbacks are invoked once each (geometry, image, then — after the
+ * instance count is known, one host sync like CR/rasterizer_impl.cu:454-455 —
+ * binning).  Outputs: out_color[3,H,W], out_language[F,H,W] (ignored when F == 0),
+ * out_depth[H,W], out_opacity[H,W], radii[P] (int32), n_touched[P] (int32).
+ * *num_rendered receives R, the number of (Gaussian, tile) instances. */
+int olsr_forward(const olsr_scene *scene,
+                 olsr_alloc_fn geometry_alloc, void *geometry_user,
+                 olsr_alloc_fn binning_alloc, void *binning_user,
+                 olsr_alloc_fn image_alloc, void *image_user,
+                 float *out_color, float *out_language, float *out_depth, float *out_opacity,
+                 int32_t *radii, int32_t *n_touched,
+                 int32_t *num_rendered, void *hip_stream);
+
+/* Forward without a host sync: the caller provides all three buffers, the binning
+ * buffer sized for `capacity` instances (olsr_binning_bytes(capacity, F)).  R stays on
+ * the device; `num_rendered_dev` (device int32[2]) receives {R, overflow_flag}.
+ * Nothing is rendered when R > capacity (overflow_flag = 1).  This is the entry the
+ * benchmark and the frame-sharded trainer use; it has no reference counterpart
+ * (SURVEY.md §7 step 8). */
+int olsr_forward_async(const olsr_scene *scene,
+                       void *geometry_buffer, void *binning_buffer, int64_t capacity,
+                       void *image_buffer,
+                       float *out_color, float *out_language, float *out_depth, float *out_opacity,
+                       int32_t *radii, int32_t *n_touched,
+                       int32_t *num_rendered_dev, void *hip_stream);
+
+/* Backward.  Replaces RasterizeGaussiansBackwardCUDA / RasterizeLanguageGaussiansBackwardCUDA ->
+ * Rasterizer::backward / LanguageRasterizer::backward
+ * (DGR/rasterize_points.cu:243-331,333-455; CR/rasterizer_impl.cu:529-636,638-756).
+ * `num_rendered` is the R returned by the forward (ignored, may be -1, when the
+ * buffers come from olsr_forward_async).  Gradient outputs, all fully overwritten:
+ *   dL_dmeans2D[P,3]  dL_dcolors[P,3]  dL_dlanguage[P,F]  dL_dopacity[P]
+ *   dL_dmeans3D[P,3]  dL_dcov3D[P,6]   dL_dsh[P,M,3]      dL_dscales[P,3]
+ *   dL_drotations[P,4]  dL_dtau[P,6]
+ * dL_dconic[P,4] and dL_ddepths[P] are the reference's internal buffers
+ * (DGR/rasterize_points.cu:390-391); they may be NULL.  dL_dtau_sum[6] (may be
+ * NULL) receives the sum over P that the Python layer computes at
+ * DGR/diff_gaussian_rasterization/__init__.py:383-385. */
+int olsr_backward(const olsr_scene *scene, const int32_t *radii,
+                  const void *geometry_buffer, int32_t num_rendered,
+                  void *binning_buffer, const void *image_buffer,
+                  const float *dL_dout_color, const float *dL_dout_language,
+                  const float *dL_dout_depth,
+                  float *dL_dmeans2D, float *dL_dconic, float *dL_dopacity,
+                  float *dL_dcolors, float *dL_dlanguage, float *dL_ddepths,
+                  float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
+                  float *dL_dscales, float *dL_drotations, float *dL_dtau,
+                  float *dL_dtau_sum, void *hip_stream);
+
+/* Near-plane visibility test.  Replaces markVisible / checkFrustum
+ * (DGR/rasterize_points.cu:457-476; CR/rasterizer_impl.cu:54-66,141-153).
+ * present[P] is one byte per Gaussian (bool). */
+int olsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
+                      const float *projmatrix, uint8_t *present, void *hip_stream);
+
+/* Introspection of the opaque state for stage-by-stage parity tests and for the
+ * benchmark's byte model.  Each returns a device pointer inside the given buffer
+ * (or NULL for an unknown name).  Names: geometry — "depths" f32[P], "means2D"
+ * f32[P,2], "cov3D" f32[P,6], "conic_opacity" f32[P,4], "rgb" f32[P,3], "clamped"
+ * u8[P,3], "tiles_touched" u32[P], "depth_order" u32[P]; binning — "point_list"
+ * u32[R]; image — "final_T" f32[H*W], "n_contrib" u32[H*W], "ranges" u32[tiles,2]. */
+const void *olsr_geometry_field(const void *geometry_buffer, int32_t P, int32_t F, const char *name);
+const void *olsr_binning_field(const void *binning_buffer, int64_t num_rendered, int32_t F,
+                               const char *name);
+const void *olsr_image_field(const void *image_buffer, int32_t width, int32_t height, int32_t tile,
+                             const char *name);
+
+/* Per-stage HIP-event timing of the most recent forward/backward on this thread
+ * (enabled with olsr_set_profiling(1); adds event records, no syncs).  names/ms
+ * receive up to `max` entries; returns the count.  Synchronises the stream. */
+void olsr_set_profiling(int enable);
+int olsr_get_stage_times(const char **names, float *ms, int max);
+
+const char *olsr_last_error(void);
+const char *olsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OLSR_H_INCLUDED */

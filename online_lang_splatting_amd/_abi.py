@@ -1,0 +1,88 @@
+"""ctypes mirror of include/olsr.h (struct olsr_scene, callback type, constants).
+
+Pure declarations: importing this module loads no native code.
+"""
+import ctypes as C
+
+OLSR_OK = 0
+OLSR_ERR_ARG = -1
+OLSR_ERR_DEVICE = -2
+OLSR_ERR_ALLOC = -3
+OLSR_ERR_CAPACITY = -4
+
+BWD_REFERENCE = 0
+BWD_EXACT = 1
+
+SUPPORTED_F = (0, 3, 15, 16, 32)
+SUPPORTED_TILES = (15, 16)
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+_fp = C.c_void_p  # device (or, for the oracle, host) float pointers travel as raw addresses
+
+
+class OlsrScene(C.Structure):
+    """struct olsr_scene, include/olsr.h."""
+
+    _fields_ = [
+        ("P", C.c_int32),
+        ("D", C.c_int32),
+        ("M", C.c_int32),
+        ("F", C.c_int32),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("tile", C.c_int32),
+        ("prefiltered", C.c_int32),
+        ("debug", C.c_int32),
+        ("bwd_mode", C.c_int32),
+        ("tan_fovx", C.c_float),
+        ("tan_fovy", C.c_float),
+        ("scale_modifier", C.c_float),
+        ("_pad0", C.c_float),
+        ("background", _fp),
+        ("means3D", _fp),
+        ("shs", _fp),
+        ("colors_precomp", _fp),
+        ("language_precomp", _fp),
+        ("opacities", _fp),
+        ("scales", _fp),
+        ("rotations", _fp),
+        ("cov3D_precomp", _fp),
+        ("viewmatrix", _fp),
+        ("projmatrix", _fp),
+        ("projmatrix_raw", _fp),
+        ("cam_pos", _fp),
+    ]
+
+
+def _ptr(t):
+    """data_ptr of a tensor, or None for an absent (None / empty) one — the reference maps
+    empty tensors to nullptr the same way (contiguous().data<float>() of a 0-element tensor,
+    tested with `!= nullptr` in CR/forward.cu:320,356)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode, tan_fovx, tan_fovy,
+               scale_modifier, background, means3D, shs, colors_precomp, language_precomp, opacities,
+               scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos):
+    s = OlsrScene()
+    s.P, s.D, s.M, s.F = int(P), int(D), int(M), int(F)
+    s.width, s.height, s.tile = int(width), int(height), int(tile)
+    s.prefiltered, s.debug, s.bwd_mode = int(bool(prefiltered)), int(bool(debug)), int(bwd_mode)
+    s.tan_fovx, s.tan_fovy, s.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
+    s.background = _ptr(background)
+    s.means3D = _ptr(means3D)
+    s.shs = _ptr(shs)
+    s.colors_precomp = _ptr(colors_precomp)
+    s.language_precomp = _ptr(language_precomp)
+    s.opacities = _ptr(opacities)
+    s.scales = _ptr(scales)
+    s.rotations = _ptr(rotations)
+    s.cov3D_precomp = _ptr(cov3D_precomp)
+    s.viewmatrix = _ptr(viewmatrix)
+    s.projmatrix = _ptr(projmatrix)
+    s.projmatrix_raw = _ptr(projmatrix_raw)
+    s.cam_pos = _ptr(cam_pos)
+    return s

@@ -1,0 +1,241 @@
+"""CPU oracle with the reference's `_C` surface.  TEST INFRASTRUCTURE ONLY.
+
+Exposes the five functions of DGR/ext.cpp:15-21 with the positional signatures of
+DGR/rasterize_points.h:17-152, operating on CPU tensors through liboracle.so
+(oracle/oracle.cpp).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this module; the product never does.
+
+Extra knobs that the reference fixes at compile time are module globals:
+TILE (CR/config.h:17-18) and BWD_MODE (reference / exact).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from online_lang_splatting_amd import _abi  # noqa: E402  (struct declarations only)
+
+TILE = 15
+BWD_MODE = _abi.BWD_REFERENCE
+
+_lib = None
+_states = {}
+_next_id = [1]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "olsr.h")
+    stale = (not os.path.exists(so)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = build()
+        L = C.CDLL(so)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        vp = C.c_void_p
+        L.oracle_forward.argtypes = [vp, C.POINTER(_abi.OlsrScene)] + [vp] * 7
+        L.oracle_forward.restype = C.c_int
+        L.oracle_backward.argtypes = [vp, C.POINTER(_abi.OlsrScene)] + [vp] * 16
+        L.oracle_backward.restype = C.c_int
+        L.oracle_mark_visible.argtypes = [C.c_int32, vp, vp, vp, vp]
+        L.oracle_mark_visible.restype = C.c_int
+        L.oracle_get_field.argtypes = [vp, C.c_char_p, vp]
+        L.oracle_get_field.restype = C.c_int64
+        L.oracle_expf_probe.argtypes = [C.c_float]
+        L.oracle_expf_probe.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+class _State:
+    def __init__(self):
+        self.h = lib().oracle_create()
+
+    def __del__(self):
+        try:
+            lib().oracle_destroy(self.h)
+        except Exception:
+            pass
+
+
+def _f(t):
+    return t.contiguous().float() if t is not None and t.numel() > 0 else None
+
+
+def _scene(bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+           projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug, F):
+    keep = [_f(x) for x in (bg, means3D, sh, colors, language, opacity, scales, rotations, cov3D_precomp,
+                            viewmatrix, projmatrix, projmatrix_raw, campos)]
+    bg_, m_, sh_, col_, lang_, op_, sc_, rot_, cov_, v_, p_, pr_, cp_ = keep
+    M = sh_.shape[1] if sh_ is not None else 0
+    s = _abi.make_scene(P=means3D.shape[0], D=degree, M=M, F=F, width=W, height=H, tile=TILE,
+                        prefiltered=prefiltered, debug=debug, bwd_mode=BWD_MODE, tan_fovx=tan_fovx,
+                        tan_fovy=tan_fovy, scale_modifier=scale_modifier, background=bg_, means3D=m_, shs=sh_,
+                        colors_precomp=col_, language_precomp=lang_, opacities=op_, scales=sc_, rotations=rot_,
+                        cov3D_precomp=cov_, viewmatrix=v_, projmatrix=p_, projmatrix_raw=pr_, cam_pos=cp_)
+    return s, keep
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def _forward(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+             viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered,
+             debug):
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    P = means3D.shape[0]
+    s, keep = _scene(bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                     viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos,
+                     prefiltered, debug, F)
+    out_color = torch.zeros(3, H, W)
+    out_lang = torch.zeros(max(F, 0), H, W)
+    out_depth = torch.zeros(1, H, W)
+    out_opacity = torch.zeros(1, H, W)
+    radii = torch.zeros(P, dtype=torch.int32)
+    n_touched = torch.zeros(P, dtype=torch.int32)
+    R = C.c_int32(0)
+    st = _State()
+    sid = _next_id[0]
+    _next_id[0] += 1
+    _states[sid] = st
+    _check(lib().oracle_forward(st.h, C.byref(s), out_color.data_ptr(), out_lang.data_ptr(), out_depth.data_ptr(),
+                                out_opacity.data_ptr(), radii.data_ptr(), n_touched.data_ptr(),
+                                C.addressof(R)), "forward")
+    geom = torch.tensor([sid], dtype=torch.int64).view(torch.uint8)
+    empty = torch.empty(0, dtype=torch.uint8)
+    return R.value, out_color, out_lang, radii, geom, empty, empty.clone(), out_depth, out_opacity, n_touched
+
+
+def state_of(geomBuffer):
+    return _states[int(geomBuffer.view(torch.int64)[0])]
+
+
+def release(geomBuffer):
+    _states.pop(int(geomBuffer.view(torch.int64)[0]), None)
+
+
+_FIELD_DT = {"clamped": torch.uint8, "tiles_touched": torch.int32, "point_offsets": torch.int32,
+             "point_list": torch.int32, "keys": torch.int64, "ranges": torch.int32, "n_contrib": torch.int32}
+
+
+def get_field(geomBuffer, name):
+    st = state_of(geomBuffer)
+    n = lib().oracle_get_field(st.h, name.encode(), None)
+    if n < 0:
+        raise KeyError(name)
+    t = torch.zeros(n, dtype=_FIELD_DT.get(name, torch.float32))
+    lib().oracle_get_field(st.h, name.encode(), t.data_ptr())
+    return t
+
+
+def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                        campos, prefiltered, debug):
+    """RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-123."""
+    r = _forward(0, bg, means3D, colors, None, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                 viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                 campos, prefiltered, debug)
+    R, color, _lang, radii, geom, binning, img, depth, opacity_out, n_touched = r
+    return R, color, radii, geom, binning, img, depth, opacity_out, n_touched
+
+
+def rasterize_language_gaussians(bg, means3D, colors, language, opacity, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy,
+                                 image_height, image_width, sh, degree, campos, prefiltered, debug):
+    """RasterizeLanguageGaussiansCUDA, DGR/rasterize_points.cu:125-241."""
+    F = language.shape[1]
+    return _forward(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                    viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh,
+                    degree, campos, prefiltered, debug)
+
+
+def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+              projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language, dL_dout_depth, sh,
+              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, keep_internal=False):
+    P = means3D.shape[0]
+    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    st = state_of(geomBuffer)
+    # opacities are not an input of the reference backward (they live in conic_opacity); the
+    # oracle keeps them in its state, so pass a dummy non-null pointer to satisfy check_scene.
+    dummy_op = torch.zeros(max(P, 1))
+    s, keep = _scene(bg, means3D, colors, language, dummy_op, scales, rotations, scale_modifier, cov3D_precomp,
+                     viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, False,
+                     debug, F)
+    M = s.M
+    g = dict(
+        dL_dmeans2D=torch.zeros(P, 3), dL_dconic=torch.zeros(P, 2, 2), dL_dopacity=torch.zeros(P, 1),
+        dL_dcolors=torch.zeros(P, 3), dL_dlanguage=torch.zeros(P, max(F, 0)), dL_ddepths=torch.zeros(P, 1),
+        dL_dmeans3D=torch.zeros(P, 3), dL_dcov3D=torch.zeros(P, 6), dL_dsh=torch.zeros(P, M, 3),
+        dL_dscales=torch.zeros(P, 3), dL_drotations=torch.zeros(P, 4), dL_dtau=torch.zeros(P, 6))
+    dc = dL_dout_color.contiguous().float()
+    dl = dL_dout_language.contiguous().float() if F > 0 else torch.zeros(1)
+    dd = dL_dout_depth.contiguous().float()
+    rad = radii.contiguous().to(torch.int32)
+    _check(lib().oracle_backward(
+        st.h, C.byref(s), rad.data_ptr(), dc.data_ptr(), dl.data_ptr(), dd.data_ptr(),
+        g["dL_dmeans2D"].data_ptr(), g["dL_dconic"].data_ptr(), g["dL_dopacity"].data_ptr(),
+        g["dL_dcolors"].data_ptr(), g["dL_dlanguage"].data_ptr(), g["dL_ddepths"].data_ptr(),
+        g["dL_dmeans3D"].data_ptr(), g["dL_dcov3D"].data_ptr(), g["dL_dsh"].data_ptr(),
+        g["dL_dscales"].data_ptr(), g["dL_drotations"].data_ptr(), g["dL_dtau"].data_ptr()), "backward")
+    return g
+
+
+def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                 debug):
+    """RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:243-331."""
+    g = _backward(0, bg, means3D, radii, colors, None, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                  projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, None, dL_dout_depths, sh, degree,
+                  campos, geomBuffer, R, binningBuffer, imageBuffer, debug)
+    return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
+            g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+
+
+def rasterize_language_gaussians_backward(bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
+                                          cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy,
+                                          dL_dout_color, dL_dout_language, dL_dout_depth, sh, degree, campos,
+                                          geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeLanguageGaussiansBackwardCUDA, DGR/rasterize_points.cu:333-455."""
+    F = language.shape[1]
+    g = _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_modifier, cov3D_precomp,
+                  viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language,
+                  dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug)
+    return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dlanguage"], g["dL_dopacity"], g["dL_dmeans3D"],
+            g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+
+
+def backward_all(F, *args, **kw):
+    """Same as the two backward functions but returns every gradient incl. dL_dconic / dL_ddepths."""
+    return _backward(F, *args, **kw)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible, DGR/rasterize_points.cu:457-476."""
+    P = means3D.shape[0]
+    present = torch.zeros(P, dtype=torch.bool)
+    m, v, p = means3D.contiguous().float(), viewmatrix.contiguous().float(), projmatrix.contiguous().float()
+    if P:
+        _check(lib().oracle_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), present.data_ptr()),
+               "mark_visible")
+    return present
+
+
+def expf(x):
+    return lib().oracle_expf_probe(float(x))
