@@ -127,11 +127,12 @@ int olsr_forward_async(const olsr_scene *scene,
  *   dL_dmeans3D[P,3]  dL_dcov3D[P,6]   dL_dsh[P,M,3]      dL_dscales[P,3]
  *   dL_drotations[P,4]  dL_dtau[P,6]
  * dL_dconic[P,4] and dL_ddepths[P] are the reference's internal buffers
- * (DGR/rasterize_points.cu:390-391); they may be NULL.  dL_dtau_sum[6] (may be
+ * (DGR/rasterize_points.cu:390-391); they may be NULL.  The geometry and binning buffers
+ * carry scratch regions the backward writes (the reference passes them as char* too).  dL_dtau_sum[6] (may be
  * NULL) receives the sum over P that the Python layer computes at
  * DGR/diff_gaussian_rasterization/__init__.py:383-385. */
 int olsr_backward(const olsr_scene *scene, const int32_t *radii,
-                  const void *geometry_buffer, int32_t num_rendered,
+                  void *geometry_buffer, int32_t num_rendered,
                   void *binning_buffer, const void *image_buffer,
                   const float *dL_dout_color, const float *dL_dout_language,
                   const float *dL_dout_depth,

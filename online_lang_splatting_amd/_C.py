@@ -1,0 +1,219 @@
+"""The reference's `_C` extension surface over the MI355X-native library.
+
+Same five functions as DGR/ext.cpp:15-21, same positional signatures and return tuples as
+DGR/rasterize_points.h:17-152 — so the autograd layer (rasterizer.py) reads like the
+reference's.  Tensors are allocated with torch (device memory and the current HIP stream are
+plumbing); all arithmetic happens behind the C-ABI of include/olsr.h in libolsr.so.
+
+Knobs the reference fixes at compile time (CR/config.h:15-18) are module attributes:
+  TILE      logical tile edge, 15 (reference) or 16
+  BWD_MODE  _abi.BWD_REFERENCE (bug-compatible, default) or _abi.BWD_EXACT (true gradient)
+The number of language channels is taken from language.shape[1] (supported: 3, 15, 16, 32).
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._lib import check, lib
+
+TILE = 15
+BWD_MODE = _abi.BWD_REFERENCE
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _c(t):
+    """contiguous fp32 view, or None for an absent tensor (0 elements -> nullptr)."""
+    if t is None or t.numel() == 0:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("every rasterizer input must live on the GPU (got a CPU tensor): "
+                           "this rasterizer has no CPU path")
+    return t.contiguous() if t.dtype == torch.float32 else t.contiguous().float()
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on the GPU: this rasterizer has no CPU path")
+
+
+class _Resizer:
+    """resizeFunctional, DGR/rasterize_points.cu:27-33: the C side asks for bytes, we resize a
+    uint8 tensor and hand back its data pointer."""
+
+    def __init__(self, device):
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _abi.ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.t.device)
+        return self.t.data_ptr()
+
+
+def _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+           projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug):
+    keep = [_c(x) for x in (bg, means3D, sh, colors, language, opacity, scales, rotations, cov3D_precomp, viewmatrix,
+                            projmatrix, projmatrix_raw, campos)]
+    bg_, m_, sh_, col_, lang_, op_, sc_, rot_, cov_, v_, p_, pr_, cp_ = keep
+    M = sh_.shape[1] if sh_ is not None else 0
+    s = _abi.make_scene(P=means3D.shape[0], D=degree, M=M, F=F, width=W, height=H, tile=TILE,
+                        prefiltered=prefiltered, debug=debug, bwd_mode=BWD_MODE, tan_fovx=tan_fovx, tan_fovy=tan_fovy,
+                        scale_modifier=scale_modifier, background=bg_, means3D=m_, shs=sh_, colors_precomp=col_,
+                        language_precomp=lang_, opacities=op_, scales=sc_, rotations=rot_, cov3D_precomp=cov_,
+                        viewmatrix=v_, projmatrix=p_, projmatrix_raw=pr_, cam_pos=cp_)
+    return s, keep
+
+
+def _forward(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+             projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+             prefiltered, debug):
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # DGR/rasterize_points.cu:159-161
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    with torch.cuda.device(dev):
+        s, keep = _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                         viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos,
+                         prefiltered, debug)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        # every output is fully written by the library (no torch::full zero-fill, unlike
+        # DGR/rasterize_points.cu:170-175)
+        out_color = torch.empty(3, H, W, **f32)
+        out_lang = torch.empty(F, H, W, **f32)
+        out_depth = torch.empty(1, H, W, **f32)
+        out_opacity = torch.empty(1, H, W, **f32)
+        radii = torch.empty(P, **i32)
+        n_touched = torch.empty(P, **i32)
+        geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
+        R = C.c_int32(0)
+        check(lib().olsr_forward(C.byref(s), geom.cb, None, binning.cb, None, img.cb, None, out_color.data_ptr(),
+                                 out_lang.data_ptr() if F > 0 else None, out_depth.data_ptr(),
+                                 out_opacity.data_ptr(), radii.data_ptr() if P else None,
+                                 n_touched.data_ptr() if P else None, C.byref(R), _stream(dev)))
+    return R.value, out_color, out_lang, radii, geom.t, binning.t, img.t, out_depth, out_opacity, n_touched
+
+
+def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """RasterizeGaussiansCUDA, DGR/rasterize_points.cu:35-123."""
+    R, color, _l, radii, geom, binning, img, depth, opac, n_touched = _forward(
+        0, bg, means3D, colors, None, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+        projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+        debug)
+    return R, color, radii, geom, binning, img, depth, opac, n_touched
+
+
+def rasterize_language_gaussians(bg, means3D, colors, language, opacity, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy,
+                                 image_height, image_width, sh, degree, campos, prefiltered, debug):
+    """RasterizeLanguageGaussiansCUDA, DGR/rasterize_points.cu:125-241."""
+    if language is None or language.dim() != 2 or language.shape[1] not in _abi.SUPPORTED_F[1:]:
+        raise RuntimeError(f"language_precomp must be [P, F] with F in {_abi.SUPPORTED_F[1:]}")
+    return _forward(language.shape[1], bg, means3D, colors, language, opacity, scales, rotations, scale_modifier,
+                    cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height,
+                    image_width, sh, degree, campos, prefiltered, debug)
+
+
+def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+              projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language, dL_dout_depth, sh,
+              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, want_internal=False):
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    with torch.cuda.device(dev):
+        s, keep = _scene(F, bg, means3D, colors, language, None, scales, rotations, scale_modifier, cov3D_precomp,
+                         viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, False,
+                         debug)
+        M = s.M
+        f32 = dict(dtype=torch.float32, device=dev)
+        # written exactly once per row by the library: no torch::zeros (DGR/rasterize_points.cu:386-398)
+        g = dict(dL_dmeans2D=torch.empty(P, 3, **f32), dL_dcolors=torch.empty(P, 3, **f32),
+                 dL_dlanguage=torch.empty(P, F, **f32), dL_dopacity=torch.empty(P, 1, **f32),
+                 dL_dmeans3D=torch.empty(P, 3, **f32), dL_dcov3D=torch.empty(P, 6, **f32),
+                 dL_dsh=torch.empty(P, M, 3, **f32), dL_dscales=torch.empty(P, 3, **f32),
+                 dL_drotations=torch.empty(P, 4, **f32), dL_dtau=torch.empty(P, 6, **f32),
+                 dL_dtau_sum=torch.empty(6, **f32))
+        if want_internal:
+            g["dL_dconic"] = torch.empty(P, 2, 2, **f32)
+            g["dL_ddepths"] = torch.empty(P, 1, **f32)
+        dc, dl, dd = _c(dL_dout_color), _c(dL_dout_language), _c(dL_dout_depth)
+        rad = radii.contiguous()
+
+        def p(name):
+            t = g.get(name)
+            return t.data_ptr() if t is not None and t.numel() > 0 else None
+        check(lib().olsr_backward(
+            C.byref(s), rad.data_ptr() if P else None, geomBuffer.data_ptr(), int(R), binningBuffer.data_ptr(),
+            imageBuffer.data_ptr(), dc.data_ptr() if dc is not None else None,
+            dl.data_ptr() if dl is not None else None, dd.data_ptr() if dd is not None else None,
+            p("dL_dmeans2D"), p("dL_dconic"), p("dL_dopacity"), p("dL_dcolors"), p("dL_dlanguage"), p("dL_ddepths"),
+            p("dL_dmeans3D"), p("dL_dcov3D"), p("dL_dsh"), p("dL_dscales"), p("dL_drotations"), p("dL_dtau"),
+            p("dL_dtau_sum"), _stream(dev)))
+    return g
+
+
+def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:243-331."""
+    g = _backward(0, bg, means3D, radii, colors, None, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                  projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, None, dL_dout_depths, sh, degree,
+                  campos, geomBuffer, R, binningBuffer, imageBuffer, debug)
+    return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
+            g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+
+
+def rasterize_language_gaussians_backward(bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
+                                          cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy,
+                                          dL_dout_color, dL_dout_language, dL_dout_depth, sh, degree, campos,
+                                          geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeLanguageGaussiansBackwardCUDA, DGR/rasterize_points.cu:333-455."""
+    g = _backward(language.shape[1], bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
+                  cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
+                  dL_dout_language, dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                  debug)
+    return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dlanguage"], g["dL_dopacity"], g["dL_dmeans3D"],
+            g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+
+
+def backward_all(F, *args, **kw):
+    """Every gradient of the backward incl. the internal dL_dconic / dL_ddepths and the
+    device-reduced dL_dtau_sum (parity tests, frame-sharded trainer)."""
+    return _backward(F, *args, want_internal=True, **kw)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible, DGR/rasterize_points.cu:457-476."""
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    present = torch.zeros(P, dtype=torch.bool, device=dev)
+    if P:
+        with torch.cuda.device(dev):
+            m, v, p = _c(means3D), _c(viewmatrix), _c(projmatrix)
+            check(lib().olsr_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr() if p is not None else None,
+                                          present.data_ptr(), _stream(dev)))
+    return present
+
+
+def state_field(kind, buf, name, *, P=0, F=0, R=0, W=0, H=0, dtype=torch.float32, count=0):
+    """View into an opaque state buffer (olsr_*_field) as a tensor of `count` elements."""
+    L = lib()
+    if kind == "geometry":
+        ptr = L.olsr_geometry_field(buf.data_ptr(), P, F, name.encode())
+    elif kind == "binning":
+        ptr = L.olsr_binning_field(buf.data_ptr(), R, F, name.encode())
+    else:
+        ptr = L.olsr_image_field(buf.data_ptr(), W, H, TILE, name.encode())
+    if not ptr:
+        raise KeyError(name)
+    off = ptr - buf.data_ptr()
+    nbytes = count * torch.empty(0, dtype=dtype).element_size()
+    return buf[off:off + nbytes].view(dtype)

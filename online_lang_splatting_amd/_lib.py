@@ -1,0 +1,76 @@
+"""Loads libolsr.so (the HIP kernels + C-ABI of include/olsr.h) and declares its prototypes.
+
+There is no fallback: if the library is missing or a symbol is absent this raises, loudly.
+"""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libolsr.so")
+
+# every symbol include/olsr.h declares
+EXPORTS = (
+    "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_forward", "olsr_forward_async",
+    "olsr_backward", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
+    "olsr_set_profiling", "olsr_get_stage_times", "olsr_last_error", "olsr_version",
+)
+
+_lib = None
+
+
+class OlsrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"olsr error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m online_lang_splatting_amd.build` "
+            "(hipcc, gfx950).  There is no CPU or PyTorch fallback for the rasterizer.")
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in EXPORTS if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} lacks symbols {missing}; rebuild it")
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    scene_p = C.POINTER(_abi.OlsrScene)
+    L.olsr_geometry_bytes.argtypes, L.olsr_geometry_bytes.restype = [i32, i32], sz
+    L.olsr_image_bytes.argtypes, L.olsr_image_bytes.restype = [i32, i32, i32], sz
+    L.olsr_binning_bytes.argtypes, L.olsr_binning_bytes.restype = [i64, i32], sz
+    L.olsr_forward.argtypes = [scene_p, _abi.ALLOC_FN, vp, _abi.ALLOC_FN, vp, _abi.ALLOC_FN, vp,
+                               vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp]
+    L.olsr_forward.restype = C.c_int
+    L.olsr_forward_async.argtypes = [scene_p, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.olsr_forward_async.restype = C.c_int
+    L.olsr_backward.argtypes = [scene_p, vp, vp, i32, vp, vp] + [vp] * 3 + [vp] * 13 + [vp]
+    L.olsr_backward.restype = C.c_int
+    L.olsr_mark_visible.argtypes, L.olsr_mark_visible.restype = [i32, vp, vp, vp, vp, vp], C.c_int
+    L.olsr_geometry_field.argtypes, L.olsr_geometry_field.restype = [vp, i32, i32, C.c_char_p], vp
+    L.olsr_binning_field.argtypes, L.olsr_binning_field.restype = [vp, i64, i32, C.c_char_p], vp
+    L.olsr_image_field.argtypes, L.olsr_image_field.restype = [vp, i32, i32, i32, C.c_char_p], vp
+    L.olsr_set_profiling.argtypes, L.olsr_set_profiling.restype = [C.c_int], None
+    L.olsr_get_stage_times.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    L.olsr_get_stage_times.restype = C.c_int
+    L.olsr_last_error.argtypes, L.olsr_last_error.restype = [], C.c_char_p
+    L.olsr_version.argtypes, L.olsr_version.restype = [], C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise OlsrError(rc, lib().olsr_last_error().decode())
+
+
+def stage_times():
+    """[(stage name, milliseconds)] of the most recent profiled forward/backward on this thread."""
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    n = lib().olsr_get_stage_times(names, ms, 32)
+    return [(names[i].decode(), float(ms[i])) for i in range(n)]

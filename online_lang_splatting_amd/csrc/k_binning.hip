@@ -1,0 +1,321 @@
+// k_binning.hip — instance offsets, emission, (tile, depth) ordering and tile ranges.
+//
+// Replaces cub::DeviceScan::InclusiveSum, duplicateWithKeys, cub::DeviceRadixSort::SortPairs
+// and identifyTileRanges (CR/rasterizer_impl.cu:451-493, 70-138).  The reference sorts R
+// 64-bit (tile | depth) keys; the required order is (tile, depth bits, Gaussian index).
+// MI355X-first formulation with the same result:
+//   1. stable radix sort of the P Gaussians by depth bits (P << R);
+//   2. emit instances in that order (so emission order is already (depth, index) sorted);
+//   3. stable radix sort of the R instances by tile id only (<= 16 bits -> 2 byte passes).
+// A stable sort of a (depth, index)-ordered stream by tile yields exactly (tile, depth, index).
+//
+// All kernels are wave64 code: per-wave ranking uses 64-bit ballots, block = 4 waves.
+#include "olsr_device.h"
+#include "olsr_kernels.h"
+
+namespace olsr {
+
+// ------------------------------------------------------------------------------- scans
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = SCAN_CHUNK / SCAN_THREADS;  // 16
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive prefix of `v` across a 256-thread block; *total receives the block sum
+__device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* total) {
+  __shared__ u32 wave_sums[4];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const u32 incl = wave_incl_scan(v);
+  if (lane == 63) wave_sums[w] = incl;
+  __syncthreads();
+  u32 base = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < w) base += wave_sums[i];
+  if (total) *total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+  __syncthreads();
+  return base + incl - v;
+}
+
+struct LoadPlain {
+  const u32* p;
+  __device__ __forceinline__ u32 operator()(int64_t i) const { return p[i]; }
+};
+// tiles_touched gathered in depth order
+struct LoadGather {
+  const u32* vals;
+  const u32* order;
+  __device__ __forceinline__ u32 operator()(int64_t i) const { return vals[order[i]]; }
+};
+
+template <class Load>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(Load ld, int64_t n, u32* partials) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k)
+    if (base + k < n) s += ld(base + k);
+  u32 total;
+  block_excl_scan_256(s, &total);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of partials[0..nb) in place; partials[nb] = grand total
+__global__ __launch_bounds__(1024) void scan_partials_kernel(u32* partials, int nb) {
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry_s;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const u32 v = (i < nb) ? partials[i] : 0;
+    const u32 incl = wave_incl_scan(v);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    u32 off = carry_s;
+    for (int k = 0; k < w; ++k) off += wsum[k];
+    if (i < nb) partials[i] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[nb] = carry_s;
+}
+
+template <class Load, bool INCLUSIVE>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(Load ld, int64_t n, const u32* partials, u32* out) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  u32 v[SCAN_ITEMS];
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < n) ? ld(base + k) : 0;
+    s += v[k];
+  }
+  u32 run = block_excl_scan_256(s, nullptr) + partials[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    if (INCLUSIVE) run += v[k];
+    if (base + k < n) out[base + k] = run;
+    if (!INCLUSIVE) run += v[k];
+  }
+}
+
+template <class Load, bool INCLUSIVE>
+static void device_scan(Load ld, int64_t n, u32* out, u32* partials, hipStream_t st) {
+  if (n <= 0) return;
+  const int nb = scan_blocks(n);
+  scan_reduce_kernel<Load><<<nb, SCAN_THREADS, 0, st>>>(ld, n, partials);
+  scan_partials_kernel<<<1, 1024, 0, st>>>(partials, nb);
+  scan_apply_kernel<Load, INCLUSIVE><<<nb, SCAN_THREADS, 0, st>>>(ld, n, partials, out);
+}
+
+// ------------------------------------------------------------------------------- radix sort
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ROUNDS = SORT_CHUNK / SORT_THREADS;  // 16 rounds of 64 per wave
+
+__device__ __forceinline__ int64_t bounded_n(int64_t n_host, const int32_t* n_dev) {
+  if (n_dev) {
+    const int64_t nd = (int64_t)(*n_dev);
+    return nd < n_host ? nd : n_host;
+  }
+  return n_host;
+}
+
+// table[d * nblk + b] = number of keys of block b whose digit is d
+__global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
+                                                                   const int32_t* __restrict__ n_dev, int shift,
+                                                                   u32* __restrict__ table) {
+  __shared__ u32 hist[256];
+  const int64_t n = bounded_n(n_host, n_dev);
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+#pragma unroll 4
+  for (int k = 0; k < SORT_ROUNDS; ++k) {
+    const int64_t i = base + (int64_t)k * SORT_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  table[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+}
+
+// Stable scatter.  Wave w of block b owns the contiguous run
+// [b*CHUNK + w*1024, +1024) and walks it in 16 rounds of 64 consecutive keys, so the order
+// inside a block is (wave, round, lane) == ascending input index.
+__global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
+    const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, int64_t n_host,
+    const int32_t* __restrict__ n_dev, int shift, const u32* __restrict__ table, u32* __restrict__ keys_out,
+    u32* __restrict__ vals_out, const u32* __restrict__ gather, u32* __restrict__ gather_out) {
+  __shared__ u32 cnt[4][256];
+  const int64_t n = bounded_n(n_host, n_dev);
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int64_t wbase = (int64_t)blockIdx.x * SORT_CHUNK + (int64_t)w * (SORT_CHUNK / 4);
+  u32 key[SORT_ROUNDS], val[SORT_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cnt[i][threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+    val[r] = valid ? (vals_in ? vals_in[i] : (u32)i) : 0u;
+    if (valid) atomicAdd(&cnt[w][(key[r] >> shift) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  {  // thread t owns digit t: turn per-wave counts into per-wave starting positions
+    u32 run = table[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32 c = cnt[i][threadIdx.x];
+      cnt[i][threadIdx.x] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  volatile u32* my = cnt[w];
+  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const bool valid = i < n;
+    const u32 d = (key[r] >> shift) & 0xFFu;
+    u64 peers = ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const u64 b = ballot(one);
+      peers &= one ? b : ~b;
+    }
+    if (valid) {
+      const u32 rank = (u32)__popcll(peers & lt_mask);
+      const u32 count = (u32)__popcll(peers);
+      const u32 start = my[d];
+      const u32 pos = start + rank;
+      if (rank == 0) my[d] = start + count;
+      keys_out[pos] = key[r];
+      if (vals_out) vals_out[pos] = val[r];
+      if (gather) gather_out[pos] = gather[val[r]];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
+                      const uint32_t* final_gather, uint32_t* final_gather_out, hipStream_t st) {
+  if (n_host <= 0) return 0;
+  const int nblk = sort_blocks(n_host);
+  const int passes = (bits + 7) / 8;
+  u32 *kin = b.key_a, *kout = b.key_b, *vin = b.val_a, *vout = b.val_b;
+  int where = 0;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    const bool last = (p == passes - 1);
+    radix_hist_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, n_host, n_dev, shift, b.table);
+    device_scan<LoadPlain, false>(LoadPlain{b.table}, (int64_t)256 * nblk, b.table, b.partials, st);
+    const u32* vsrc = (p == 0 && vals_in_identity) ? nullptr : vin;
+    radix_scatter_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, vsrc, n_host, n_dev, shift, b.table, kout, vout,
+                                                        last ? final_gather : nullptr,
+                                                        last ? final_gather_out : nullptr);
+    u32* t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+    where ^= 1;
+  }
+  return where;
+}
+
+// ------------------------------------------------------------------------------- offsets
+__global__ void finalize_counts_kernel(const u32* offsets, int P, long long capacity, int32_t* counters) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const u32 R = (P > 0) ? offsets[P - 1] : 0u;
+    const bool ok = (long long)R <= capacity && R <= 0x7FFFFFFFu;
+    counters[0] = (int32_t)R;
+    counters[1] = ok ? (int32_t)R : 0;
+    counters[2] = ok ? 0 : 1;
+  }
+}
+
+// cub::DeviceScan::InclusiveSum over tiles_touched (CR/rasterizer_impl.cu:451), taken in depth order
+void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, hipStream_t st) {
+  device_scan<LoadGather, true>(LoadGather{g.tiles_touched, g.depth_order}, (int64_t)P, g.offsets, g.scan_partials, st);
+  finalize_counts_kernel<<<1, 64, 0, st>>>(g.offsets, P, (long long)capacity, g.counters);
+}
+
+// ------------------------------------------------------------------------------- emission
+// duplicateWithKeys (CR/rasterizer_impl.cu:70-111), one thread per depth rank.  The depth half
+// of the reference's key is implied by the emission order; only the tile id is written.
+template <int TILE>
+__global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict__ order,
+                                                   const u32* __restrict__ offsets,
+                                                   const u32* __restrict__ tiles_touched,
+                                                   const float* __restrict__ means2D, const int32_t* __restrict__ radii,
+                                                   int gx, int gy, const int32_t* __restrict__ counters,
+                                                   u32* __restrict__ keys, u32* __restrict__ inst_gid) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P) return;
+  if (counters[2] != 0) return;  // overflow: nothing is emitted
+  const u32 g = order[r];
+  const int rad = radii[g];
+  if (rad > 0) {
+    u32 off = offsets[r] - tiles_touched[g];
+    const Rect rc = get_rect<TILE>(means2D[2 * (size_t)g], means2D[2 * (size_t)g + 1], rad, gx, gy);
+    for (int y = rc.y0; y < rc.y1; y++)
+      for (int x = rc.x0; x < rc.x1; x++) {
+        keys[off] = (u32)(y * gx + x);
+        inst_gid[off] = g;
+        off++;
+      }
+  }
+}
+
+void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
+                 const BinningState& b, hipStream_t st) {
+  if (s.P <= 0) return;
+  const int nb = (s.P + 255) / 256;
+  if (d.tile == 15)
+    emit_kernel<15><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii, d.gx, d.gy,
+                                        g.counters, b.key_a, b.inst_gid);
+  else
+    emit_kernel<16><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii, d.gx, d.gy,
+                                        g.counters, b.key_a, b.inst_gid);
+}
+
+// ------------------------------------------------------------------------------- ranges
+// identifyTileRanges (CR/rasterizer_impl.cu:116-138); ranges must be zeroed beforehand.
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict__ keys, int64_t n_host,
+                                                          const int32_t* __restrict__ n_dev, u32* __restrict__ ranges) {
+  const int64_t n = bounded_n(n_host, n_dev);
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const u32 cur = keys[idx];
+  if (idx == 0)
+    ranges[2 * cur] = 0;
+  else {
+    const u32 prev = keys[idx - 1];
+    if (cur != prev) {
+      ranges[2 * prev + 1] = (u32)idx;
+      ranges[2 * cur] = (u32)idx;
+    }
+  }
+  if (idx == n - 1) ranges[2 * cur + 1] = (u32)n;
+}
+
+void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
+                        int ntiles, hipStream_t st) {
+  (void)hipMemsetAsync(ranges, 0, sizeof(u32) * 2 * (size_t)ntiles, st);
+  if (n_host <= 0) return;
+  const int nb = (int)((n_host + 255) / 256);
+  tile_ranges_kernel<<<nb, 256, 0, st>>>(sorted_keys, n_host, n_dev, ranges);
+}
+
+}  // namespace olsr

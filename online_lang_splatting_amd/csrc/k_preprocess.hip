@@ -1,0 +1,174 @@
+// k_preprocess.hip — per-Gaussian forward preprocess and the near-plane visibility test.
+//
+// Replaces preprocessCUDA / languagePreprocessCUDA (CR/forward.cu:158-259, 262-371) and
+// checkFrustum (CR/rasterizer_impl.cu:54-66).  One lane per Gaussian; the 4x4 matrices are
+// wave-uniform and arrive through the scalar cache.  Besides the reference's outputs the
+// kernel seeds the depth sort: key = depth bits (0xFFFFFFFF for culled Gaussians, which
+// emit no instances anyway), value = Gaussian index.
+#include "olsr_device.h"
+#include "olsr_kernels.h"
+
+namespace olsr {
+
+// computeColorFromSH, CR/forward.cu:23-74
+__device__ __forceinline__ f3 color_from_sh(int idx, int deg, int max_coeffs, const f3& pos, const float* campos,
+                                            const float* __restrict__ shs, uint8_t* __restrict__ clamped) {
+  f3 dir = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+  const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+  dir = {dir.x / len, dir.y / len, dir.z / len};
+  const float* sh = shs + (size_t)idx * max_coeffs * 3;
+  float res[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float result = SH_C0 * sh[ch];
+    if (deg > 0) {
+      const float x = dir.x, y = dir.y, z = dir.z;
+      result = result - SH_C1 * y * sh[3 * 1 + ch] + SH_C1 * z * sh[3 * 2 + ch] - SH_C1 * x * sh[3 * 3 + ch];
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        result = result + SH_C2[0] * xy * sh[3 * 4 + ch] + SH_C2[1] * yz * sh[3 * 5 + ch] +
+                 SH_C2[2] * (2.0f * zz - xx - yy) * sh[3 * 6 + ch] + SH_C2[3] * xz * sh[3 * 7 + ch] +
+                 SH_C2[4] * (xx - yy) * sh[3 * 8 + ch];
+        if (deg > 2) {
+          result = result + SH_C3[0] * y * (3.0f * xx - yy) * sh[3 * 9 + ch] + SH_C3[1] * xy * z * sh[3 * 10 + ch] +
+                   SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[3 * 11 + ch] +
+                   SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[3 * 12 + ch] +
+                   SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[3 * 13 + ch] + SH_C3[5] * z * (xx - yy) * sh[3 * 14 + ch] +
+                   SH_C3[6] * x * (xx - 3.0f * yy) * sh[3 * 15 + ch];
+        }
+      }
+    }
+    result += 0.5f;
+    clamped[3 * (size_t)idx + ch] = (result < 0);
+    res[ch] = fmaxf_ref(result, 0.0f);
+  }
+  return {res[0], res[1], res[2]};
+}
+
+// computeCov3D, CR/forward.cu:121-155
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float mod, const float* rot, float* cov3D) {
+  m3 S = {{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}};
+  S.c[0][0] = mod * scale[0];
+  S.c[1][1] = mod * scale[1];
+  S.c[2][2] = mod * scale[2];
+  const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+  const m3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                 {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                 {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
+  const m3 M = mul(S, R);
+  const m3 Sigma = mul(transpose(M), M);
+  cov3D[0] = Sigma.c[0][0];
+  cov3D[1] = Sigma.c[0][1];
+  cov3D[2] = Sigma.c[0][2];
+  cov3D[3] = Sigma.c[1][1];
+  cov3D[4] = Sigma.c[1][2];
+  cov3D[5] = Sigma.c[2][2];
+}
+
+template <int TILE>
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int P, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+    uint8_t* __restrict__ clamped, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, int W,
+    int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int32_t* __restrict__ radii,
+    float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
+    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, u32* __restrict__ sort_key,
+    u32* __restrict__ sort_val, int prefiltered) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P) return;
+  radii[idx] = 0;
+  tiles_touched[idx] = 0;
+  sort_key[idx] = 0xFFFFFFFFu;
+  sort_val[idx] = (u32)idx;
+
+  // in_frustum, CR/auxiliary.h:139-164
+  const f3 p_orig = {orig_points[3 * (size_t)idx], orig_points[3 * (size_t)idx + 1], orig_points[3 * (size_t)idx + 2]};
+  const f3 p_view = transformPoint4x3(p_orig, viewmatrix);
+  if (p_view.z <= 0.2f) {
+    if (prefiltered) {
+      printf("Point is filtered although prefiltered is set. This shouldn't happen!");
+      __builtin_trap();
+    }
+    return;
+  }
+  const f4 p_hom = transformPoint4x4(p_orig, projmatrix);
+  const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+  const f3 p_proj = {p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w};
+
+  float cov3D[6];
+  if (cov3D_precomp != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
+  } else {
+    cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, cov3D);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cov3Ds[6 * (size_t)idx + i] = cov3D[i];
+  }
+
+  Cov2D ci;
+  cov2d_common(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, ci);
+  const float cx = ci.cov.c[0][0] + 0.3f, cy = ci.cov.c[0][1], cz = ci.cov.c[1][1] + 0.3f;
+  const float det = (cx * cz - cy * cy);
+  if (det == 0.0f) return;
+  const float det_inv = 1.f / det;
+  const f3 conic = {cz * det_inv, -cy * det_inv, cx * det_inv};
+
+  const float mid = 0.5f * (cx + cz);
+  const float lambda1 = mid + sqrtf(fmaxf_ref(0.1f, mid * mid - det));
+  const float lambda2 = mid - sqrtf(fmaxf_ref(0.1f, mid * mid - det));
+  const float my_radius = ceilf(3.f * sqrtf(fmaxf_ref(lambda1, lambda2)));
+  const float pix_x = ndc2Pix(p_proj.x, W), pix_y = ndc2Pix(p_proj.y, H);
+  const int irad = f2i_sat(my_radius);
+  const Rect rc = get_rect<TILE>(pix_x, pix_y, irad, gx, gy);
+  if ((rc.x1 - rc.x0) * (rc.y1 - rc.y0) == 0) return;
+
+  if (colors_precomp == nullptr) {
+    const f3 c = color_from_sh(idx, D, M, p_orig, cam_pos, shs, clamped);
+    rgb[3 * (size_t)idx + 0] = c.x;
+    rgb[3 * (size_t)idx + 1] = c.y;
+    rgb[3 * (size_t)idx + 2] = c.z;
+  }
+  depths[idx] = p_view.z;
+  radii[idx] = irad;
+  means2D[2 * (size_t)idx + 0] = pix_x;
+  means2D[2 * (size_t)idx + 1] = pix_y;
+  float4 co = make_float4(conic.x, conic.y, conic.z, opacities[idx]);
+  reinterpret_cast<float4*>(conic_opacity)[idx] = co;
+  tiles_touched[idx] = (u32)((rc.y1 - rc.y0) * (rc.x1 - rc.x0));
+  sort_key[idx] = f2bits(p_view.z);
+}
+
+void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometryState& g, int32_t* radii,
+                       hipStream_t st) {
+  if (s.P <= 0) return;
+  const int nb = (s.P + 255) / 256;
+#define OLSR_PRE_ARGS                                                                                                 \
+  s.P, s.D, s.M, s.means3D, s.scales, s.scale_modifier, s.rotations, s.opacities, s.shs, g.clamped, s.cov3D_precomp,  \
+      s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
+      d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched, g.key_a,   \
+      g.val_a, s.prefiltered
+  if (d.tile == 15)
+    preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
+  else
+    preprocess_kernel<16><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
+#undef OLSR_PRE_ARGS
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ pts,
+                                                           const float* __restrict__ view,
+                                                           uint8_t* __restrict__ present) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P) return;
+  const f3 p = {pts[3 * (size_t)idx], pts[3 * (size_t)idx + 1], pts[3 * (size_t)idx + 2]};
+  const f3 pv = transformPoint4x3(p, view);
+  present[idx] = !(pv.z <= 0.2f);
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st) {
+  if (P <= 0) return;
+  mark_visible_kernel<<<(P + 255) / 256, 256, 0, st>>>(P, means3D, view, present);
+}
+
+}  // namespace olsr

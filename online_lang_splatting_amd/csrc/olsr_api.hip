@@ -1,0 +1,383 @@
+// olsr_api.hip — the C-ABI of include/olsr.h: argument checking, state-buffer carving and
+// the launch sequence of the forward and backward passes.
+//
+// Counterpart of CR/rasterizer_impl.cu:216-756 (orchestration) and of the torch glue in
+// DGR/rasterize_points.cu (allocation), minus everything torch: the caller owns memory.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/olsr.h"
+#include "olsr_device.h"
+#include "olsr_kernels.h"
+#include "olsr_state.h"
+
+using namespace olsr;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local bool g_profiling = false;
+struct StageMark {
+  const char* name;
+  hipEvent_t ev;
+};
+thread_local std::vector<StageMark> g_marks;
+thread_local hipStream_t g_mark_stream = nullptr;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(OLSR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+  } while (0)
+
+void marks_reset(hipStream_t st) {
+  for (auto& m : g_marks) (void)hipEventDestroy(m.ev);
+  g_marks.clear();
+  g_mark_stream = st;
+}
+void mark(const char* name, hipStream_t st) {
+  if (!g_profiling) return;
+  StageMark m{name, nullptr};
+  if (hipEventCreate(&m.ev) != hipSuccess) return;
+  (void)hipEventRecord(m.ev, st);
+  g_marks.push_back(m);
+}
+
+// CHECK_CUDA(A, debug), CR/auxiliary.h:166-173
+int stage_check(const olsr_scene& s, const char* stage, hipStream_t st) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string(stage) + " launch: " + hipGetErrorString(e));
+  if (s.debug) {
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string(stage) + ": " + hipGetErrorString(e));
+  }
+  return OLSR_OK;
+}
+#define STAGE(name)                                       \
+  do {                                                    \
+    int _rc = stage_check(s, name, st);                   \
+    if (_rc != OLSR_OK) return _rc;                       \
+    mark(name, st);                                       \
+  } while (0)
+
+bool supported_F(int F) { return F == 0 || F == 3 || F == 15 || F == 16 || F == 32; }
+
+int check_scene(const olsr_scene* s, bool backward) {
+  if (!s) return fail(OLSR_ERR_ARG, "scene is NULL");
+  if (s->P < 0) return fail(OLSR_ERR_ARG, "P must be >= 0");
+  if (s->width <= 0 || s->height <= 0) return fail(OLSR_ERR_ARG, "image size must be positive");
+  if (s->tile != 15 && s->tile != 16) return fail(OLSR_ERR_ARG, "tile must be 15 or 16");
+  if (!supported_F(s->F)) return fail(OLSR_ERR_ARG, "F (language channels) must be one of 0, 3, 15, 16, 32");
+  if (s->D < 0 || s->D > 3) return fail(OLSR_ERR_ARG, "SH degree must be 0..3");
+  if (s->P == 0) return OLSR_OK;
+  if (!s->means3D || !s->background || !s->viewmatrix || !s->projmatrix || !s->cam_pos)
+    return fail(OLSR_ERR_ARG, "means3D, background, viewmatrix, projmatrix and cam_pos are required");
+  if (!backward && !s->opacities) return fail(OLSR_ERR_ARG, "opacities are required");
+  if ((s->shs == nullptr) == (s->colors_precomp == nullptr))
+    return fail(OLSR_ERR_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+  const bool has_sr = s->scales != nullptr && s->rotations != nullptr;
+  const bool any_sr = s->scales != nullptr || s->rotations != nullptr;
+  if ((!has_sr && !s->cov3D_precomp) || (any_sr && s->cov3D_precomp))
+    return fail(OLSR_ERR_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  if (s->shs && (s->M < (s->D + 1) * (s->D + 1))) return fail(OLSR_ERR_ARG, "shs holds fewer coefficients than the degree needs");
+  if (s->F > 0 && !s->language_precomp) return fail(OLSR_ERR_ARG, "language_precomp is required when F > 0");
+  if (backward && !s->projmatrix_raw) return fail(OLSR_ERR_ARG, "projmatrix_raw is required by backward");
+  return OLSR_OK;
+}
+
+FrameDims frame_dims(const olsr_scene& s) {
+  FrameDims d;
+  d.W = s.width;
+  d.H = s.height;
+  d.tile = s.tile;
+  d.gx = (s.width + s.tile - 1) / s.tile;
+  d.gy = (s.height + s.tile - 1) / s.tile;
+  d.ntiles = d.gx * d.gy;
+  d.focal_y = s.height / (2.0f * s.tan_fovy);  // CR/rasterizer_impl.cu:394-395
+  d.focal_x = s.width / (2.0f * s.tan_fovx);
+  return d;
+}
+
+int tile_bits(int ntiles) {
+  int bits = 1;
+  while ((1LL << bits) < (long long)ntiles) ++bits;
+  return bits;
+}
+// where the tile sort leaves its result: 0 = (key_a, src), 1 = (key_b, val_b)
+int tile_sort_where(int ntiles) { return ((tile_bits(ntiles) + 7) / 8) & 1; }
+
+struct BinningProvider {
+  olsr_alloc_fn fn = nullptr;
+  void* user = nullptr;
+  void* fixed = nullptr;
+  int64_t capacity = -1;  // async mode when >= 0
+};
+
+int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
+                 float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
+                 int32_t* num_rendered_host, int32_t* num_rendered_dev, hipStream_t st) {
+  const FrameDims d = frame_dims(s);
+  const size_t N = (size_t)d.W * d.H;
+  size_t gb, ib, bb;
+  const GeometryState g = GeometryState::carve(geom_buf, (size_t)s.P, gb);
+  const ImageState im = ImageState::carve(img_buf, N, (size_t)d.ntiles, ib);
+  if (g_profiling) marks_reset(st);
+  mark("begin", st);
+
+  if (!out_color || !out_depth || !out_opacity || (s.F > 0 && !out_language))
+    return fail(OLSR_ERR_ARG, "output image pointers must not be NULL");
+  if (s.P > 0 && (!radii || !n_touched)) return fail(OLSR_ERR_ARG, "radii and n_touched must not be NULL");
+
+  if (s.P > 0) HIP_TRY(hipMemsetAsync(n_touched, 0, sizeof(int32_t) * (size_t)s.P, st));
+  HIP_TRY(hipMemsetAsync(g.counters, 0, sizeof(int32_t) * 8, st));
+
+  int64_t n_host = 0;
+  BinningState b{};
+  if (s.P > 0) {
+    launch_preprocess(s, d, g, radii, st);
+    STAGE("preprocess");
+    SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
+    launch_radix_sort(sb, s.P, nullptr, 32, false, nullptr, nullptr, st);
+    STAGE("depth_sort");
+    launch_instance_offsets(g, s.P, bp.capacity >= 0 ? bp.capacity : 0x7FFFFFFFLL, st);
+    STAGE("instance_offsets");
+  }
+
+  void* bin_buf = nullptr;
+  if (bp.capacity >= 0) {
+    n_host = bp.capacity;
+    bin_buf = bp.fixed;
+  } else {
+    int32_t R = 0;
+    if (s.P > 0) {
+      HIP_TRY(hipMemcpyAsync(&R, g.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));  // the reference's blocking D2H, CR/rasterizer_impl.cu:454-455
+      if (R < 0) return fail(OLSR_ERR_CAPACITY, "instance count exceeds 2^31-1");
+    }
+    n_host = R;
+    if (num_rendered_host) *num_rendered_host = R;
+    const size_t need = olsr_binning_bytes(R, s.F);
+    bin_buf = bp.fn ? bp.fn(bp.user, need) : nullptr;
+    if (!bin_buf) return fail(OLSR_ERR_ALLOC, "binning allocation callback returned NULL");
+  }
+  b = BinningState::carve(bin_buf, (size_t)n_host, grad_row(s.F), bb);
+  const int32_t* n_dev = &g.counters[1];
+
+  const uint32_t* sorted_keys = b.key_a;
+  if (s.P > 0 && n_host > 0) {
+    launch_emit(s, d, g, radii, b, st);
+    HIP_TRY(hipMemsetAsync(b.flags, 0, (size_t)n_host, st));
+    STAGE("emit");
+    SortBuffers sb{b.key_a, b.key_b, b.src, b.val_b, b.radix_table, b.scan_partials};
+    const int where = launch_radix_sort(sb, n_host, n_dev, tile_bits(d.ntiles), true, b.inst_gid, b.point_list, st);
+    if (where) {
+      sorted_keys = b.key_b;
+      b.src = b.val_b;
+    }
+    STAGE("tile_sort");
+  }
+  launch_tile_ranges(sorted_keys, (s.P > 0) ? n_host : 0, n_dev, im.ranges, d.ntiles, st);
+  STAGE("tile_ranges");
+  launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, st);
+  STAGE("render_forward");
+
+  if (num_rendered_dev) {
+    HIP_TRY(hipMemcpyAsync(num_rendered_dev, &g.counters[0], sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(num_rendered_dev + 1, &g.counters[2], sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  }
+  (void)gb;
+  (void)ib;
+  (void)bb;
+  return OLSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t olsr_geometry_bytes(int32_t P, int32_t F) {
+  (void)F;
+  size_t bytes = 0;
+  GeometryState::carve(nullptr, (size_t)(P > 0 ? P : 0), bytes);
+  return bytes;
+}
+
+size_t olsr_image_bytes(int32_t width, int32_t height, int32_t tile) {
+  size_t bytes = 0;
+  if (tile <= 0) tile = 15;
+  const size_t tiles = (size_t)((width + tile - 1) / tile) * (size_t)((height + tile - 1) / tile);
+  ImageState::carve(nullptr, (size_t)width * (size_t)height, tiles, bytes);
+  return bytes;
+}
+
+size_t olsr_binning_bytes(int64_t num_rendered, int32_t F) {
+  size_t bytes = 0;
+  BinningState::carve(nullptr, (size_t)(num_rendered > 0 ? num_rendered : 0), grad_row(supported_F(F) ? F : 0), bytes);
+  return bytes;
+}
+
+int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* geometry_user,
+                 olsr_alloc_fn binning_alloc, void* binning_user, olsr_alloc_fn image_alloc, void* image_user,
+                 float* out_color, float* out_language, float* out_depth, float* out_opacity, int32_t* radii,
+                 int32_t* n_touched, int32_t* num_rendered, void* hip_stream) {
+  int rc = check_scene(scene, false);
+  if (rc != OLSR_OK) return rc;
+  if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(OLSR_ERR_ARG, "allocation callbacks are required");
+  void* geom = geometry_alloc(geometry_user, olsr_geometry_bytes(scene->P, scene->F));
+  if (!geom) return fail(OLSR_ERR_ALLOC, "geometry allocation callback returned NULL");
+  void* img = image_alloc(image_user, olsr_image_bytes(scene->width, scene->height, scene->tile));
+  if (!img) return fail(OLSR_ERR_ALLOC, "image allocation callback returned NULL");
+  BinningProvider bp;
+  bp.fn = binning_alloc;
+  bp.user = binning_user;
+  if (num_rendered) *num_rendered = 0;
+  return forward_impl(*scene, geom, img, bp, out_color, out_language, out_depth, out_opacity, radii, n_touched,
+                      num_rendered, nullptr, (hipStream_t)hip_stream);
+}
+
+int olsr_forward_async(const olsr_scene* scene, void* geometry_buffer, void* binning_buffer, int64_t capacity,
+                       void* image_buffer, float* out_color, float* out_language, float* out_depth, float* out_opacity,
+                       int32_t* radii, int32_t* n_touched, int32_t* num_rendered_dev, void* hip_stream) {
+  int rc = check_scene(scene, false);
+  if (rc != OLSR_OK) return rc;
+  if (!geometry_buffer || !binning_buffer || !image_buffer || capacity < 0)
+    return fail(OLSR_ERR_ARG, "state buffers and a non-negative capacity are required");
+  BinningProvider bp;
+  bp.fixed = binning_buffer;
+  bp.capacity = capacity;
+  return forward_impl(*scene, geometry_buffer, image_buffer, bp, out_color, out_language, out_depth, out_opacity,
+                      radii, n_touched, nullptr, num_rendered_dev, (hipStream_t)hip_stream);
+}
+
+int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_buffer, int32_t num_rendered,
+                  void* binning_buffer, const void* image_buffer, const float* dL_dout_color,
+                  const float* dL_dout_language, const float* dL_dout_depth, float* dL_dmeans2D, float* dL_dconic,
+                  float* dL_dopacity, float* dL_dcolors, float* dL_dlanguage, float* dL_ddepths, float* dL_dmeans3D,
+                  float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dtau,
+                  float* dL_dtau_sum, void* hip_stream) {
+  int rc = check_scene(scene, true);
+  if (rc != OLSR_OK) return rc;
+  const olsr_scene& s = *scene;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (s.bwd_mode != OLSR_BWD_REFERENCE && s.bwd_mode != OLSR_BWD_EXACT)
+    return fail(OLSR_ERR_ARG, "bwd_mode must be OLSR_BWD_REFERENCE or OLSR_BWD_EXACT");
+  if (g_profiling) marks_reset(st);
+  mark("begin", st);
+  if (s.P == 0) {
+    if (dL_dtau_sum) HIP_TRY(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), st));
+    return OLSR_OK;
+  }
+  if (!radii || !geometry_buffer || !binning_buffer || !image_buffer || num_rendered < 0)
+    return fail(OLSR_ERR_ARG, "radii, the three state buffers and num_rendered (>= 0) are required");
+  if (!dL_dout_color || !dL_dout_depth || (s.F > 0 && !dL_dout_language))
+    return fail(OLSR_ERR_ARG, "upstream gradients must not be NULL");
+  if (!dL_dmeans2D || !dL_dopacity || !dL_dcolors || (s.F > 0 && !dL_dlanguage) || !dL_dmeans3D || !dL_dcov3D ||
+      (s.M > 0 && !dL_dsh) || !dL_dscales || !dL_drotations || !dL_dtau)
+    return fail(OLSR_ERR_ARG, "gradient outputs must not be NULL");
+  const FrameDims d = frame_dims(s);
+  size_t gb, ib, bb;
+  const GeometryState g = GeometryState::carve(geometry_buffer, (size_t)s.P, gb);
+  const ImageState im = ImageState::carve(const_cast<void*>(image_buffer), (size_t)d.W * d.H, (size_t)d.ntiles, ib);
+  BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, grad_row(s.F), bb);
+  if (tile_sort_where(d.ntiles)) b.src = b.val_b;
+
+  if (s.bwd_mode == OLSR_BWD_REFERENCE)
+    launch_render_backward_reference(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, st);
+  else
+    launch_render_backward_exact(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, st);
+  STAGE("render_backward");
+  GradOut o{dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dlanguage, dL_ddepths, dL_dmeans3D,
+            dL_dcov3D,   dL_dsh,    dL_dscales,  dL_drotations, dL_dtau,    dL_dtau_sum};
+  launch_preprocess_backward(s, d, g, b, radii, o, g.tau_partials, st);
+  STAGE("preprocess_backward");
+  (void)gb;
+  (void)ib;
+  (void)bb;
+  return OLSR_OK;
+}
+
+int olsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present, void* hip_stream) {
+  (void)projmatrix;  // the reference computes p_hom and discards it (CR/auxiliary.h:149-151)
+  if (P < 0) return fail(OLSR_ERR_ARG, "P must be >= 0");
+  if (P == 0) return OLSR_OK;
+  if (!means3D || !viewmatrix || !present) return fail(OLSR_ERR_ARG, "means3D, viewmatrix and present are required");
+  launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("mark_visible launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
+const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t F, const char* name) {
+  (void)F;
+  size_t bytes;
+  const GeometryState g = GeometryState::carve(const_cast<void*>(geometry_buffer), (size_t)P, bytes);
+  if (!std::strcmp(name, "depths")) return g.depths;
+  if (!std::strcmp(name, "means2D")) return g.means2D;
+  if (!std::strcmp(name, "cov3D")) return g.cov3D;
+  if (!std::strcmp(name, "conic_opacity")) return g.conic_opacity;
+  if (!std::strcmp(name, "rgb")) return g.rgb;
+  if (!std::strcmp(name, "clamped")) return g.clamped;
+  if (!std::strcmp(name, "tiles_touched")) return g.tiles_touched;
+  if (!std::strcmp(name, "depth_order")) return g.depth_order;
+  if (!std::strcmp(name, "offsets")) return g.offsets;
+  if (!std::strcmp(name, "counters")) return g.counters;
+  return nullptr;
+}
+
+const void* olsr_binning_field(const void* binning_buffer, int64_t num_rendered, int32_t F, const char* name) {
+  size_t bytes;
+  const BinningState b =
+      BinningState::carve(const_cast<void*>(binning_buffer), (size_t)num_rendered, grad_row(supported_F(F) ? F : 0), bytes);
+  if (!std::strcmp(name, "point_list")) return b.point_list;
+  if (!std::strcmp(name, "inst_gid")) return b.inst_gid;
+  if (!std::strcmp(name, "flags")) return b.flags;
+  if (!std::strcmp(name, "rows")) return b.rows;
+  if (!std::strcmp(name, "key_a")) return b.key_a;
+  if (!std::strcmp(name, "key_b")) return b.key_b;
+  if (!std::strcmp(name, "src")) return b.src;
+  if (!std::strcmp(name, "val_b")) return b.val_b;
+  return nullptr;
+}
+
+const void* olsr_image_field(const void* image_buffer, int32_t width, int32_t height, int32_t tile, const char* name) {
+  size_t bytes;
+  if (tile <= 0) tile = 15;
+  const size_t tiles = (size_t)((width + tile - 1) / tile) * (size_t)((height + tile - 1) / tile);
+  const ImageState im = ImageState::carve(const_cast<void*>(image_buffer), (size_t)width * height, tiles, bytes);
+  if (!std::strcmp(name, "final_T")) return im.final_T;
+  if (!std::strcmp(name, "n_contrib")) return im.n_contrib;
+  if (!std::strcmp(name, "ranges")) return im.ranges;
+  return nullptr;
+}
+
+void olsr_set_profiling(int enable) { g_profiling = enable != 0; }
+
+int olsr_get_stage_times(const char** names, float* ms, int max) {
+  if (g_marks.size() < 2) return 0;
+  (void)hipStreamSynchronize(g_mark_stream);
+  int n = 0;
+  for (size_t i = 1; i < g_marks.size() && n < max; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_marks[i - 1].ev, g_marks[i].ev) != hipSuccess) t = -1.f;
+    names[n] = g_marks[i].name;
+    ms[n] = t;
+    ++n;
+  }
+  return n;
+}
+
+const char* olsr_last_error(void) { return g_err.c_str(); }
+const char* olsr_version(void) { return "olsr 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// olsr_device.h — device-side helpers shared by the gfx950 kernels.
+//
+// Numerics contract: every expression on a decision path (culling, tile
+// rectangle, alpha / transmittance thresholds) is strict IEEE fp32 in the reference's source
+// order; the build uses -ffp-contract=off so nothing is fused implicitly, and FMAs appear
+// only where written (__builtin_fmaf).  `exp` is the fully specified routine below (the same
+// constants and operation sequence the CPU oracle pins), because the reference's CUDA libm
+// bits cannot be reproduced by any other libm.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace olsr {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+// ---- wave64 helpers ---------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return ballot(p) != 0ull; }
+__device__ __forceinline__ bool wave_all(bool p) { return ballot(!p) == 0ull; }
+
+__device__ __forceinline__ float bits2f(u32 u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ u32 f2bits(float f) { return __builtin_bit_cast(u32, f); }
+
+// ---- pinned exp --------------------------------------------------------------------------
+// Cephes-style expf: n = rne(x*log2e); r = x - n*ln2 (two-term); degree-5 polynomial;
+// scale by 2^n.  Clamped to [-87, 88] so 2^n is a normal number.
+__device__ __forceinline__ float pinned_expf(float x) {
+  x = (x < -87.0f) ? -87.0f : x;
+  x = (x > 88.0f) ? 88.0f : x;
+  float n = __builtin_rintf(x * 1.44269504088896341f);
+  float r = __builtin_fmaf(n, -0.693359375f, x);
+  r = __builtin_fmaf(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  float e = __builtin_fmaf(p, r * r, r) + 1.0f;
+  int ni = (int)n;
+  return e * bits2f((u32)(ni + 127) << 23);
+}
+
+// float -> int, truncating and saturating (v_cvt_i32_f32 semantics; NaN -> 0), written out
+// so that the conversion is defined for every input.
+__device__ __forceinline__ int f2i_sat(float v) {
+  if (v != v) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (int)0x80000000;
+  return (int)v;
+}
+
+__device__ __forceinline__ float fminf_ref(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
+__device__ __forceinline__ float fmaxf_ref(float a, float b) { return (a < b) ? b : a; }  // std::max(a,b)
+
+// ---- geometry helpers (CR/auxiliary.h:41-97) ---------------------------------------------
+__device__ __forceinline__ float ndc2Pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+struct Rect { int x0, y0, x1, y1; };
+template <int TILE>
+__device__ __forceinline__ Rect get_rect(float px, float py, int max_radius, int gx, int gy) {
+  Rect r;
+  r.x0 = min(gx, max(0, f2i_sat((px - (float)max_radius) / (float)TILE)));
+  r.y0 = min(gy, max(0, f2i_sat((py - (float)max_radius) / (float)TILE)));
+  r.x1 = min(gx, max(0, f2i_sat((px + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
+  r.y1 = min(gy, max(0, f2i_sat((py + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
+  return r;
+}
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ f3 transformPoint4x3(const f3& p, const float* m) {
+  return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+          m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+}
+__device__ __forceinline__ f4 transformPoint4x4(const f3& p, const float* m) {
+  return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+          m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]};
+}
+__device__ __forceinline__ f3 transformVec4x3Transpose(const f3& p, const float* m) {
+  return {m[0] * p.x + m[1] * p.y + m[2] * p.z, m[4] * p.x + m[5] * p.y + m[6] * p.z,
+          m[8] * p.x + m[9] * p.y + m[10] * p.z};
+}
+
+// column-major 3x3 with glm's accumulation order: (a*b)[c][r] = a[0][r]b[c][0] + a[1][r]b[c][1] + a[2][r]b[c][2]
+struct m3 { float c[3][3]; };
+__device__ __forceinline__ m3 mul(const m3& a, const m3& b) {
+  m3 o;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o.c[c][r] = a.c[0][r] * b.c[c][0] + a.c[1][r] * b.c[c][1] + a.c[2][r] * b.c[c][2];
+  return o;
+}
+__device__ __forceinline__ m3 transpose(const m3& a) {
+  m3 o;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o.c[c][r] = a.c[r][c];
+  return o;
+}
+
+// Shared by forward preprocess and the backward recomputation (CR/forward.cu:77-116,
+// CR/backward.cu:171-206).
+struct Cov2D {
+  f3 t;
+  float txtz, tytz;
+  m3 J, Wm, T, Vrk, cov;
+};
+__device__ __forceinline__ void cov2d_common(const f3& mean, float focal_x, float focal_y, float tan_fovx,
+                                             float tan_fovy, const float* cov3D, const float* view, Cov2D& o) {
+  f3 t = transformPoint4x3(mean, view);
+  const float limx = 1.3f * tan_fovx;
+  const float limy = 1.3f * tan_fovy;
+  o.txtz = t.x / t.z;
+  o.tytz = t.y / t.z;
+  t.x = fminf_ref(limx, fmaxf_ref(-limx, o.txtz)) * t.z;
+  t.y = fminf_ref(limy, fmaxf_ref(-limy, o.tytz)) * t.z;
+  o.t = t;
+  o.J = {{{focal_x / t.z, 0.0f, -(focal_x * t.x) / (t.z * t.z)},
+          {0.0f, focal_y / t.z, -(focal_y * t.y) / (t.z * t.z)},
+          {0.0f, 0.0f, 0.0f}}};
+  o.Wm = {{{view[0], view[4], view[8]}, {view[1], view[5], view[9]}, {view[2], view[6], view[10]}}};
+  o.T = mul(o.Wm, o.J);
+  o.Vrk = {{{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}}};
+  o.cov = mul(mul(transpose(o.T), transpose(o.Vrk)), o.T);
+}
+
+// SH constants, CR/auxiliary.h:22-39
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// XCD-aware tile remap: workgroup b is observed to run on XCD b % 8; give each XCD a
+// contiguous run of tiles so neighbouring tiles (which share Gaussians) share an L2.
+// Bijective for any n (cdna_hip_programming.md §5 "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = b & 7, k = b >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + k;
+}
+
+constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// staged per-Gaussian feature row: [r, g, b, depth, lang[F]] padded to a multiple of 4 floats
+constexpr int feat_row(int F) { return round_up(4 + F, 4); }
+// partial-gradient row written per (tile, Gaussian) instance by the backward composite:
+// [mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, r, g, b, depth, lang[F]] padded to 16 floats
+constexpr int grad_row(int F) { return round_up(10 + F, 16); }
+
+}  // namespace olsr

@@ -1,0 +1,60 @@
+// olsr_kernels.h — host-side launchers of the gfx950 kernels (one translation unit each).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/olsr.h"
+#include "olsr_state.h"
+
+namespace olsr {
+
+struct FrameDims {
+  int W, H, tile, gx, gy, ntiles;
+  float focal_x, focal_y;
+};
+
+// k_preprocess.hip
+void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometryState& g, int32_t* radii,
+                       hipStream_t st);
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
+
+// k_binning.hip
+// Stable LSD radix sort of (key, val) on `bits` low bits of key, 8 bits per pass.
+// n_dev (nullable) bounds the element count on the device; n_host sizes the grid.
+struct SortBuffers {
+  uint32_t *key_a, *key_b, *val_a, *val_b, *table, *partials;
+};
+// Returns 0 if the result ends in (key_a,val_a), 1 if in (key_b,val_b).
+int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
+                      const uint32_t* final_gather, uint32_t* final_gather_out, hipStream_t st);
+void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, hipStream_t st);
+void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
+                 const BinningState& b, hipStream_t st);
+void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
+                        int ntiles, hipStream_t st);
+
+// k_render_fwd.hip
+void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                           const ImageState& im, float* out_color, float* out_language, float* out_depth,
+                           float* out_opacity, int32_t* n_touched, hipStream_t st);
+
+// k_render_bwd.hip
+// (two translation units, one per backward mode, so they compile in parallel)
+void launch_render_backward_reference(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+                                      const BinningState& b, const ImageState& im, const float* dL_dcolor,
+                                      const float* dL_dlanguage, const float* dL_ddepth, hipStream_t st);
+void launch_render_backward_exact(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+                                  const BinningState& b, const ImageState& im, const float* dL_dcolor,
+                                  const float* dL_dlanguage, const float* dL_ddepth, hipStream_t st);
+
+// k_preprocess_bwd.hip
+struct GradOut {
+  float *dL_dmeans2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_dlanguage, *dL_ddepths, *dL_dmeans3D, *dL_dcov3D,
+      *dL_dsh, *dL_dscales, *dL_drotations, *dL_dtau, *dL_dtau_sum;
+};
+void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+                                const BinningState& b, const int32_t* radii, const GradOut& o, float* tau_partials,
+                                hipStream_t st);
+int tau_partial_blocks(int P);
+
+}  // namespace olsr

@@ -1,0 +1,134 @@
+// olsr_state.h — layout of the three opaque state buffers in HBM.
+//
+// Counterpart of GeometryState / ImageState / BinningState (CR/rasterizer_impl.h:31-81,
+// CR/rasterizer_impl.cu:155-212).  The buffers only need to be self-consistent between a
+// forward and its backward; the layout is MI355X-first (struct-of-arrays, every array on a
+// 256-byte boundary so wave-wide accesses start on a full cache line):
+//
+//   geometry  — per-Gaussian results of preprocess, the depth order, instance offsets and the
+//               radix-sort scratch for the P-sized depth sort.
+//   image     — final transmittance, last-contributor index, per-tile ranges.
+//   binning   — per-instance arrays: tile keys (ping/pong), sorted Gaussian list, the
+//               sorted->emission map `src`, per-instance contribution flags (written by the
+//               forward composite) and the partial-gradient rows the backward composite
+//               writes for the per-Gaussian reduction.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace olsr {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+// elements handled by one block of the radix passes / scans
+constexpr int SORT_CHUNK = 4096;
+constexpr int SCAN_CHUNK = 4096;
+inline int sort_blocks(long long n) { return (int)((n + SORT_CHUNK - 1) / SORT_CHUNK); }
+inline int scan_blocks(long long n) { return (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK); }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  // a non-null base is rounded up to ALIGN (total() reserves the slack)
+  explicit Carver(void* b) : base(b ? (char*)(((uintptr_t)b + ALIGN - 1) / ALIGN * ALIGN) : nullptr) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off);
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+  size_t total() const { return align_up(off) + ALIGN; }
+};
+
+struct GeometryState {
+  float* depths;          // [P]
+  float* means2D;         // [P][2]
+  float* conic_opacity;   // [P][4]
+  float* cov3D;           // [P][6]
+  float* rgb;             // [P][3]
+  uint8_t* clamped;       // [P][3]
+  uint32_t* tiles_touched;  // [P]
+  uint32_t* key_a;        // [P] depth keys (ping)
+  uint32_t* key_b;        // [P] (pong)
+  uint32_t* val_a;        // [P] Gaussian ids (ping)
+  uint32_t* val_b;        // [P] (pong)
+  uint32_t* depth_order;  // alias of the buffer holding the final order (val_a after 4 passes)
+  uint32_t* offsets;      // [P] inclusive scan of tiles_touched in depth order
+  uint32_t* radix_table;  // [256 * sort_blocks(P)]
+  uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
+  int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag
+  float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
+  static GeometryState carve(void* buf, size_t P, size_t& bytes) {
+    Carver c(buf);
+    GeometryState g;
+    g.depths = c.take<float>(P);
+    g.means2D = c.take<float>(2 * P);
+    g.conic_opacity = c.take<float>(4 * P);
+    g.cov3D = c.take<float>(6 * P);
+    g.rgb = c.take<float>(3 * P);
+    g.clamped = c.take<uint8_t>(3 * P);
+    g.tiles_touched = c.take<uint32_t>(P);
+    g.key_a = c.take<uint32_t>(P);
+    g.key_b = c.take<uint32_t>(P);
+    g.val_a = c.take<uint32_t>(P);
+    g.val_b = c.take<uint32_t>(P);
+    g.depth_order = g.val_a;
+    g.offsets = c.take<uint32_t>(P);
+    const size_t table = 256 * (size_t)sort_blocks((long long)P);
+    g.radix_table = c.take<uint32_t>(table);
+    g.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)(table > P ? table : P)) + 1);
+    g.counters = c.take<int32_t>(8);
+    g.tau_partials = c.take<float>(6 * ((P + 127) / 128) + 6);
+    bytes = c.total();
+    return g;
+  }
+};
+
+struct ImageState {
+  float* final_T;       // [H*W]
+  uint32_t* n_contrib;  // [H*W]
+  uint32_t* ranges;     // [tiles][2]
+  static ImageState carve(void* buf, size_t N, size_t tiles, size_t& bytes) {
+    Carver c(buf);
+    ImageState s;
+    s.final_T = c.take<float>(N);
+    s.n_contrib = c.take<uint32_t>(N);
+    s.ranges = c.take<uint32_t>(2 * tiles);
+    bytes = c.total();
+    return s;
+  }
+};
+
+struct BinningState {
+  uint32_t* key_a;       // [R] tile id per instance in emission order (ping)
+  uint32_t* key_b;       // [R] (pong)
+  uint32_t* val_b;       // [R] emission index after pass 1
+  uint32_t* src;         // [R] sorted position -> emission index
+  uint32_t* point_list;  // [R] sorted position -> Gaussian id
+  uint32_t* inst_gid;    // [R] emission index -> Gaussian id
+  uint8_t* flags;        // [R] emission index -> "some pixel of the tile used this instance"
+  uint32_t* radix_table;   // [256 * sort_blocks(R)]
+  uint32_t* scan_partials; // [scan_blocks(table) + 1]
+  float* rows;           // [R][grad_row(F)] partial gradients, emission order
+  static BinningState carve(void* buf, size_t R, int grad_row_floats, size_t& bytes) {
+    Carver c(buf);
+    BinningState b;
+    b.key_a = c.take<uint32_t>(R);
+    b.key_b = c.take<uint32_t>(R);
+    b.val_b = c.take<uint32_t>(R);
+    b.src = c.take<uint32_t>(R);
+    b.point_list = c.take<uint32_t>(R);
+    b.inst_gid = c.take<uint32_t>(R);
+    b.flags = c.take<uint8_t>(R);
+    const size_t table = 256 * (size_t)sort_blocks((long long)R);
+    b.radix_table = c.take<uint32_t>(table);
+    b.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)table) + 1);
+    b.rows = c.take<float>(R * (size_t)grad_row_floats);
+    bytes = c.total();
+    return b;
+  }
+};
+
+}  // namespace olsr

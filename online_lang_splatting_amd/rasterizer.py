@@ -1,0 +1,166 @@
+"""Drop-in Python API of `diff_gaussian_rasterization` on the MI355X-native library.
+
+Public surface, argument meaning, return arity/order and error behaviour follow
+DGR/diff_gaussian_rasterization/__init__.py (settings tuple :405-419, modules :421-576,
+autograd bridges :79-202 and :205-403):
+
+    GaussianRasterizationSettings, GaussianRasterizer, LanguageGaussianRasterizer
+
+so gaussian_splatting/gaussian_renderer/__init__.py runs against it unmodified.  Backward
+ignores the cotangents of radii / opacity / n_touched exactly like the reference (:296,
+:317-345), and returns gradients in the reference's input order.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    projmatrix_raw: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _settings_args(rs):
+    return (rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, rs.tanfovx, rs.tanfovy)
+
+
+def _split_tau(grad_tau):
+    """[P,6] -> (grad_theta[1,3], grad_rho[1,3]); dL_dtau = [rho | theta] per Gaussian (:383-385)."""
+    tau = torch.sum(grad_tau.view(-1, 6), dim=0)
+    return tau[3:].view(1, -1), tau[:3].view(1, -1)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """RGB + depth + opacity rasterization (reference :79-202)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
+                raster_settings):
+        rs = raster_settings
+        (num_rendered, color, radii, geom, binning, img, depth, opacity, n_touched) = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            *_settings_args(rs), rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
+            rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii, n_touched)
+        return color, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_radii, grad_out_depth, grad_out_opacity, grad_n_touched):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_tau) = _C.rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            *_settings_args(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
+            binning, img, rs.debug)
+        grad_theta, grad_rho = _split_tau(grad_tau)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
+
+
+class _RasterizeLanguageGaussians(torch.autograd.Function):
+    """RGB + language + depth + opacity rasterization (reference :205-403)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, language_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, theta, rho, raster_settings):
+        rs = raster_settings
+        (num_rendered, color, language, radii, geom, binning, img, depth, opacity,
+         n_touched) = _C.rasterize_language_gaussians(
+            rs.bg, means3D, colors_precomp, language_precomp, opacities, scales, rotations, rs.scale_modifier,
+            cov3Ds_precomp, *_settings_args(rs), rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+            rs.prefiltered, rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, language_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+                              geom, binning, img)
+        ctx.mark_non_differentiable(radii, n_touched)
+        return color, language, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_language, grad_out_radii, grad_out_depth, grad_out_opacity,
+                 grad_n_touched):
+        rs = ctx.raster_settings
+        (colors_precomp, language_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
+         img) = ctx.saved_tensors
+        (grad_means2D, grad_colors_precomp, grad_language_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
+         grad_sh, grad_scales, grad_rotations, grad_tau) = _C.rasterize_language_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, language_precomp, scales, rotations, rs.scale_modifier,
+            cov3Ds_precomp, *_settings_args(rs), grad_out_color, grad_out_language, grad_out_depth, sh, rs.sh_degree,
+            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug)
+        grad_theta, grad_rho = _split_tau(grad_tau)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_language_precomp, grad_opacities,
+                grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, theta, rho, raster_settings)
+
+
+def rasterize_language_gaussians(means3D, means2D, sh, colors_precomp, language_precomp, opacities, scales, rotations,
+                                 cov3Ds_precomp, theta, rho, raster_settings):
+    return _RasterizeLanguageGaussians.apply(means3D, means2D, sh, colors_precomp, language_precomp, opacities,
+                                             scales, rotations, cov3Ds_precomp, theta, rho, raster_settings)
+
+
+def _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    """The two argument-exclusivity rules of the reference, with its messages (:441-445, :515-528)."""
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+
+
+def _or_empty(t):
+    return torch.Tensor([]) if t is None else t
+
+
+class _RasterizerBase(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of points in front of the near plane (reference :426-435, :487-496)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+
+class GaussianRasterizer(_RasterizerBase):
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, theta=None, rho=None):
+        _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        return rasterize_gaussians(means3D, means2D, _or_empty(shs), _or_empty(colors_precomp), opacities,
+                                   _or_empty(scales), _or_empty(rotations), _or_empty(cov3D_precomp), _or_empty(theta),
+                                   _or_empty(rho), self.raster_settings)
+
+
+class LanguageGaussianRasterizer(_RasterizerBase):
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, language_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None, theta=None, rho=None):
+        _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        return rasterize_language_gaussians(means3D, means2D, _or_empty(shs), _or_empty(colors_precomp),
+                                            _or_empty(language_precomp), opacities, _or_empty(scales),
+                                            _or_empty(rotations), _or_empty(cov3D_precomp), _or_empty(theta),
+                                            _or_empty(rho), self.raster_settings)

@@ -1,0 +1,82 @@
+"""Shared helpers of the parity tests: run the same seeded scene through the CPU oracle
+(oracle/oracle_C.py) and through the HIP library (online_lang_splatting_amd/_C.py) at the
+`_C` level, i.e. with the reference's own positional signatures (DGR/rasterize_points.h)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from online_lang_splatting_amd.scene import make_scene  # noqa: E402
+
+EMPTY = torch.empty(0)
+
+
+def fwd_args(sc, dev=None, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0, prefiltered=False,
+             debug=False):
+    """Positional args of rasterize_language_gaussians / rasterize_gaussians (minus `language` for F == 0)."""
+    cam = sc.camera
+
+    def mv(t):
+        if t is None:
+            return torch.empty(0, device=dev) if dev is not None else torch.empty(0)
+        return t.to(dev) if dev is not None else t
+    shs = None if colors_precomp is not None else sc.shs
+    scales = None if cov3D_precomp is not None else sc.scales
+    rots = None if cov3D_precomp is not None else sc.rotations
+    a = [mv(sc.bg), mv(sc.means3D), mv(colors_precomp)]
+    if sc.F > 0:
+        a.append(mv(sc.language))
+    a += [mv(sc.opacities), mv(scales), mv(rots), scale_modifier, mv(cov3D_precomp), mv(cam.world_view_transform),
+          mv(cam.full_proj_transform), mv(cam.projection_matrix), cam.tanfovx, cam.tanfovy, cam.height, cam.width,
+          mv(shs), sc.sh_degree, mv(cam.camera_center), prefiltered, debug]
+    return a
+
+
+def run_backend(C, sc, dev=None, seed=0, tile=15, mode=0, **kw):
+    """Forward + backward through backend module C (oracle_C or the product _C).  Returns (fwd dict, grads dict)."""
+    C.TILE = tile
+    C.BWD_MODE = mode
+    F = sc.F
+    a = fwd_args(sc, dev, **kw)
+    if F > 0:
+        R, color, lang, radii, geom, binb, img, depth, opac, nt = C.rasterize_language_gaussians(*a)
+    else:
+        R, color, radii, geom, binb, img, depth, opac, nt = C.rasterize_gaussians(*a)
+        lang = None
+    fwd = dict(R=R, color=color, language=lang, radii=radii, depth=depth, opacity=opac, n_touched=nt, geom=geom,
+               binning=binb, img=img)
+    dc, dl, dd = sc.cotangents(seed)
+    mv = (lambda t: None if t is None else t.to(dev)) if dev is not None else (lambda t: t)
+    off = 1 if F > 0 else 0
+    # backward positional args (DGR/rasterize_points.h): bg, means3D, radii, colors, [language], scales, rotations,
+    # scale_modifier, cov3D_precomp, view, proj, proj_raw, tanx, tany, dL_dcolor, [dL_dlang], dL_ddepth, sh, degree,
+    # campos, geom, R, binning, img, debug
+    b = [a[0], a[1], radii, a[2]]
+    if F > 0:
+        b.append(a[3])
+    b += [a[4 + off], a[5 + off], a[6 + off], a[7 + off], a[8 + off], a[9 + off], a[10 + off], a[11 + off],
+          a[12 + off], mv(dc)]
+    if F > 0:
+        b.append(mv(dl))
+    b += [mv(dd), a[15 + off], a[16 + off], a[17 + off], geom, R, binb, img, False]
+    if F > 0:
+        grads = C.backward_all(F, *b)
+    else:
+        b2 = list(b)
+        b2.insert(4, None)   # language slot
+        b2.insert(15, None)  # dL_dout_language slot
+        grads = C.backward_all(0, *b2)
+    return fwd, grads
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b| (scale-relative) and the plain max abs error."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if a.numel() == 0:
+        return 0.0, 0.0
+    err = (a - b).abs().max().item()
+    return err / (b.abs().max().item() + 1e-30), err
