@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: language-Gaussian rasterizer forward+backward frames/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3]
+
+A "step" is one pass of the hot path over one frame: forward (preprocess, depth sort, binning,
+tile sort, composite) + backward (composite backward, per-Gaussian backward) of BASELINE.json's
+config 3 — 500 k Gaussians, 1200x680, RGB + depth + 15 language channels — through the
+sync-free C-ABI entry points (olsr_forward_async / olsr_backward) with every input already
+resident in HBM, plus the accumulation of the view's gradients into the flat per-Gaussian
+gradient buffer.  With N > 1 (one process per GPU, torch.distributed over RCCL) every rank
+renders its own viewpoint of the same Gaussians per step and the step ends with the one
+all-reduce of the shared-Gaussian gradient buffer (frame sharding, weak scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against the 8 TB/s HBM
+peak using the algorithmic byte model of DESIGN.md §6 and its duration measured with HIP
+events on the launch stream over the timed region; `cpu_baseline` is the CPU oracle (a port —
+the reference has no CPU path) on one full frame of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from online_lang_splatting_amd import _abi, _lib  # noqa: E402
+from online_lang_splatting_amd.frame_shard import FrameShardedStep, RasterWorkspace  # noqa: E402
+from online_lang_splatting_amd.scene import CONFIGS, arc_cameras, make_scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(P, R, N, C=3, F=15, M=1):
+    """SURVEY.md §8(d) / DESIGN.md §6 byte model, per frame and per dominant stage."""
+    per = {
+        "frame": (466 + 8 * C + 4 * F + 48 * M) * P + (136 + 12 * C + 12 * F) * R + (28 + 8 * C + 8 * F) * N,
+        # forward composite: per-instance gather (id 4 + xy 8 + conic/opacity 16 + depth 4 + colour 4C + lang 4F)
+        # + per-pixel outputs (colour 4C, lang 4F, depth 4, opacity 4, T 4, n_contrib 4)
+        "render_forward": (32 + 4 * C + 4 * F) * R + (16 + 4 * C + 4 * F) * N,
+        # backward composite: the same gather + the partial-gradient row 4(7+C+F) per instance
+        # + per-pixel dL_dpix (4C+4F+4), T 4, n_contrib 4
+        "render_backward": (60 + 8 * C + 8 * F) * R + (12 + 4 * C + 4 * F) * N,
+    }
+    return per
+
+
+def device_inputs(sc, cam, dev):
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev),
+             language=None if sc.language is None else sc.language.to(dev))
+    c = dict(viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+             projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+             tanfovy=cam.tanfovy)
+    return g, c
+
+
+def cpu_baseline(sc, seed):
+    """The oracle (port) on one full frame, forward+backward, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_common import run_backend
+    from oracle import oracle_C as O
+    threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    fo, _ = run_backend(O, sc, None, seed, 15, _abi.BWD_REFERENCE)
+    dt = time.perf_counter() - t0
+    O.release(fo["geom"])
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 full frame of the same workload (P={sc.P}, R={fo['R']}), forward+backward, "
+                      f"OpenMP over tiles/Gaussians, {dt:.2f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="reference", choices=["reference", "exact"])
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    cfg = CONFIGS[a.config]
+    P, W, H, F = cfg["P"], cfg["W"], cfg["H"], cfg["F"]
+    sc = make_scene(P, W, H, F, seed=a.config, max_sh_degree=cfg["max_sh_degree"])
+    M = sc.shs.shape[1]
+    cams = arc_cameras(W, H, n=max(world, 1))  # n == 1 -> the identity pose of config 3
+    g_dev, _ = device_inputs(sc, cams[0], dev)
+    cam_dev = [device_inputs(sc, c, dev)[1] for c in cams]
+    dc, dl, dd = [None if t is None else t.to(dev) for t in sc.cotangents(a.config)]
+    mode = _abi.BWD_REFERENCE if a.mode == "reference" else _abi.BWD_EXACT
+
+    # size the instance capacity from one synchronous forward of this rank's view
+    from online_lang_splatting_amd import _C
+    my_view = rank % len(cams)
+    c0 = cam_dev[my_view]
+    r = _C.rasterize_language_gaussians(g_dev["bg"], g_dev["means3D"], torch.empty(0, device=dev), g_dev["language"],
+                                        g_dev["opacities"], g_dev["scales"], g_dev["rotations"], 1.0,
+                                        torch.empty(0, device=dev), c0["viewmatrix"], c0["projmatrix"],
+                                        c0["projmatrix_raw"], c0["tanfovx"], c0["tanfovy"], H, W, g_dev["shs"],
+                                        sc.sh_degree, c0["campos"], False, False) if F > 0 else \
+        _C.rasterize_gaussians(g_dev["bg"], g_dev["means3D"], torch.empty(0, device=dev), g_dev["opacities"],
+                               g_dev["scales"], g_dev["rotations"], 1.0, torch.empty(0, device=dev), c0["viewmatrix"],
+                               c0["projmatrix"], c0["projmatrix_raw"], c0["tanfovx"], c0["tanfovy"], H, W,
+                               g_dev["shs"], sc.sh_degree, c0["campos"], False, False)
+    R = int(r[0])
+    del r
+    capacity = int(R * 1.25) + (1 << 16)
+    ws = RasterWorkspace(P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode)
+    step = FrameShardedStep(ws, rank=rank, world=world)
+
+    def cot(_v, _out):
+        return dc, dl, dd
+
+    def one_step():
+        # every rank renders exactly one view per step (weak scaling): its own
+        step.bucket.zero_()
+        ws.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
+        out = ws.forward()
+        g = ws.backward(dc, dl, dd)
+        step.bucket.accumulate(g, out["radii"])
+        step.bucket.all_reduce()
+
+    for _ in range(a.warmup):
+        one_step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    _lib.set_profiling(rank == 0)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    stages = _lib.stage_times() if rank == 0 else []
+    _lib.set_profiling(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    Rr, overflow = ws.rendered()
+
+    if rank == 0:
+        frames = world * a.steps
+        fps = frames / elapsed
+        per_stage = {}
+        for name, ms in stages:
+            per_stage.setdefault(name, []).append(ms)
+        avg = {k: sum(v) / len(v) for k, v in per_stage.items()}
+        N = W * H
+        model = algorithmic_bytes(P, Rr, N, 3, F, M)
+        comp = {k: avg[k] for k in ("render_forward", "render_backward") if k in avg}
+        dom = max(comp, key=comp.get) if comp else None
+        roof = None
+        if dom:
+            achieved = model[dom] / (avg[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(model[dom]), "avg_launch_ms": round(avg[dom], 4)}
+        gpu_ms = sum(avg.values())
+        frame = {"algorithmic_bytes": int(model["frame"]),
+                 "achieved_GBs_wall": round(model["frame"] * fps / world / 1e9, 2),
+                 "frac_of_8TBs_wall": round(model["frame"] * fps / world / 1e9 / HBM_PEAK_GBS, 5),
+                 "gpu_stage_ms_sum": round(gpu_ms, 4)}
+        out = {
+            "metric": "rasterizer fwd+bwd frames/sec @500k Gaussians, 1200x680, 15-dim lang"
+                      if a.config == 3 else f"rasterizer fwd+bwd frames/sec, config {a.config}",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{a.config - 1}]: {P} Gaussians, {W}x{H}, RGB+depth+{F} "
+                                   f"language channels, forward+backward, tile 15, backward mode {a.mode}",
+                       "P": P, "width": W, "height": H, "F": F, "R": Rr, "R_over_P": round(Rr / max(P, 1), 3),
+                       "views_per_step": world, "parallelism": f"frame-shard x{world}",
+                       "capacity_overflow": overflow},
+            "roofline": roof,
+            "stage_ms": {k: round(v, 4) for k, v in avg.items()},
+            "frame_model": frame,
+            "target": {"fps": 40.0, "met": fps / world >= 40.0},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, a.config)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

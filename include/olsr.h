@@ -121,8 +121,9 @@ int olsr_forward_async(const olsr_scene *scene,
 /* Backward.  Replaces RasterizeGaussiansBackwardCUDA / RasterizeLanguageGaussiansBackwardCUDA ->
  * Rasterizer::backward / LanguageRasterizer::backward
  * (DGR/rasterize_points.cu:243-331,333-455; CR/rasterizer_impl.cu:529-636,638-756).
- * `num_rendered` is the R returned by the forward (ignored, may be -1, when the
- * buffers come from olsr_forward_async).  Gradient outputs, all fully overwritten:
+ * `num_rendered` is the R returned by olsr_forward — or, for buffers filled by
+ * olsr_forward_async, the `capacity` that call was given (it fixes the carving of the
+ * binning buffer).  Gradient outputs, all fully overwritten:
  *   dL_dmeans2D[P,3]  dL_dcolors[P,3]  dL_dlanguage[P,F]  dL_dopacity[P]
  *   dL_dmeans3D[P,3]  dL_dcov3D[P,6]   dL_dsh[P,M,3]      dL_dscales[P,3]
  *   dL_drotations[P,4]  dL_dtau[P,6]
@@ -160,9 +161,11 @@ const void *olsr_binning_field(const void *binning_buffer, int64_t num_rendered,
 const void *olsr_image_field(const void *image_buffer, int32_t width, int32_t height, int32_t tile,
                              const char *name);
 
-/* Per-stage HIP-event timing of the most recent forward/backward on this thread
- * (enabled with olsr_set_profiling(1); adds event records, no syncs).  names/ms
- * receive up to `max` entries; returns the count.  Synchronises the stream. */
+/* Per-stage HIP-event timing (events recorded on the stream the kernels run on).
+ * olsr_set_profiling(1) clears the log and starts recording one event per stage of every
+ * forward/backward issued by this thread (no synchronisation is added);
+ * olsr_get_stage_times waits for the last event and returns, in issue order, one
+ * (stage name, milliseconds) entry per stage executed since then (up to `max`). */
 void olsr_set_profiling(int enable);
 int olsr_get_stage_times(const char **names, float *ms, int max);
 

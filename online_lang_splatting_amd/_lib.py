@@ -68,9 +68,14 @@ def check(rc):
         raise OlsrError(rc, lib().olsr_last_error().decode())
 
 
-def stage_times():
-    """[(stage name, milliseconds)] of the most recent profiled forward/backward on this thread."""
-    names = (C.c_char_p * 32)()
-    ms = (C.c_float * 32)()
-    n = lib().olsr_get_stage_times(names, ms, 32)
+def stage_times(max_entries=1 << 16):
+    """[(stage name, milliseconds)] for every stage issued on this thread since
+    olsr_set_profiling(1), in issue order."""
+    names = (C.c_char_p * max_entries)()
+    ms = (C.c_float * max_entries)()
+    n = lib().olsr_get_stage_times(names, ms, max_entries)
     return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+
+def set_profiling(enable):
+    lib().olsr_set_profiling(1 if enable else 0)

@@ -40,13 +40,13 @@ int fail(int code, const std::string& msg) {
       return fail(OLSR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));         \
   } while (0)
 
-void marks_reset(hipStream_t st) {
+void marks_reset() {
   for (auto& m : g_marks) (void)hipEventDestroy(m.ev);
   g_marks.clear();
-  g_mark_stream = st;
 }
 void mark(const char* name, hipStream_t st) {
-  if (!g_profiling) return;
+  if (!g_profiling || g_marks.size() >= (1u << 16)) return;
+  g_mark_stream = st;
   StageMark m{name, nullptr};
   if (hipEventCreate(&m.ev) != hipSuccess) return;
   (void)hipEventRecord(m.ev, st);
@@ -131,7 +131,6 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   size_t gb, ib, bb;
   const GeometryState g = GeometryState::carve(geom_buf, (size_t)s.P, gb);
   const ImageState im = ImageState::carve(img_buf, N, (size_t)d.ntiles, ib);
-  if (g_profiling) marks_reset(st);
   mark("begin", st);
 
   if (!out_color || !out_depth || !out_opacity || (s.F > 0 && !out_language))
@@ -271,7 +270,6 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   hipStream_t st = (hipStream_t)hip_stream;
   if (s.bwd_mode != OLSR_BWD_REFERENCE && s.bwd_mode != OLSR_BWD_EXACT)
     return fail(OLSR_ERR_ARG, "bwd_mode must be OLSR_BWD_REFERENCE or OLSR_BWD_EXACT");
-  if (g_profiling) marks_reset(st);
   mark("begin", st);
   if (s.P == 0) {
     if (dL_dtau_sum) HIP_TRY(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), st));
@@ -361,13 +359,17 @@ const void* olsr_image_field(const void* image_buffer, int32_t width, int32_t he
   return nullptr;
 }
 
-void olsr_set_profiling(int enable) { g_profiling = enable != 0; }
+void olsr_set_profiling(int enable) {
+  g_profiling = enable != 0;
+  marks_reset();
+}
 
 int olsr_get_stage_times(const char** names, float* ms, int max) {
   if (g_marks.size() < 2) return 0;
-  (void)hipStreamSynchronize(g_mark_stream);
+  (void)hipEventSynchronize(g_marks.back().ev);
   int n = 0;
   for (size_t i = 1; i < g_marks.size() && n < max; ++i) {
+    if (!std::strcmp(g_marks[i].name, "begin")) continue;  // interval between two calls
     float t = 0.f;
     if (hipEventElapsedTime(&t, g_marks[i - 1].ev, g_marks[i].ev) != hipSuccess) t = -1.f;
     names[n] = g_marks[i].name;

@@ -1,0 +1,212 @@
+"""Pre-allocated rasterizer workspace and the frame-sharded multi-GPU step.
+
+Two things the reference does not have:
+
+* `RasterWorkspace` — one forward+backward of the rasterizer with every buffer allocated once
+  (geometry / image / binning state sized for a capacity of instances, outputs, gradients) and
+  NO host synchronisation: it drives `olsr_forward_async` / `olsr_backward` of include/olsr.h.
+  The reference re-allocates and zero-fills ~20 tensors per call and blocks on a D2H copy of
+  the instance count (DGR/rasterize_points.cu:170-184,386-398; CR/rasterizer_impl.cu:454-455).
+
+* `FrameShardedStep` — the mapping loop of utils/slam_backend.py:499-670 renders up to 12
+  viewpoints of the SAME Gaussians and sums their losses before one backward.  Views are
+  independent, so view v goes to rank v mod world; each rank accumulates its views' gradients
+  into one flat fp32 buffer [P x (3 xyz + 3M sh + 1 opacity + 3 scale + 4 rot + F lang)] and ONE
+  sum all-reduce (RCCL over xGMI) per optimisation step makes every rank hold the total, after
+  which all ranks apply the identical update.  Side reductions needed by densification are
+  computed per view BEFORE reducing where they are not linear (||means2D.grad||,
+  gaussian_model.py:965-969).  Pose gradients stay on the owning rank.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _abi
+from ._lib import check, lib
+
+
+def views_of_rank(num_views: int, rank: int, world: int) -> List[int]:
+    """View v is rendered by rank v mod world."""
+    return [v for v in range(num_views) if v % world == rank]
+
+
+@dataclass
+class GradLayout:
+    """Column layout of the flat per-Gaussian gradient buffer."""
+    M: int
+    F: int
+
+    @property
+    def fields(self):
+        return [("means3D", 3), ("sh", 3 * self.M), ("opacity", 1), ("scales", 3), ("rotations", 4),
+                ("language", self.F)]
+
+    @property
+    def width(self):
+        return sum(w for _, w in self.fields)
+
+    def slices(self):
+        out, c = {}, 0
+        for name, w in self.fields:
+            out[name] = slice(c, c + w)
+            c += w
+        return out
+
+
+class GradientBucket:
+    """Flat [P, width] fp32 gradient buffer + the side buffers of the densification bookkeeping."""
+
+    def __init__(self, P, layout: GradLayout, device):
+        self.layout = layout
+        self.flat = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
+        # xyz_gradient_accum, denom (gaussian_model.py:965-969): sum-reducible once the norm is taken per view
+        self.densify = torch.zeros(P, 2, dtype=torch.float32, device=device)
+        self.max_radii = torch.zeros(P, dtype=torch.int32, device=device)  # max-reducible
+        self._sl = layout.slices()
+
+    def zero_(self):
+        self.flat.zero_()
+        self.densify.zero_()
+        self.max_radii.zero_()
+
+    def view(self, name):
+        return self.flat[:, self._sl[name]]
+
+    def accumulate(self, grads: Dict[str, torch.Tensor], radii: torch.Tensor):
+        """Add one view's gradients (names of the C-ABI / reference backward outputs)."""
+        self.view("means3D").add_(grads["dL_dmeans3D"])
+        if self.layout.M > 0:
+            self.view("sh").add_(grads["dL_dsh"].reshape(grads["dL_dsh"].shape[0], -1))
+        self.view("opacity").add_(grads["dL_dopacity"].reshape(-1, 1))
+        self.view("scales").add_(grads["dL_dscales"])
+        self.view("rotations").add_(grads["dL_drotations"])
+        if self.layout.F > 0:
+            self.view("language").add_(grads["dL_dlanguage"])
+        vis = radii > 0
+        self.densify[:, 0].add_(torch.norm(grads["dL_dmeans2D"][:, :2], dim=-1) * vis)
+        self.densify[:, 1].add_(vis.to(torch.float32))
+        torch.maximum(self.max_radii, radii.to(torch.int32), out=self.max_radii)
+
+    def all_reduce(self, group=None):
+        """The one exchange step.  backend 'nccl' is RCCL on ROCm; 'gloo' in the CPU tests."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(self.densify, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
+
+
+class RasterWorkspace:
+    """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
+
+    def __init__(self, P, W, H, F, M, capacity, device, tile=15, bwd_mode=_abi.BWD_REFERENCE):
+        self.P, self.W, self.H, self.F, self.M = int(P), int(W), int(H), int(F), int(M)
+        self.capacity, self.tile, self.bwd_mode = int(capacity), int(tile), int(bwd_mode)
+        self.device = torch.device(device)
+        L = lib()
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.geom = torch.empty(L.olsr_geometry_bytes(P, F), **u8)
+        self.img = torch.empty(L.olsr_image_bytes(W, H, tile), **u8)
+        self.binning = torch.empty(L.olsr_binning_bytes(self.capacity, F), **u8)
+        self.out = dict(color=torch.empty(3, H, W, **f32), language=torch.empty(F, H, W, **f32),
+                        depth=torch.empty(1, H, W, **f32), opacity=torch.empty(1, H, W, **f32),
+                        radii=torch.empty(P, **i32), n_touched=torch.empty(P, **i32))
+        self.num_rendered = torch.zeros(2, **i32)  # {R, overflow flag}, stays on the device
+        self.grads = dict(dL_dmeans2D=torch.empty(P, 3, **f32), dL_dconic=torch.empty(P, 4, **f32),
+                          dL_dopacity=torch.empty(P, 1, **f32), dL_dcolors=torch.empty(P, 3, **f32),
+                          dL_dlanguage=torch.empty(P, F, **f32), dL_ddepths=torch.empty(P, 1, **f32),
+                          dL_dmeans3D=torch.empty(P, 3, **f32), dL_dcov3D=torch.empty(P, 6, **f32),
+                          dL_dsh=torch.empty(P, M, 3, **f32), dL_dscales=torch.empty(P, 3, **f32),
+                          dL_drotations=torch.empty(P, 4, **f32), dL_dtau=torch.empty(P, 6, **f32),
+                          dL_dtau_sum=torch.empty(6, **f32))
+        self._scene = None
+        self._keep = None
+
+    def state_bytes(self):
+        return self.geom.numel() + self.img.numel() + self.binning.numel()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_scene(self, *, bg, means3D, opacities, scales, rotations, shs, language, viewmatrix, projmatrix,
+                  projmatrix_raw, campos, tanfovx, tanfovy, sh_degree, scale_modifier=1.0, colors_precomp=None,
+                  cov3D_precomp=None):
+        """Bind (borrow) the input tensors of the next forward/backward.  All must be contiguous fp32 on the
+        workspace device."""
+        keep = [bg, means3D, shs, colors_precomp, language, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                projmatrix, projmatrix_raw, campos]
+        for t in keep:
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                raise RuntimeError("RasterWorkspace inputs must be contiguous fp32 tensors on the GPU")
+        self._keep = keep
+        self._scene = _abi.make_scene(
+            P=self.P, D=sh_degree, M=self.M if shs is not None else 0, F=self.F, width=self.W, height=self.H,
+            tile=self.tile, prefiltered=False, debug=False, bwd_mode=self.bwd_mode, tan_fovx=tanfovx,
+            tan_fovy=tanfovy, scale_modifier=scale_modifier, background=bg, means3D=means3D, shs=shs,
+            colors_precomp=colors_precomp, language_precomp=language, opacities=opacities, scales=scales,
+            rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix,
+            projmatrix_raw=projmatrix_raw, cam_pos=campos)
+
+    def forward(self):
+        o = self.out
+        check(lib().olsr_forward_async(
+            C.byref(self._scene), self.geom.data_ptr(), self.binning.data_ptr(), self.capacity, self.img.data_ptr(),
+            o["color"].data_ptr(), o["language"].data_ptr() if self.F > 0 else None, o["depth"].data_ptr(),
+            o["opacity"].data_ptr(), o["radii"].data_ptr(), o["n_touched"].data_ptr(), self.num_rendered.data_ptr(),
+            self._stream()))
+        return o
+
+    def backward(self, dL_dcolor, dL_dlanguage, dL_ddepth):
+        g = self.grads
+
+        def p(t):
+            return t.data_ptr() if t is not None and t.numel() > 0 else None
+        check(lib().olsr_backward(
+            C.byref(self._scene), self.out["radii"].data_ptr(), self.geom.data_ptr(), self.capacity,
+            self.binning.data_ptr(), self.img.data_ptr(), p(dL_dcolor), p(dL_dlanguage), p(dL_ddepth),
+            p(g["dL_dmeans2D"]), p(g["dL_dconic"]), p(g["dL_dopacity"]), p(g["dL_dcolors"]), p(g["dL_dlanguage"]),
+            p(g["dL_ddepths"]), p(g["dL_dmeans3D"]), p(g["dL_dcov3D"]), p(g["dL_dsh"]), p(g["dL_dscales"]),
+            p(g["dL_drotations"]), p(g["dL_dtau"]), p(g["dL_dtau_sum"]), self._stream()))
+        return g
+
+    def rendered(self):
+        """(R, overflow) — synchronises; call outside timed regions."""
+        r = self.num_rendered.cpu()
+        return int(r[0]), bool(r[1])
+
+
+class FrameShardedStep:
+    """One optimisation step's worth of rasterization, sharded by viewpoint over the ranks of a
+    torch.distributed group (one process per GPU).  `cameras` is the full list of views of the step
+    (identical on every rank); this rank renders views_of_rank(...)."""
+
+    def __init__(self, workspace: RasterWorkspace, rank=0, world=1, group=None):
+        self.ws = workspace
+        self.rank, self.world, self.group = rank, world, group
+        self.bucket = GradientBucket(workspace.P, GradLayout(workspace.M, workspace.F), workspace.device)
+        self.pose_grads: Dict[int, torch.Tensor] = {}
+
+    def run(self, gaussians: Dict[str, torch.Tensor], cameras: Sequence[Dict], cotangents, sh_degree=0):
+        """gaussians: bg, means3D, opacities, scales, rotations, shs, language.
+        cameras[v]: viewmatrix, projmatrix, projmatrix_raw, campos (device tensors), tanfovx, tanfovy.
+        cotangents(v, outputs) -> (dL_dcolor, dL_dlanguage, dL_ddepth): the caller's loss gradient."""
+        ws = self.ws
+        self.bucket.zero_()
+        self.pose_grads.clear()
+        for v in views_of_rank(len(cameras), self.rank, self.world):
+            cam = cameras[v]
+            ws.set_scene(sh_degree=sh_degree, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
+                         projmatrix_raw=cam["projmatrix_raw"], campos=cam["campos"], tanfovx=cam["tanfovx"],
+                         tanfovy=cam["tanfovy"], **gaussians)
+            out = ws.forward()
+            dc, dl, dd = cotangents(v, out)
+            g = ws.backward(dc, dl, dd)
+            self.bucket.accumulate(g, out["radii"])
+            self.pose_grads[v] = g["dL_dtau_sum"].clone()  # [rho | theta], stays on the owning rank
+        self.bucket.all_reduce(self.group)
+        return self.bucket
