@@ -920,6 +920,7 @@ static void preprocess_backward(const olsr_scene& s, const State& st, const int*
 
 static bool check_scene(const olsr_scene* s) {
   if (!s || s->P < 0 || s->width <= 0 || s->height <= 0 || s->tile <= 0) return false;
+  if (s->P == 0) return true;  // nothing is dereferenced (DGR/rasterize_points.cu:187,400)
   if ((s->shs == nullptr) == (s->colors_precomp == nullptr)) return false;
   const bool has_sr = s->scales != nullptr && s->rotations != nullptr;
   if (has_sr == (s->cov3D_precomp != nullptr)) return false;

@@ -1,0 +1,127 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol that
+include/olsr.h declares, buffer-size functions behave, the Python API validates arguments with
+the reference's exceptions, and the product never silently falls back to the CPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from online_lang_splatting_amd import build
+    build.build()  # hipcc cross-compiles gfx950 without a GPU
+    from online_lang_splatting_amd import _lib
+    return _lib.lib()
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "olsr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(olsr_[a-z_]+)\s*\(", src)) - {"olsr_alloc_fn"})
+
+
+def test_library_exports_every_declared_symbol(L):
+    from online_lang_splatting_amd import _lib
+    declared = _declared_functions()
+    assert len(declared) >= 14
+    assert sorted(_lib.EXPORTS) == declared
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+
+
+def test_buffer_sizes(L):
+    g1, g2 = L.olsr_geometry_bytes(1000, 15), L.olsr_geometry_bytes(500000, 15)
+    assert 0 < g1 < g2
+    assert g2 >= 500000 * (4 + 8 + 16 + 24 + 12 + 3 + 4 * 6)
+    assert L.olsr_image_bytes(1200, 680, 15) >= 1200 * 680 * 8 + 80 * 46 * 8
+    b15, b32, b0 = (L.olsr_binning_bytes(1 << 20, F) for F in (15, 32, 0))
+    assert b0 < b15 < b32
+    # row strides: 10+F floats padded to 16
+    assert b15 - b0 == (1 << 20) * 4 * (32 - 16) and b32 - b15 == (1 << 20) * 4 * (48 - 32)
+    assert L.olsr_geometry_bytes(0, 0) > 0 and L.olsr_binning_bytes(0, 15) > 0
+    assert L.olsr_version().startswith(b"olsr")
+
+
+def test_struct_layout_matches_header():
+    from online_lang_splatting_amd._abi import OlsrScene
+    # 10 int32 + 4 float + 13 pointers, no implicit padding
+    assert ctypes.sizeof(OlsrScene) == 10 * 4 + 4 * 4 + 13 * 8
+    assert OlsrScene.background.offset == 56 and OlsrScene.cam_pos.offset == 56 + 12 * 8
+
+
+def test_c_abi_argument_errors(L):
+    from online_lang_splatting_amd import _abi
+    s = _abi.OlsrScene()
+    s.P, s.width, s.height, s.tile, s.F = 10, 64, 64, 17, 15
+    cb = _abi.ALLOC_FN(lambda u, n: None)
+    R = ctypes.c_int32(0)
+    rc = L.olsr_forward(ctypes.byref(s), cb, None, cb, None, cb, None, None, None, None, None, None, None,
+                        ctypes.byref(R), None)
+    assert rc == _abi.OLSR_ERR_ARG and b"tile" in L.olsr_last_error()
+    s.tile, s.F = 15, 7
+    rc = L.olsr_forward(ctypes.byref(s), cb, None, cb, None, cb, None, None, None, None, None, None, None,
+                        ctypes.byref(R), None)
+    assert rc == _abi.OLSR_ERR_ARG and b"language channels" in L.olsr_last_error()
+
+
+def test_python_api_surface_and_exceptions():
+    import diff_gaussian_rasterization as D
+    from online_lang_splatting_amd import GaussianRasterizationSettings, LanguageGaussianRasterizer
+    assert D.GaussianRasterizationSettings is GaussianRasterizationSettings
+    assert GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "projmatrix_raw", "sh_degree", "campos", "prefiltered", "debug")
+    rs = GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), torch.eye(4), 0,
+                                       torch.zeros(3), False, False)
+    P = 4
+    m, m2, o = torch.zeros(P, 3), torch.zeros(P, 3), torch.ones(P, 1)
+    sh, col = torch.zeros(P, 1, 3), torch.zeros(P, 3)
+    sc, rot, cov = torch.ones(P, 3), torch.zeros(P, 4), torch.zeros(P, 6)
+    lang = torch.zeros(P, 15)
+    for cls in (D.GaussianRasterizer, LanguageGaussianRasterizer):
+        r = cls(rs)
+        extra = dict(language_precomp=lang) if cls is LanguageGaussianRasterizer else {}
+        with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+            r(m, m2, o, shs=None, colors_precomp=None, scales=sc, rotations=rot, **extra)
+        with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+            r(m, m2, o, shs=sh, colors_precomp=col, scales=sc, rotations=rot, **extra)
+        with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+            r(m, m2, o, shs=sh, scales=sc, rotations=None, **extra)
+        with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+            r(m, m2, o, shs=sh, scales=sc, rotations=rot, cov3D_precomp=cov, **extra)
+        # CPU tensors are refused loudly: there is no CPU fallback in the product
+        with pytest.raises(RuntimeError, match="GPU"):
+            r(m, m2, o, shs=sh, scales=sc, rotations=rot, **extra)
+    with pytest.raises(RuntimeError, match=r"\(num_points, 3\)"):
+        from online_lang_splatting_amd import _C
+        _C.rasterize_gaussians(torch.zeros(3), torch.zeros(P, 4), col, o, sc, rot, 1.0, torch.empty(0), torch.eye(4),
+                               torch.eye(4), torch.eye(4), 1.0, 1.0, 8, 8, torch.empty(0), 0, torch.zeros(3), False,
+                               False)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "online_lang_splatting_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_C" not in txt and "liboracle" not in txt and "import oracle" not in txt, f
+    shim = open(os.path.join(ROOT, "diff_gaussian_rasterization", "__init__.py")).read()
+    assert "oracle" not in shim
+
+
+def test_scene_generator_is_deterministic():
+    from online_lang_splatting_amd.scene import make_config_scene, make_scene
+    a, b = make_scene(1000, 64, 48, 15, seed=3), make_scene(1000, 64, 48, 15, seed=3)
+    for k in ("means3D", "opacities", "scales", "rotations", "shs", "language"):
+        assert torch.equal(getattr(a, k), getattr(b, k))
+    c = make_config_scene(1, P=500)
+    assert c.shs.shape == (500, 16, 3) and c.F == 0 and c.sh_degree == 3
+    assert torch.allclose(a.language.norm(dim=1), torch.ones(1000), atol=1e-5)
+    assert torch.allclose(a.rotations.norm(dim=1), torch.ones(1000), atol=1e-5)

@@ -1,0 +1,60 @@
+"""The N > 1 path on CPU: two gloo processes shard views, accumulate per-view gradients into the
+flat buffer and all-reduce it.  (The rasterization itself needs a GPU; here the per-view gradients
+are synthetic, so this covers the sharding rule, the buffer layout and the collectives.)"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket, views_of_rank
+
+
+def _fake_view_grads(P, M, F, v):
+    g = torch.Generator().manual_seed(100 + v)
+    return dict(dL_dmeans3D=torch.randn(P, 3, generator=g), dL_dsh=torch.randn(P, M, 3, generator=g),
+                dL_dopacity=torch.randn(P, 1, generator=g), dL_dscales=torch.randn(P, 3, generator=g),
+                dL_drotations=torch.randn(P, 4, generator=g), dL_dlanguage=torch.randn(P, F, generator=g),
+                dL_dmeans2D=torch.randn(P, 3, generator=g)), torch.randint(0, 9, (P,), generator=g, dtype=torch.int32)
+
+
+def _worker(rank, world, port, P, M, F, V, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = GradientBucket(P, GradLayout(M, F), "cpu")
+    for v in views_of_rank(V, rank, world):
+        g, radii = _fake_view_grads(P, M, F, v)
+        b.accumulate(g, radii)
+    b.all_reduce()
+    if rank == 0:
+        ret["flat"], ret["densify"], ret["max_radii"] = b.flat.clone(), b.densify.clone(), b.max_radii.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_views_of_rank_partition():
+    for world in (1, 2, 4, 8):
+        seen = sorted(v for r in range(world) for v in views_of_rank(12, r, world))
+        assert seen == list(range(12))
+
+
+def test_two_rank_all_reduce_equals_single_process():
+    P, M, F, V, world = 257, 1, 15, 5, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, P, M, F, V, ret), nprocs=world, join=True)
+    ref = GradientBucket(P, GradLayout(M, F), "cpu")
+    for v in range(V):
+        g, radii = _fake_view_grads(P, M, F, v)
+        ref.accumulate(g, radii)
+    assert ref.layout.width == 3 + 3 + 1 + 3 + 4 + 15
+    torch.testing.assert_close(ret["flat"], ref.flat, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ret["densify"], ref.densify, rtol=1e-6, atol=1e-6)
+    assert torch.equal(ret["max_radii"], ref.max_radii)
+    # the densification statistic is the sum of per-view norms, not the norm of the summed gradient
+    summed = sum(_fake_view_grads(P, M, F, v)[0]["dL_dmeans2D"] for v in range(V))
+    assert not torch.allclose(ref.densify[:, 0], summed[:, :2].norm(dim=-1))

@@ -1,0 +1,147 @@
+"""The drop-in Python API on the GPU: autograd wiring of GaussianRasterizer /
+LanguageGaussianRasterizer, the render() harness of the reference caller, the sync-free
+workspace, and size-independent properties at BASELINE.json's full config-3 size."""
+import math
+
+import pytest
+import torch
+
+from online_lang_splatting_amd import _abi
+from online_lang_splatting_amd.scene import make_config_scene, make_scene
+from parity_common import rel_err, run_backend
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _settings(sc, dev):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    cam = sc.camera
+    return GaussianRasterizationSettings(
+        image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=sc.bg.to(dev),
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+        projmatrix_raw=cam.projection_matrix.to(dev), sh_degree=sc.sh_degree, campos=cam.camera_center.to(dev),
+        prefiltered=False, debug=False)
+
+
+def test_language_rasterizer_autograd_matches_c_level(hip, oracle):
+    """What gaussian_renderer._language_render does (GS/gaussian_renderer/__init__.py:195-347)."""
+    from diff_gaussian_rasterization import LanguageGaussianRasterizer
+    dev = torch.device(DEV)
+    sc = make_scene(3000, 160, 120, 15, seed=5)
+    leaf = lambda t: t.to(dev).clone().requires_grad_(True)  # noqa: E731
+    means3D, opac, scales, rots, shs, lang = (leaf(t) for t in (sc.means3D, sc.opacities, sc.scales, sc.rotations,
+                                                                sc.shs, sc.language))
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    rast = LanguageGaussianRasterizer(raster_settings=_settings(sc, dev))
+    image, language, radii, depth, opacity, n_touched = rast(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, language_precomp=lang, opacities=opac,
+        scales=scales, rotations=rots, cov3D_precomp=None, theta=theta, rho=rho)
+    assert image.shape == (3, 120, 160) and language.shape == (15, 120, 160) and depth.shape == (1, 120, 160)
+    assert opacity.shape == (1, 120, 160) and radii.dtype == torch.int32 and n_touched.dtype == torch.int32
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(3))
+    # opacity takes part in the loss but, like the reference, contributes no gradient
+    loss = (image * dc).sum() + (language * dl).sum() + (depth * dd).sum() + opacity.sum() * 0.123
+    loss.backward()
+    fo, go = run_backend(oracle, sc, None, 3, 15, _abi.BWD_REFERENCE)
+    assert torch.equal(image.detach().cpu(), fo["color"]) and torch.equal(language.detach().cpu(), fo["language"])
+    for name, t in (("dL_dmeans3D", means3D), ("dL_dopacity", opac), ("dL_dscales", scales), ("dL_drotations", rots),
+                    ("dL_dsh", shs), ("dL_dlanguage", lang), ("dL_dmeans2D", means2D)):
+        assert rel_err(t.grad, go[name])[0] <= 1e-4, name
+    tau = go["dL_dtau"].sum(0)
+    assert rel_err(rho.grad, tau[:3])[0] <= 1e-4 and rel_err(theta.grad, tau[3:])[0] <= 1e-4
+    assert theta.grad.shape == (3,) and rho.grad.shape == (3,)
+    oracle.release(fo["geom"])
+
+
+def test_rgb_rasterizer_autograd_and_mark_visible(hip, oracle):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device(DEV)
+    sc = make_scene(2000, 128, 96, 0, seed=6, max_sh_degree=1, sh_degree=1)
+    leaf = lambda t: t.to(dev).clone().requires_grad_(True)  # noqa: E731
+    means3D, opac, scales, rots, shs = (leaf(t) for t in (sc.means3D, sc.opacities, sc.scales, sc.rotations, sc.shs))
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    rast = GaussianRasterizer(raster_settings=_settings(sc, dev))
+    image, radii, depth, opacity, n_touched = rast(means3D=means3D, means2D=means2D, shs=shs, opacities=opac,
+                                                   scales=scales, rotations=rots)
+    dc, _, dd = sc.cotangents(4)
+    ((image * dc.to(dev)).sum() + (depth * dd.to(dev)).sum()).backward()
+    fo, go = run_backend(oracle, sc, None, 4, 15, _abi.BWD_REFERENCE)
+    assert torch.equal(image.detach().cpu(), fo["color"])
+    assert rel_err(means3D.grad, go["dL_dmeans3D"])[0] <= 1e-4 and rel_err(shs.grad, go["dL_dsh"])[0] <= 1e-4
+    vis = rast.markVisible(means3D.detach())
+    assert torch.equal(vis.cpu(), sc.means3D[:, 2] > 0.2)
+    oracle.release(fo["geom"])
+
+
+def test_workspace_async_equals_dropin_path(hip):
+    """olsr_forward_async / olsr_backward with pre-allocated buffers == the allocating drop-in path."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    dev = torch.device(DEV)
+    sc = make_scene(20000, 320, 240, 15, seed=7)
+    fg, gg = run_backend(hip, sc, dev, 5, 15, 0)
+    cam = sc.camera
+    ws = RasterWorkspace(sc.P, 320, 240, 15, sc.shs.shape[1], int(fg["R"] * 1.2) + 1000, dev)
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(5))
+    kw = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+              rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev),
+              viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+              projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+              tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+    for _ in range(2):  # buffers are reused: the second pass must not see stale state
+        ws.set_scene(**kw)
+        out = ws.forward()
+        g = ws.backward(dc, dl, dd)
+    assert ws.rendered() == (fg["R"], False)
+    for k in ("color", "language", "depth", "opacity", "radii", "n_touched"):
+        assert torch.equal(out[k], fg[k]), k
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dlanguage", "dL_dtau"):
+        assert torch.equal(g[k].reshape(gg[k].shape), gg[k]), k
+    # capacity overflow is reported, nothing is rendered, nothing crashes
+    small = RasterWorkspace(sc.P, 320, 240, 15, sc.shs.shape[1], 1000, dev)
+    small.set_scene(**kw)
+    o2 = small.forward()
+    R, overflow = small.rendered()
+    assert overflow and R == fg["R"] and float(o2["opacity"].abs().max()) == 0.0
+
+
+def test_full_size_config3_properties(hip):
+    """BASELINE.json configs[2] (500 k Gaussians, 1200x680, F=15) on the GPU: properties that do not
+    need the oracle — sort order, range partition, transmittance/opacity identities, linearity of
+    the backward in the cotangent, determinism."""
+    dev = torch.device(DEV)
+    sc = make_config_scene(3)
+    P, W, H, F = sc.P, 1200, 680, 15
+    fg, g1 = run_backend(hip, sc, dev, 3, 15, 0)
+    R = fg["R"]
+    assert 4_000_000 < R < 7_000_000
+    gx, gy = math.ceil(W / 15), math.ceil(H / 15)
+    pl = hip.state_field("binning", fg["binning"], "point_list", R=R, F=F, dtype=torch.int32, count=R).long()
+    rg = hip.state_field("image", fg["img"], "ranges", W=W, H=H, dtype=torch.int32, count=2 * gx * gy).view(-1, 2).long()
+    lens = rg[:, 1] - rg[:, 0]
+    assert int(lens.sum()) == R
+    nz = lens > 0
+    starts = rg[nz, 0]
+    assert bool((starts[1:] == rg[nz, 1][:-1]).all()) and int(starts[0]) == 0  # contiguous partition
+    depths = hip.state_field("geometry", fg["geom"], "depths", P=P, F=F, dtype=torch.float32, count=P)
+    d = depths[pl]
+    tile_of = torch.repeat_interleave(torch.arange(gx * gy, device=dev), lens)
+    same_tile = tile_of[1:] == tile_of[:-1]
+    assert bool((d[1:][same_tile] >= d[:-1][same_tile]).all())  # front-to-back inside every tile
+    tie = same_tile & (d[1:] == d[:-1])
+    assert bool((pl[1:][tie] > pl[:-1][tie]).all())  # ties by Gaussian index
+    tt = hip.state_field("geometry", fg["geom"], "tiles_touched", P=P, F=F, dtype=torch.int32, count=P).long()
+    assert torch.equal(torch.bincount(pl, minlength=P), tt * (fg["radii"] > 0))
+    final_T = hip.state_field("image", fg["img"], "final_T", W=W, H=H, dtype=torch.float32, count=W * H)
+    assert torch.equal(fg["opacity"].reshape(-1), 1 - final_T)
+    assert float(fg["opacity"].min()) >= 0 and float(fg["opacity"].max()) <= 1
+    assert bool(torch.isfinite(fg["color"]).all()) and bool(torch.isfinite(fg["language"]).all())
+    assert bool((fg["n_touched"] <= 0).logical_or(fg["radii"] > 0).all())
+    # backward is linear in the cotangent and deterministic
+    _, g2 = run_backend(hip, sc, dev, 3, 15, 0)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+        assert bool(torch.isfinite(g1[k]).all()), k
+    hip.TILE, hip.BWD_MODE = 15, 0
