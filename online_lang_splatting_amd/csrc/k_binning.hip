@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict_
                                                    const u32* __restrict__ tiles_touched,
                                                    const float* __restrict__ means2D, const int32_t* __restrict__ radii,
                                                    int gx, int gy, const int32_t* __restrict__ counters,
-                                                   u32* __restrict__ keys, u32* __restrict__ inst_gid) {
+                                                   u32* __restrict__ keys, u32* __restrict__ inst_gid,
+                                                   u32* __restrict__ inst_start) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= P) return;
   if (counters[2] != 0) return;  // overflow: nothing is emitted
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict_
   const int rad = radii[g];
   if (rad > 0) {
     u32 off = offsets[r] - tiles_touched[g];
+    inst_start[g] = off;
     const Rect rc = get_rect<TILE>(means2D[2 * (size_t)g], means2D[2 * (size_t)g + 1], rad, gx, gy);
     for (int y = rc.y0; y < rc.y1; y++)
       for (int x = rc.x0; x < rc.x1; x++) {
@@ -284,10 +286,10 @@ void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g
   const int nb = (s.P + 255) / 256;
   if (d.tile == 15)
     emit_kernel<15><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii, d.gx, d.gy,
-                                        g.counters, b.key_a, b.inst_gid);
+                                        g.counters, b.key_a, b.inst_gid, g.inst_start);
   else
     emit_kernel<16><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii, d.gx, d.gy,
-                                        g.counters, b.key_a, b.inst_gid);
+                                        g.counters, b.key_a, b.inst_gid, g.inst_start);
 }
 
 // ------------------------------------------------------------------------------- ranges

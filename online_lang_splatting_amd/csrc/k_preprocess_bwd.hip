@@ -3,11 +3,19 @@
 //
 // Replaces the atomicAdd accumulation of CR/backward.cu:1176-1198 together with
 // computeCov2DCUDA (:150-346), preprocessCUDA / language_preprocessCUDA (:418-539, 541-682),
-// computeCov3D (:350-413) and computeColorFromSH (:21-145), fused into ONE kernel so the
-// intermediate dL_dmean2D / dL_dconic / dL_dcolor / dL_ddepth never round-trip through HBM
-// between stages.  One lane per Gaussian, visited in depth order so that the rows a lane
-// reads (emission order == depth order) are contiguous and neighbouring lanes read
-// neighbouring runs.  Rows whose instance was never blended (flags == 0) are not read.
+// computeCov3D (:350-413) and computeColorFromSH (:21-145).  Two kernels:
+//   row_reduce_kernel   — sums, per Gaussian, the partial-gradient rows its (instance, slot)
+//     pairs received from the backward composite.  It walks the Gaussians in DEPTH order, i.e.
+//     in emission order: a Gaussian's rows are one contiguous run, neighbouring lanes read
+//     neighbouring runs, and lanes of a wave have similar footprints (balanced loops).  A
+//     Gaussian covering many tiles (up to thousands for a near splat) is not looped over by one
+//     lane: the wave picks it up cooperatively — 64 lanes stride over its instances, then one
+//     multi-value butterfly.  Rows of pairs that were never blended (flag bit clear) are not
+//     read — and were never written.  Fixed summation order: bit-reproducible.
+//   preprocess_bwd_kernel — the analytic chain, one lane per Gaussian in INDEX order so that
+//     every per-Gaussian input and output is a coalesced access; dL_dmean2D / dL_dconic /
+//     dL_dcolor / dL_ddepth are taken from the reduced row in registers and the four reference
+//     stages are fused.
 // Every output row is written exactly once (zeros for culled Gaussians), so no memset of the
 // gradient tensors is needed (the reference zero-fills 12 tensors per call,
 // DGR/rasterize_points.cu:386-398).
@@ -22,6 +30,108 @@ namespace olsr {
 
 constexpr int PB_THREADS = 128;
 int tau_partial_blocks(int P) { return (P + PB_THREADS - 1) / PB_THREADS; }
+
+constexpr int next_pow2_(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+// static-index multi-value wave butterfly (see k_render_bwd.hip)
+template <int H, int M, int N>
+__device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
+  if constexpr (H >= 1) {
+    const bool upper = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const float send = upper ? v[i] : v[i + H];
+      const float keep = upper ? v[i + H] : v[i];
+      v[i] = keep + __shfl_xor(send, M);
+    }
+    wave_reduce_rec<H / 2, M / 2, N>(v, lane);
+  } else if constexpr (M >= 1) {
+    v[0] += __shfl_xor(v[0], M);
+    wave_reduce_rec<0, M / 2, N>(v, lane);
+  }
+}
+
+constexpr int RR_THREADS = 256;
+constexpr u32 RR_BIG = 24;  // instances: above this a Gaussian is reduced by the whole wave
+
+template <int F>
+__device__ __forceinline__ void add_instance_rows(const float* __restrict__ rows, u32 u, u32 fl, float (&acc)[next_pow2_(10 + F)]) {
+  constexpr int ROW = grad_row(F);
+  constexpr int NVAL = 10 + F;
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    if (!((fl >> sl) & 1u)) continue;
+    const float4* row = reinterpret_cast<const float4*>(rows + ((size_t)u * 4 + sl) * ROW);
+#pragma unroll
+    for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
+      const float4 x = row[v4];
+      if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] += x.x;
+      if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] += x.y;
+      if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] += x.z;
+      if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] += x.w;
+    }
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(RR_THREADS) void row_reduce_kernel(int P, const u32* __restrict__ order,
+                                                                const u32* __restrict__ offsets,
+                                                                const u32* __restrict__ tiles_touched,
+                                                                const int32_t* __restrict__ radii,
+                                                                const uint8_t* __restrict__ flags,
+                                                                const float* __restrict__ rows,
+                                                                float* __restrict__ gacc) {
+  constexpr int ROW = grad_row(F);
+  constexpr int NVAL = 10 + F;
+  constexpr int NP = next_pow2_(NVAL);
+  constexpr int G_LANES = 64 / NP;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  u32 idx = 0, n = 0, u0 = 0;
+  if (r < P) {
+    idx = order[r];
+    if (radii[idx] > 0) {
+      n = tiles_touched[idx];
+      u0 = offsets[r] - n;
+    }
+  }
+  // small footprints: one lane per Gaussian
+  if (n > 0 && n <= RR_BIG) {
+    float acc[NP];
+#pragma unroll
+    for (int v = 0; v < NP; ++v) acc[v] = 0.f;
+    for (u32 t = 0; t < n; ++t) {
+      const u32 fl = flags[u0 + t];
+      if (fl) add_instance_rows<F>(rows, u0 + t, fl, acc);
+    }
+    float4* dst = reinterpret_cast<float4*>(gacc + (size_t)idx * ROW);
+#pragma unroll
+    for (int v4 = 0; v4 < ROW / 4; ++v4)
+      dst[v4] = make_float4(4 * v4 + 0 < NVAL ? acc[4 * v4 + 0] : 0.f, 4 * v4 + 1 < NVAL ? acc[4 * v4 + 1] : 0.f,
+                            4 * v4 + 2 < NVAL ? acc[4 * v4 + 2] : 0.f, 4 * v4 + 3 < NVAL ? acc[4 * v4 + 3] : 0.f);
+  }
+  // large footprints: the wave takes them one at a time
+  u64 big = ballot(n > RR_BIG);
+  while (big) {
+    const int src_lane = __builtin_ctzll(big);
+    big &= big - 1;
+    const u32 bn = __shfl(n, src_lane), bu0 = __shfl(u0, src_lane), bidx = __shfl(idx, src_lane);
+    float acc[NP];
+#pragma unroll
+    for (int v = 0; v < NP; ++v) acc[v] = 0.f;
+    for (u32 t = (u32)lane; t < bn; t += 64) {
+      const u32 fl = flags[bu0 + t];
+      if (fl) add_instance_rows<F>(rows, bu0 + t, fl, acc);
+    }
+    wave_reduce_rec<NP / 2, 32, NP>(acc, lane);
+    float v = __shfl(acc[0], (lane * G_LANES) & 63);
+    if (lane >= NVAL) v = 0.f;
+    if (lane < ROW) gacc[(size_t)bidx * ROW + lane] = v;
+  }
+}
 
 // -skew(v) column i (CR/math.h:27-31 negated)
 __device__ __forceinline__ f3 nskew_col(const f3& v, int i) {
@@ -174,8 +284,7 @@ __device__ __forceinline__ void cov3d_backward(const float* scale, float mod, co
 
 template <int F>
 __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
-    int P, int D, int M, const u32* __restrict__ order, const u32* __restrict__ offsets,
-    const u32* __restrict__ tiles_touched, const uint8_t* __restrict__ flags, const float* __restrict__ rows,
+    int P, int D, int M, const float* __restrict__ gacc,
     const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
     const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
     float scale_modifier, const float* __restrict__ cov3Ds, const float* __restrict__ view,
@@ -190,26 +299,20 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (r < P) {
-    const u32 idx = order[r];
+    const u32 idx = (u32)r;
     const bool vis = radii[idx] > 0;
     float acc[NVAL];
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) acc[v] = 0.f;
     if (vis) {
-      const u32 n = tiles_touched[idx];
-      const u32 u0 = offsets[r] - n;
-      for (u32 t = 0; t < n; ++t) {
-        const u32 u = u0 + t;
-        if (flags[u] == 0) continue;
-        const float4* row = reinterpret_cast<const float4*>(rows + (size_t)u * ROW);
+      const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
-        for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
-          const float4 x = row[v4];
-          if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] += x.x;
-          if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] += x.y;
-          if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] += x.z;
-          if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] += x.w;
-        }
+      for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
+        const float4 x = row[v4];
+        if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] = x.x;
+        if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] = x.y;
+        if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] = x.z;
+        if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
       }
     }
     // what the composite's atomics produced in the reference
@@ -453,8 +556,10 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
                         const int32_t* radii, const GradOut& o, float* tau_partials, hipStream_t st) {
   const int nb = tau_partial_blocks(s.P);
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
+  row_reduce_kernel<F><<<(s.P + RR_THREADS - 1) / RR_THREADS, RR_THREADS, 0, st>>>(
+      s.P, g.depth_order, g.offsets, g.tiles_touched, radii, b.flags, b.rows, g.gacc);
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, 0, st>>>(
-      s.P, s.D, s.M, g.depth_order, g.offsets, g.tiles_touched, b.flags, b.rows, s.means3D, radii, s.shs, g.clamped,
+      s.P, s.D, s.M, g.gacc, s.means3D, radii, s.shs, g.clamped,
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,

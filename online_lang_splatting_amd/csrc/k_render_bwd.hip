@@ -6,13 +6,15 @@
 //
 // The reference spends, per splat per tile, 3 block barriers + a shared-memory atomic per
 // skipping thread + an 8-barrier shared-memory tree over 225 threads + up to 25 global float
-// atomics.  MI355X mapping (same fold as the forward: one wave64 per tile, 4 pixel slots per
-// lane, rank = slot*64 + lane):
-//   * no barriers: the tile-wide "does any pixel use this splat" predicate was recorded by the
-//     forward composite (flags[]), so unused instances are skipped by a uniform branch;
-//   * each lane first adds its (up to) 4 pixels in registers, then ONE multi-value wave
-//     butterfly (N values in ~N+log2 shuffle-adds instead of 6N) leaves value k in lane
-//     k*(64/N); the row is written to HBM with a single coalesced 64..256-byte store;
+// atomics.  MI355X mapping (same as the forward: one workgroup per tile, 4 wave64s, one pixel
+// per lane, wave w = the 64-pixel slot of ranks 64w..64w+63):
+//   * no barrier per splat: the forward composite recorded, per (tile, splat) instance, which
+//     slots blended it (flags[] bit w).  A wave skips instances its slot never touched with a
+//     uniform branch, and the four waves of a tile only meet when the next batch of 128 list
+//     entries is staged into LDS;
+//   * the per-splat reduction never leaves the wave: ONE multi-value butterfly (N values in
+//     ~N+log2 shuffle-adds instead of 6N) leaves value k in lane k*(64/N), and the wave writes
+//     its own partial-gradient row (instance, slot) with a single coalesced 64..192-byte store;
 //   * no float atomics: rows are indexed by the instance's emission position, so the
 //     per-Gaussian reduction (k_preprocess_bwd.hip) reads a contiguous run of rows and the
 //     gradients are bit-reproducible from run to run.
@@ -51,26 +53,36 @@ constexpr int next_pow2(int v) {
 
 // Sum N per-lane values across the wave.  On return lane l holds (in v[0]) the wave total of
 // value index l / (64 / N); all 64/N lanes of a group hold the same total.
+// Step (H, M): lanes with bit M set keep the upper H values and send the lower H (and vice
+// versa), halving the live values; once one value is left the remaining lane bits are folded
+// with plain xor-shuffles.  Written as a template recursion so that every register-array index
+// is a compile-time constant (a runtime-indexed private array is lowered to select chains).
+template <int H, int M, int N>
+__device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
+  if constexpr (H >= 1) {
+    const bool upper = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const float send = upper ? v[i] : v[i + H];
+      const float keep = upper ? v[i + H] : v[i];
+      v[i] = keep + __shfl_xor(send, M);
+    }
+    wave_reduce_rec<H / 2, M / 2, N>(v, lane);
+  } else if constexpr (M >= 1) {
+    v[0] += __shfl_xor(v[0], M);
+    wave_reduce_rec<0, M / 2, N>(v, lane);
+  }
+}
 template <int N>
 __device__ __forceinline__ void wave_reduce_multi(float (&v)[N], int lane) {
   static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two <= 64");
-  int m = 32;
-#pragma unroll
-  for (int h = N / 2; h >= 1; h >>= 1, m >>= 1) {
-    const bool upper = (lane & m) != 0;
-#pragma unroll
-    for (int i = 0; i < h; ++i) {
-      const float send = upper ? v[i] : v[i + h];
-      const float keep = upper ? v[i + h] : v[i];
-      v[i] = keep + __shfl_xor(send, m);
-    }
-  }
-#pragma unroll
-  for (; m >= 1; m >>= 1) v[0] += __shfl_xor(v[0], m);
+  wave_reduce_rec<N / 2, 32, N>(v, lane);
 }
 
+constexpr int BWD_BATCH = 128;
+
 template <int TILE, int F, int MODE>
-__global__ __launch_bounds__(64) void render_bwd_kernel(
+__global__ __launch_bounds__(256) void render_bwd_kernel(
     const u32* __restrict__ ranges, const u32* __restrict__ point_list, const u32* __restrict__ src,
     const uint8_t* __restrict__ flags, int W, int H, int gx, int ntiles, const float* __restrict__ bg,
     const float* __restrict__ means2D, const float* __restrict__ conic_opacity, const float* __restrict__ colors,
@@ -78,23 +90,26 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
     const u32* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_lang,
     const float* __restrict__ dL_dpixels_depth, float* __restrict__ rows) {
   constexpr int BS = TILE * TILE;
-  constexpr int SLOTS = (BS + 63) / 64;
   constexpr int FR = feat_row(F);
   constexpr int ROW = grad_row(F);
   constexpr bool REF = (MODE == OLSR_BWD_REFERENCE);
   constexpr int NV = REF ? 10 : 10 + F;  // values that go through the wave reduction
   constexpr int NP = next_pow2(NV);
+  constexpr int G_LANES = 64 / NP;        // lanes per value group after the butterfly
   constexpr int FX = (F > 0) ? F : 1;
+  constexpr int B = BWD_BATCH;
+  static_assert(ROW <= 64, "one lane per row element");
 
-  __shared__ float2 s_xy[64];
-  __shared__ float4 s_co[64];
-  __shared__ __attribute__((aligned(16))) float s_feat[64 * FR];
-  __shared__ u32 s_src[64];
-  __shared__ u32 s_flag[64];
-  __shared__ __attribute__((aligned(16))) float s_row[ROW];
+  __shared__ float2 s_xy[B];
+  __shared__ float4 s_co[B];
+  __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
+  __shared__ u32 s_src[B];
+  __shared__ u32 s_flag[B];
+  __shared__ int s_kmax[4];
 
   const int tile_id = xcd_remap((int)blockIdx.x, ntiles);
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
   const int bx = tile_id % gx, by = tile_id / gx;
   const u32 r0 = ranges[2 * tile_id], r1 = ranges[2 * tile_id + 1];
   if (r1 <= r0) return;
@@ -105,192 +120,195 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
   const float ddelx_dx = 0.5f * W;
   const float ddely_dy = 0.5f * H;
 
-  bool inside[SLOTS], surv[SLOTS];
-  float pixfx[SLOTS], pixfy[SLOTS], T_final[SLOTS], T[SLOTS], last_alpha[SLOTS], bg_dot[SLOTS];
-  int last_contributor[SLOTS];
-  float accum_c[SLOTS][3], last_c[SLOTS][3], dLc[SLOTS][3];
-  float accum_d[SLOTS], last_d[SLOTS], dLd[SLOTS];
-  float accum_f[SLOTS][FX], dLf[SLOTS][FX];
-  float last_f[REF ? 1 : SLOTS][FX];  // REF: one wave-uniform copy (the recursion is unguarded)
-  int kmax = 0;
+  // ---- per-pixel state (one pixel per lane; thread rank = ty*TILE + tx as in the reference) ----
+  // Language channels are carried in "dot form": the reference keeps accum_rec_F[F] and
+  // last_language_feature[F] per thread only to evaluate sum_ch (f - accum_rec_F)[ch] * dL_dF[ch];
+  // with A = <accum_rec_F, dL_dF> and D = <f, dL_dF> the recursion
+  //   accum_rec_F <- last_alpha * last_F + (1 - last_alpha) * accum_rec_F     (CR/backward.cu:1132)
+  // becomes A <- last_alpha * D_last + (1 - last_alpha) * A and the contribution is D - A.
+  // Algebraically identical, 2 registers per pixel instead of 2F.
+  const int rank = tid;
+  const int px = bx * TILE + rank % TILE, py = by * TILE + rank / TILE;
+  const bool inside = (rank < BS) && (px < W) && (py < H);
+  const bool surv = REF ? ref_survives<TILE>(rank) : true;
+  const float pixfx = (float)px, pixfy = (float)py;
+  const size_t pix = (size_t)W * py + px;
+  const float T_final = inside ? final_Ts[pix] : 0.f;
+  float T = T_final;
+  const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+  float last_alpha = 0.f;
+  float accum_c[3] = {0.f, 0.f, 0.f}, last_c[3] = {0.f, 0.f, 0.f}, dLc[3];
 #pragma unroll
-  for (int q = 0; q < SLOTS; ++q) {
-    const int rank = q * 64 + lane;
-    const int px = bx * TILE + rank % TILE, py = by * TILE + rank / TILE;
-    inside[q] = (rank < BS) && (px < W) && (py < H);
-    surv[q] = REF ? ref_survives<TILE>(rank) : true;
-    pixfx[q] = (float)px;
-    pixfy[q] = (float)py;
-    const size_t pix = (size_t)W * py + px;
-    T_final[q] = inside[q] ? final_Ts[pix] : 0.f;
-    T[q] = T_final[q];
-    last_contributor[q] = inside[q] ? (int)n_contrib[pix] : 0;
-    kmax = max(kmax, last_contributor[q]);
-    last_alpha[q] = 0.f;
-    float bd = 0.f;
+  for (int ch = 0; ch < 3; ++ch) dLc[ch] = inside ? dL_dpixels[ch * HW + pix] : 0.f;
+  float bg_dot = 0.f;
+  bg_dot += bg0 * dLc[0];
+  bg_dot += bg1 * dLc[1];
+  bg_dot += bg2 * dLc[2];
+  float accum_d = 0.f, last_d = 0.f;
+  const float dLd = inside ? dL_dpixels_depth[pix] : 0.f;
+  float A_f = 0.f, D_last = 0.f, dLf[FX];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      accum_c[q][ch] = 0.f;
-      last_c[q][ch] = 0.f;
-      dLc[q][ch] = inside[q] ? dL_dpixels[ch * HW + pix] : 0.f;
-    }
-    bd += bg0 * dLc[q][0];
-    bd += bg1 * dLc[q][1];
-    bd += bg2 * dLc[q][2];
-    bg_dot[q] = bd;
-    accum_d[q] = 0.f;
-    last_d[q] = 0.f;
-    dLd[q] = inside[q] ? dL_dpixels_depth[pix] : 0.f;
-#pragma unroll
-    for (int ch = 0; ch < FX; ++ch) {
-      accum_f[q][ch] = 0.f;
-      dLf[q][ch] = (F > 0 && inside[q]) ? dL_dpixels_lang[ch * HW + pix] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < (REF ? 1 : SLOTS); ++q)
-#pragma unroll
-    for (int ch = 0; ch < FX; ++ch) last_f[q][ch] = 0.f;
+  for (int ch = 0; ch < FX; ++ch) dLf[ch] = (F > 0 && inside) ? dL_dpixels_lang[ch * HW + pix] : 0.f;
+
   // entries at list positions >= max(last_contributor) are skipped by every pixel of the tile
+  int kmax = last_contributor;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) kmax = max(kmax, __shfl_xor(kmax, m));
-  if (lane < ROW) s_row[lane] = 0.f;
-  if (ROW > 64 && lane + 64 < ROW) s_row[lane + 64] = 0.f;
+  if (lane == 0) s_kmax[w] = kmax;
+  __syncthreads();
+  kmax = max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
 
-  for (int kstart = kmax - 1; kstart >= 0; kstart -= 64) {
-    const int cnt = min(64, kstart + 1);
+  for (int kstart = kmax - 1; kstart >= 0; kstart -= B) {
+    const int cnt = min(B, kstart + 1);
     __syncthreads();
-    if (lane < cnt) {
-      const u32 sp = r0 + (u32)(kstart - lane);
-      const u32 gid = point_list[sp];
-      const u32 u = src[sp];
-      s_src[lane] = u;
-      s_flag[lane] = flags[u];
-      s_xy[lane] = reinterpret_cast<const float2*>(means2D)[gid];
-      s_co[lane] = reinterpret_cast<const float4*>(conic_opacity)[gid];
-      float* fr = &s_feat[lane * FR];
-      fr[0] = colors[3 * (size_t)gid + 0];
-      fr[1] = colors[3 * (size_t)gid + 1];
-      fr[2] = colors[3 * (size_t)gid + 2];
-      fr[3] = depths[gid];
+    {
+      const int e = tid & (B - 1);
+      if (e < cnt) {
+        const u32 sp = r0 + (u32)(kstart - e);
+        const u32 gid = point_list[sp];
+        if (tid < B) {
+          const u32 u = src[sp];
+          s_src[e] = u;
+          s_flag[e] = flags[u];
+          s_xy[e] = reinterpret_cast<const float2*>(means2D)[gid];
+          s_co[e] = reinterpret_cast<const float4*>(conic_opacity)[gid];
+        } else {
+          float* fr = &s_feat[e * FR];
+          fr[0] = colors[3 * (size_t)gid + 0];
+          fr[1] = colors[3 * (size_t)gid + 1];
+          fr[2] = colors[3 * (size_t)gid + 2];
+          fr[3] = depths[gid];
 #pragma unroll
-      for (int ch = 0; ch < F; ++ch) fr[4 + ch] = lang[(size_t)gid * F + ch];
+          for (int ch = 0; ch < F; ++ch) fr[4 + ch] = lang[(size_t)gid * F + ch];
+        }
+      }
     }
     __syncthreads();
 
+    // From here to the next batch the four waves run independently: no barrier per splat.
     for (int i = 0; i < cnt; ++i) {
-      if (s_flag[i] == 0) continue;  // whole tile skips this splat: no state changes (CR/backward.cu:1091-1093)
-      const int k = kstart - i;      // == `contributor` after its decrement (CR/backward.cu:999,1073)
+      const u32 fl = s_flag[i];
+      if (fl == 0) continue;  // whole tile skips this splat: no state changes (CR/backward.cu:1091-1093)
+      const bool mine = (fl >> w) & 1u;  // did any pixel of THIS wave's slot blend it in the forward?
+      if (!REF && !mine) continue;
+      const float* fr = &s_feat[i * FR];
+      float D_cur = 0.f;
+      if constexpr (F > 0) {
+#pragma clang fp contract(fast)
+#pragma unroll
+        for (int ch = 0; ch < F; ++ch) D_cur += fr[4 + ch] * dLf[ch];
+      }
+      if (REF && !mine) {
+        // every pixel of this slot skips, but the tile does not: only the unguarded language
+        // recursion advances (CR/backward.cu:1127-1139)
+        if constexpr (F > 0) {
+#pragma clang fp contract(fast)
+          A_f = last_alpha * D_last + (1.f - last_alpha) * A_f;
+          D_last = D_cur;
+        }
+        continue;
+      }
+      const int k = kstart - i;  // == `contributor` after its decrement (CR/backward.cu:999,1073)
       const float2 xy = s_xy[i];
       const float4 co = s_co[i];
-      const float* fr = &s_feat[i * FR];
+
+      // -- decision path: bit-for-bit the forward's arithmetic (no contraction)
+      bool skip = !inside;
+      skip |= (k >= last_contributor);
+      const float dx = xy.x - pixfx, dy = xy.y - pixfy;
+      const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+      skip |= power > 0.0f;
+      const float G = pinned_expf(power);
+      const float alpha = fminf_ref(0.99f, co.w * G);
+      skip |= alpha < 1.0f / 255.0f;
+
       float sum[NP];
 #pragma unroll
       for (int v = 0; v < NP; ++v) sum[v] = 0.f;
-      float lang0[FX];  // REF: rank 0's language partials (slot 0 of lane 0)
+      float lang0[FX];  // REF: rank 0's language partials (lane 0 of wave 0)
 #pragma unroll
       for (int ch = 0; ch < FX; ++ch) lang0[ch] = 0.f;
 
+      // -- value path: FMA contraction allowed (rounding differs from the oracle by ~1 ulp per
+      //    operation; no decision depends on these values)
+      {
+#pragma clang fp contract(fast)
+        const float la = last_alpha, one_m_la = 1.f - last_alpha;
+        if constexpr (REF && F > 0) {  // unguarded (CR/backward.cu:1132-1133)
+          A_f = la * D_last + one_m_la * A_f;
+          D_last = D_cur;
+        }
+        if (!skip) {
+          const float one_m_alpha = 1.f - alpha;
+          T = T / one_m_alpha;
+          const float dchannel_dcolor = alpha * T;
+          float dL_dalpha = 0.0f;
 #pragma unroll
-      for (int q = 0; q < SLOTS; ++q) {
-        bool skip = !inside[q];
-        skip |= (k >= last_contributor[q]);
-        const float dx = xy.x - pixfx[q], dy = xy.y - pixfy[q];
-        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-        skip |= power > 0.0f;
-        const float G = pinned_expf(power);
-        const float alpha = fminf_ref(0.99f, co.w * G);
-        skip |= alpha < 1.0f / 255.0f;
-        const bool slot_live = wave_any(!skip);
-        if (!REF && !slot_live) continue;  // nothing in this slot changes
-
-        if (REF && !slot_live) {
-          // every pixel of this slot skips, but the tile does not: only the unguarded language
-          // recursion advances (CR/backward.cu:1127-1139)
-          if constexpr (F > 0) {
-#pragma unroll
-            for (int ch = 0; ch < F; ++ch)
-              accum_f[q][ch] = last_alpha[q] * last_f[0][ch] + (1.f - last_alpha[q]) * accum_f[q][ch];
+          for (int ch = 0; ch < 3; ++ch) {
+            const float c = fr[ch];
+            accum_c[ch] = la * last_c[ch] + one_m_la * accum_c[ch];
+            last_c[ch] = c;
+            dL_dalpha += (c - accum_c[ch]) * dLc[ch];
           }
-          continue;
-        }
+          const float depth = fr[3];
+          accum_d = la * last_d + one_m_la * accum_d;
+          last_d = depth;
+          dL_dalpha += (depth - accum_d) * dLd;
+          if constexpr (F > 0) {
+            if constexpr (!REF) {
+              A_f = la * D_last + one_m_la * A_f;
+              D_last = D_cur;
+            }
+            dL_dalpha += D_cur - A_f;
+          }
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          if (has_bg) dL_dalpha += (-T_final / one_m_alpha) * bg_dot;
 
-        T[q] = skip ? T[q] : T[q] / (1.f - alpha);
-        const float dchannel_dcolor = alpha * T[q];
-        const bool count = !skip && surv[q];
-        float dL_dalpha = 0.0f;
+          if (surv) {
+            const float dL_dG = co.w * dL_dalpha;
+            const float gdx = G * dx;
+            const float gdy = G * dy;
+            const float dG_ddelx = -gdx * co.x - gdy * co.y;
+            const float dG_ddely = -gdy * co.z - gdx * co.y;
+            sum[0] = dL_dG * dG_ddelx * ddelx_dx;
+            sum[1] = dL_dG * dG_ddely * ddely_dy;
+            sum[2] = -0.5f * gdx * dx * dL_dG;
+            sum[3] = -0.5f * gdx * dy * dL_dG;
+            sum[4] = -0.5f * gdy * dy * dL_dG;
+            sum[5] = G * dL_dalpha;
+            sum[6] = dchannel_dcolor * dLc[0];
+            sum[7] = dchannel_dcolor * dLc[1];
+            sum[8] = dchannel_dcolor * dLc[2];
+            sum[9] = dchannel_dcolor * dLd;
+            if constexpr (!REF && F > 0) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float c = fr[ch];
-          accum_c[q][ch] = skip ? accum_c[q][ch] : last_alpha[q] * last_c[q][ch] + (1.f - last_alpha[q]) * accum_c[q][ch];
-          last_c[q][ch] = skip ? last_c[q][ch] : c;
-          const float dL_dchannel = dLc[q][ch];
-          dL_dalpha += (c - accum_c[q][ch]) * dL_dchannel;
-          sum[6 + ch] += count ? dchannel_dcolor * dL_dchannel : 0.0f;
+              for (int ch = 0; ch < F; ++ch) sum[10 + ch] = dchannel_dcolor * dLf[ch];
+            }
+          }
+          if constexpr (REF && F > 0) {
+#pragma unroll
+            for (int ch = 0; ch < F; ++ch) lang0[ch] = dchannel_dcolor * dLf[ch];
+          }
         }
-        const float depth = fr[3];
-        accum_d[q] = skip ? accum_d[q] : last_alpha[q] * last_d[q] + (1.f - last_alpha[q]) * accum_d[q];
-        last_d[q] = skip ? last_d[q] : depth;
-        dL_dalpha += (depth - accum_d[q]) * dLd[q];
-        sum[9] += count ? dchannel_dcolor * dLd[q] : 0.f;
-        if constexpr (F > 0) {
+      }
+
+      // One multi-value butterfly; afterwards lane l holds the wave total of value l / G_LANES.
+      wave_reduce_multi<NP>(sum, lane);
+      // Transpose into row order: lane j (< NV) fetches value j from lane j * G_LANES.
+      float rowval = __shfl(sum[0], (lane * G_LANES) & 63);
+      if (lane >= NV) rowval = 0.f;
+      if constexpr (REF && F > 0) {
+        // language gradients come from tile rank 0 only (lane 0 of wave 0): broadcast and place
+        if (w == 0) {
 #pragma unroll
           for (int ch = 0; ch < F; ++ch) {
-            const float f = fr[4 + ch];
-            if constexpr (REF) {
-              accum_f[q][ch] = last_alpha[q] * last_f[0][ch] + (1.f - last_alpha[q]) * accum_f[q][ch];
-            } else {
-              accum_f[q][ch] =
-                  skip ? accum_f[q][ch] : last_alpha[q] * last_f[q][ch] + (1.f - last_alpha[q]) * accum_f[q][ch];
-              last_f[q][ch] = skip ? last_f[q][ch] : f;
-            }
-            const float dL_dchannel_F = dLf[q][ch];
-            dL_dalpha += (f - accum_f[q][ch]) * dL_dchannel_F;
-            const float part = skip ? 0.0f : dchannel_dcolor * dL_dchannel_F;
-            if constexpr (REF) {
-              if (q == 0) lang0[ch] = part;
-            } else {
-              sum[10 + ch] += part;
-            }
+            const float v = __shfl(lang0[ch], 0);
+            rowval = (lane == 10 + ch) ? v : rowval;
           }
         }
-        dL_dalpha *= T[q];
-        last_alpha[q] = skip ? last_alpha[q] : alpha;
-        if (has_bg) dL_dalpha += (-T_final[q] / (1.f - alpha)) * bg_dot[q];
-
-        const float dL_dG = co.w * dL_dalpha;
-        const float gdx = G * dx;
-        const float gdy = G * dy;
-        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-        const float dG_ddely = -gdy * co.z - gdx * co.y;
-        sum[0] += count ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
-        sum[1] += count ? dL_dG * dG_ddely * ddely_dy : 0.f;
-        sum[2] += count ? -0.5f * gdx * dx * dL_dG : 0.f;
-        sum[3] += count ? -0.5f * gdx * dy * dL_dG : 0.f;
-        sum[4] += count ? -0.5f * gdy * dy * dL_dG : 0.f;
-        sum[5] += count ? G * dL_dalpha : 0.f;
       }
-      if constexpr (REF && F > 0) {
-        // last_language_feature = f for every thread of a non-skipping tile (CR/backward.cu:1133)
-#pragma unroll
-        for (int ch = 0; ch < F; ++ch) last_f[0][ch] = fr[4 + ch];
-      }
-
-      wave_reduce_multi<NP>(sum, lane);
-      constexpr int G_LANES = 64 / NP;  // lanes per value group after the butterfly
-      const int vi = lane / G_LANES;
-      if ((lane % G_LANES) == 0 && vi < NV) s_row[vi] = sum[0];
-      if constexpr (REF && F > 0) {
-        if (lane == 0) {
-#pragma unroll
-          for (int ch = 0; ch < F; ++ch) s_row[10 + ch] = lang0[ch];
-        }
-      }
-      __syncthreads();
-      float* dst = rows + (size_t)s_src[i] * ROW;
-      if (lane < ROW) dst[lane] = s_row[lane];
-      if (ROW > 64 && lane + 64 < ROW) dst[lane + 64] = s_row[lane + 64];
-      __syncthreads();
+      if (lane < ROW) rows[((size_t)s_src[i] * 4 + w) * ROW + lane] = rowval;
     }
   }
 }
@@ -299,7 +317,7 @@ template <int TILE, int F, int MODE>
 static void launch_bwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, const float* dc, const float* dl, const float* dd, hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
-  render_bwd_kernel<TILE, F, MODE><<<d.ntiles, 64, 0, st>>>(im.ranges, b.point_list, b.src, b.flags, d.W, d.H, d.gx,
+  render_bwd_kernel<TILE, F, MODE><<<d.ntiles, 256, 0, st>>>(im.ranges, b.point_list, b.src, b.flags, d.W, d.H, d.gx,
                                                             d.ntiles, s.background, g.means2D, g.conic_opacity, colors,
                                                             s.language_precomp, g.depths, im.final_T, im.n_contrib, dc,
                                                             dl, dd, b.rows);

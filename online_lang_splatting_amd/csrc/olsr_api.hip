@@ -129,7 +129,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   const FrameDims d = frame_dims(s);
   const size_t N = (size_t)d.W * d.H;
   size_t gb, ib, bb;
-  const GeometryState g = GeometryState::carve(geom_buf, (size_t)s.P, gb);
+  const GeometryState g = GeometryState::carve(geom_buf, (size_t)s.P, grad_row(s.F), gb);
   const ImageState im = ImageState::carve(img_buf, N, (size_t)d.ntiles, ib);
   mark("begin", st);
 
@@ -205,9 +205,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
 extern "C" {
 
 size_t olsr_geometry_bytes(int32_t P, int32_t F) {
-  (void)F;
   size_t bytes = 0;
-  GeometryState::carve(nullptr, (size_t)(P > 0 ? P : 0), bytes);
+  GeometryState::carve(nullptr, (size_t)(P > 0 ? P : 0), grad_row(supported_F(F) ? F : 0), bytes);
   return bytes;
 }
 
@@ -284,7 +283,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
     return fail(OLSR_ERR_ARG, "gradient outputs must not be NULL");
   const FrameDims d = frame_dims(s);
   size_t gb, ib, bb;
-  const GeometryState g = GeometryState::carve(geometry_buffer, (size_t)s.P, gb);
+  const GeometryState g = GeometryState::carve(geometry_buffer, (size_t)s.P, grad_row(s.F), gb);
   const ImageState im = ImageState::carve(const_cast<void*>(image_buffer), (size_t)d.W * d.H, (size_t)d.ntiles, ib);
   BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, grad_row(s.F), bb);
   if (tile_sort_where(d.ntiles)) b.src = b.val_b;
@@ -317,9 +316,9 @@ int olsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
 }
 
 const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t F, const char* name) {
-  (void)F;
   size_t bytes;
-  const GeometryState g = GeometryState::carve(const_cast<void*>(geometry_buffer), (size_t)P, bytes);
+  const GeometryState g =
+      GeometryState::carve(const_cast<void*>(geometry_buffer), (size_t)P, grad_row(supported_F(F) ? F : 0), bytes);
   if (!std::strcmp(name, "depths")) return g.depths;
   if (!std::strcmp(name, "means2D")) return g.means2D;
   if (!std::strcmp(name, "cov3D")) return g.cov3D;

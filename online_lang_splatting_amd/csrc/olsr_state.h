@@ -56,11 +56,13 @@ struct GeometryState {
   uint32_t* val_b;        // [P] (pong)
   uint32_t* depth_order;  // alias of the buffer holding the final order (val_a after 4 passes)
   uint32_t* offsets;      // [P] inclusive scan of tiles_touched in depth order
+  uint32_t* inst_start;   // [P] Gaussian id -> emission index of its first instance
   uint32_t* radix_table;  // [256 * sort_blocks(P)]
   uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
   int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
-  static GeometryState carve(void* buf, size_t P, size_t& bytes) {
+  float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
+  static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
     Carver c(buf);
     GeometryState g;
     g.depths = c.take<float>(P);
@@ -76,11 +78,13 @@ struct GeometryState {
     g.val_b = c.take<uint32_t>(P);
     g.depth_order = g.val_a;
     g.offsets = c.take<uint32_t>(P);
+    g.inst_start = c.take<uint32_t>(P);
     const size_t table = 256 * (size_t)sort_blocks((long long)P);
     g.radix_table = c.take<uint32_t>(table);
     g.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)(table > P ? table : P)) + 1);
     g.counters = c.take<int32_t>(8);
     g.tau_partials = c.take<float>(6 * ((P + 127) / 128) + 6);
+    g.gacc = c.take<float>(P * (size_t)grad_row_floats);
     bytes = c.total();
     return g;
   }
@@ -108,10 +112,10 @@ struct BinningState {
   uint32_t* src;         // [R] sorted position -> emission index
   uint32_t* point_list;  // [R] sorted position -> Gaussian id
   uint32_t* inst_gid;    // [R] emission index -> Gaussian id
-  uint8_t* flags;        // [R] emission index -> "some pixel of the tile used this instance"
+  uint8_t* flags;        // [R] emission index -> bit w: 64-pixel slot w of the tile blended this instance
   uint32_t* radix_table;   // [256 * sort_blocks(R)]
   uint32_t* scan_partials; // [scan_blocks(table) + 1]
-  float* rows;           // [R][grad_row(F)] partial gradients, emission order
+  float* rows;           // [R][4 slots][grad_row(F)] partial gradients, emission order
   static BinningState carve(void* buf, size_t R, int grad_row_floats, size_t& bytes) {
     Carver c(buf);
     BinningState b;
@@ -125,7 +129,7 @@ struct BinningState {
     const size_t table = 256 * (size_t)sort_blocks((long long)R);
     b.radix_table = c.take<uint32_t>(table);
     b.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)table) + 1);
-    b.rows = c.take<float>(R * (size_t)grad_row_floats);
+    b.rows = c.take<float>(R * 4 * (size_t)grad_row_floats);
     bytes = c.total();
     return b;
   }
