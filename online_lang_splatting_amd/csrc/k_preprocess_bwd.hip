@@ -8,9 +8,9 @@
 //     pairs received from the backward composite.  It walks the Gaussians in DEPTH order, i.e.
 //     in emission order: a Gaussian's rows are one contiguous run, neighbouring lanes read
 //     neighbouring runs, and lanes of a wave have similar footprints (balanced loops).  A
-//     Gaussian covering many tiles (up to thousands for a near splat) is not looped over by one
-//     lane: the wave picks it up cooperatively — 64 lanes stride over its instances, then one
-//     multi-value butterfly.  Rows of pairs that were never blended (flag bit clear) are not
+//     Gaussian covering more than RR_BIG tiles (up to thousands for a near splat) is not looped
+//     over by one lane: it goes to a work list and a second, persistent kernel gives it a whole
+//     wave — 64 lanes stride over its instances, then one multi-value butterfly.  Rows of pairs that were never blended (flag bit clear) are not
 //     read — and were never written.  Fixed summation order: bit-reproducible.
 //   preprocess_bwd_kernel — the analytic chain, one lane per Gaussian in INDEX order so that
 //     every per-Gaussian input and output is a coalesced access; dL_dmean2D / dL_dconic /
@@ -55,10 +55,12 @@ __device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
 }
 
 constexpr int RR_THREADS = 256;
-constexpr u32 RR_BIG = 24;  // instances: above this a Gaussian is reduced by the whole wave
+constexpr u32 RR_BIG = 16;      // instances: above this a Gaussian is reduced by a whole wave
+constexpr int RR_BIG_BLOCKS = 1024;  // persistent grid of the wave-per-Gaussian kernel
 
 template <int F>
-__device__ __forceinline__ void add_instance_rows(const float* __restrict__ rows, u32 u, u32 fl, float (&acc)[next_pow2_(10 + F)]) {
+__device__ __forceinline__ void add_instance_rows(const float* __restrict__ rows, u32 u, u32 fl,
+                                                  float (&acc)[next_pow2_(10 + F)]) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
 #pragma unroll
@@ -76,18 +78,17 @@ __device__ __forceinline__ void add_instance_rows(const float* __restrict__ rows
   }
 }
 
+// Pass 1: one lane per Gaussian (depth order) for footprints of <= RR_BIG instances; larger ones
+// are appended to big_list (one aggregated atomic per wave; the list order does not influence
+// any result).
 template <int F>
-__global__ __launch_bounds__(RR_THREADS) void row_reduce_kernel(int P, const u32* __restrict__ order,
-                                                                const u32* __restrict__ offsets,
-                                                                const u32* __restrict__ tiles_touched,
-                                                                const int32_t* __restrict__ radii,
-                                                                const uint8_t* __restrict__ flags,
-                                                                const float* __restrict__ rows,
-                                                                float* __restrict__ gacc) {
+__global__ __launch_bounds__(RR_THREADS) void row_reduce_small_kernel(
+    int P, const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ tiles_touched,
+    const int32_t* __restrict__ radii, const uint8_t* __restrict__ flags, const float* __restrict__ rows,
+    float* __restrict__ gacc, u32* __restrict__ big_list, int32_t* __restrict__ big_count) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   constexpr int NP = next_pow2_(NVAL);
-  constexpr int G_LANES = 64 / NP;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   u32 idx = 0, n = 0, u0 = 0;
@@ -98,13 +99,17 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_kernel(int P, const u32
       u0 = offsets[r] - n;
     }
   }
-  // small footprints: one lane per Gaussian
   if (n > 0 && n <= RR_BIG) {
+    // fetch all slot masks first (independent loads), 4 bits per instance
+    u64 live = 0ull;
+#pragma unroll
+    for (u32 t = 0; t < RR_BIG; ++t)
+      if (t < n) live |= (u64)(flags[u0 + t] & 0xFu) << (4 * t);
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = 0; t < n; ++t) {
-      const u32 fl = flags[u0 + t];
+    for (u32 t = 0; live != 0ull; ++t, live >>= 4) {  // ascending instance (tile) order
+      const u32 fl = (u32)(live & 0xFull);
       if (fl) add_instance_rows<F>(rows, u0 + t, fl, acc);
     }
     float4* dst = reinterpret_cast<float4*>(gacc + (size_t)idx * ROW);
@@ -113,23 +118,47 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_kernel(int P, const u32
       dst[v4] = make_float4(4 * v4 + 0 < NVAL ? acc[4 * v4 + 0] : 0.f, 4 * v4 + 1 < NVAL ? acc[4 * v4 + 1] : 0.f,
                             4 * v4 + 2 < NVAL ? acc[4 * v4 + 2] : 0.f, 4 * v4 + 3 < NVAL ? acc[4 * v4 + 3] : 0.f);
   }
-  // large footprints: the wave takes them one at a time
-  u64 big = ballot(n > RR_BIG);
-  while (big) {
-    const int src_lane = __builtin_ctzll(big);
-    big &= big - 1;
-    const u32 bn = __shfl(n, src_lane), bu0 = __shfl(u0, src_lane), bidx = __shfl(idx, src_lane);
+  const bool is_big = n > RR_BIG;
+  const u64 bigm = ballot(is_big);
+  if (bigm) {
+    u32 base = 0;
+    if (lane == 0) base = (u32)atomicAdd(big_count, (int)__popcll(bigm));
+    base = __shfl(base, 0);
+    if (is_big) big_list[base + (u32)__popcll(bigm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (u32)r;
+  }
+}
+
+// Pass 2: one wave per large-footprint Gaussian: 64 lanes stride over its instances, then one
+// multi-value butterfly.  Persistent grid; the work count lives on the device.
+template <int F>
+__global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(
+    const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ tiles_touched,
+    const uint8_t* __restrict__ flags, const float* __restrict__ rows, float* __restrict__ gacc,
+    const u32* __restrict__ big_list, const int32_t* __restrict__ big_count) {
+  constexpr int ROW = grad_row(F);
+  constexpr int NVAL = 10 + F;
+  constexpr int NP = next_pow2_(NVAL);
+  constexpr int G_LANES = 64 / NP;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(blockIdx.x * (RR_THREADS / 64) + (threadIdx.x >> 6));
+  const int nwaves = (int)(gridDim.x * (RR_THREADS / 64));
+  const int count = *big_count;
+  for (int item = wave; item < count; item += nwaves) {
+    const u32 r = big_list[item];
+    const u32 idx = order[r];
+    const u32 n = tiles_touched[idx];
+    const u32 u0 = offsets[r] - n;
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = (u32)lane; t < bn; t += 64) {
-      const u32 fl = flags[bu0 + t];
-      if (fl) add_instance_rows<F>(rows, bu0 + t, fl, acc);
+    for (u32 t = (u32)lane; t < n; t += 64) {
+      const u32 fl = flags[u0 + t];
+      if (fl) add_instance_rows<F>(rows, u0 + t, fl, acc);
     }
     wave_reduce_rec<NP / 2, 32, NP>(acc, lane);
     float v = __shfl(acc[0], (lane * G_LANES) & 63);
     if (lane >= NVAL) v = 0.f;
-    if (lane < ROW) gacc[(size_t)bidx * ROW + lane] = v;
+    if (lane < ROW) gacc[(size_t)idx * ROW + lane] = v;
   }
 }
 
@@ -556,8 +585,12 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
                         const int32_t* radii, const GradOut& o, float* tau_partials, hipStream_t st) {
   const int nb = tau_partial_blocks(s.P);
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
-  row_reduce_kernel<F><<<(s.P + RR_THREADS - 1) / RR_THREADS, RR_THREADS, 0, st>>>(
-      s.P, g.depth_order, g.offsets, g.tiles_touched, radii, b.flags, b.rows, g.gacc);
+  int32_t* big_count = &g.counters[4];
+  (void)hipMemsetAsync(big_count, 0, sizeof(int32_t), st);
+  row_reduce_small_kernel<F><<<(s.P + RR_THREADS - 1) / RR_THREADS, RR_THREADS, 0, st>>>(
+      s.P, g.depth_order, g.offsets, g.tiles_touched, radii, b.flags, b.rows, g.gacc, g.big_list, big_count);
+  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(g.depth_order, g.offsets, g.tiles_touched, b.flags,
+                                                                 b.rows, g.gacc, g.big_list, big_count);
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, 0, st>>>(
       s.P, s.D, s.M, g.gacc, s.means3D, radii, s.shs, g.clamped,
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
