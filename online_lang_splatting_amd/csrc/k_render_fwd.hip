@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   constexpr int NA = 4 + F;  // r g b depth lang[F]
   constexpr int B = FWD_BATCH;
 
-  __shared__ float2 s_xy[B];
-  __shared__ float4 s_co[B];
+  __shared__ float4 s_geo[B + 1];  // {mean x, mean y, conservative power threshold, -}
+  __shared__ float4 s_co[B + 1];   // {conic a, b, c, opacity}
   __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
   __shared__ u32 s_id[B];
   __shared__ u32 s_src[B];
@@ -79,8 +79,14 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
           s_src[e] = src[sp];
           s_flag[e] = 0;
           s_touch[e] = 0;
-          s_xy[e] = reinterpret_cast<const float2*>(means2D)[gid];
-          s_co[e] = reinterpret_cast<const float4*>(conic_opacity)[gid];
+          const float2 m = reinterpret_cast<const float2*>(means2D)[gid];
+          const float4 c = reinterpret_cast<const float4*>(conic_opacity)[gid];
+          // alpha = o * exp(power) can only reach 1/255 if power >= -ln(255 o).  Keep a margin far
+          // above the error of __logf and of the pinned exp, so that the wave-level early-out
+          // below never drops a pair the exact test would keep.
+          const float L = -__logf(255.0f * c.w);
+          s_geo[e] = make_float4(m.x, m.y, L - (1e-3f + 1e-4f * fabsf(L)), 0.f);
+          s_co[e] = c;
         } else {
           float* fr = &s_feat[e * FR];
           fr[0] = colors[3 * (size_t)gid + 0];
@@ -95,34 +101,35 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
     __syncthreads();
 
     if (!wave_all(done)) {
+      // software pipeline: splat j+1's geometry is fetched from LDS while splat j is evaluated
+      float4 ngeo = s_geo[0];
+      float4 nco = s_co[0];
       for (int j = 0; j < cnt; ++j) {
-        const float2 xy = s_xy[j];
-        const float4 co = s_co[j];
-        bool contrib = false, touched = false;
-        if (!done) {
-          const float dx = xy.x - pixfx, dy = xy.y - pixfy;
-          const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-          if (!(power > 0.0f)) {
-            const float alpha = fminf_ref(0.99f, co.w * pinned_expf(power));
-            if (!(alpha < 1.0f / 255.0f)) {
-              const float test_T = T * (1 - alpha);
-              if (test_T < 0.0001f) {
-                done = true;
-              } else {
-                const float* fr = &s_feat[j * FR];
+        const float4 geo = ngeo;
+        const float4 co = nco;
+        ngeo = s_geo[j + 1];  // arrays hold B + 1 entries: the look-ahead never leaves them
+        nco = s_co[j + 1];
+        // Branch-free restatement of CR/forward.cu:449-476: same tests, same order of arithmetic.
+        const float dx = geo.x - pixfx, dy = geo.y - pixfy;
+        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        // wave-level early-out: no live pixel of this slot can reach the alpha floor
+        if (!wave_any(!done && !(power < geo.z))) continue;
+        const float alpha = fminf_ref(0.99f, co.w * pinned_expf(power));
+        const float test_T = T * (1 - alpha);
+        const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        const bool term = ok && (test_T < 0.0001f);
+        const bool contrib = ok && !term;
+        done = done || term;
+        if (contrib) {
+          const float* fr = &s_feat[j * FR];
 #pragma unroll
-                for (int k = 0; k < NA; ++k) acc[k] += fr[k] * alpha * T;
-                touched = test_T > 0.5f;
-                T = test_T;
-                last_contributor = (u32)(base + j + 1);
-                contrib = true;
-              }
-            }
-          }
+          for (int k = 0; k < NA; ++k) acc[k] += fr[k] * alpha * T;
+          T = test_T;
+          last_contributor = (u32)(base + j + 1);
         }
         const u64 cb = ballot(contrib);
         if (cb != 0ull) {
-          const u32 tc = (u32)__popcll(ballot(touched));
+          const u32 tc = (u32)__popcll(ballot(contrib && test_T > 0.5f));
           if ((tid & 63) == 0) {
             atomicOr(&s_flag[j], 1u << w);
             if (tc) atomicAdd(&s_touch[j], tc);

@@ -24,6 +24,32 @@ __device__ __forceinline__ bool wave_all(bool p) { return ballot(!p) == 0ull; }
 __device__ __forceinline__ float bits2f(u32 u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ u32 f2bits(float f) { return __builtin_bit_cast(u32, f); }
 
+// ---- DPP wave reduction --------------------------------------------------------------------
+// Sum over the 64 lanes with data-parallel-primitive row operations (no LDS traffic): xor-1 and
+// xor-2 inside quads, half-mirror and mirror inside each row of 16, then row_bcast:15 / :31 to
+// chain the four rows.  The total lands in lane 63.  Fixed order => bit-reproducible.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_mov<0xB1>(v);        // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E>(v);        // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x141>(v);       // row_half_mirror
+  v += dpp_mov<0x140>(v);       // row_mirror
+  v += dpp_mov<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+  v += dpp_mov<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ float lane_read(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// put a wave-uniform value into one lane of `row` (this clang has no writelane builtin; a
+// compare + select with a scalar source is what it lowers to anyway)
+__device__ __forceinline__ float lane_write(float row, float uniform_value, int lane, int my_lane) {
+  return (my_lane == lane) ? uniform_value : row;
+}
+
 // ---- pinned exp --------------------------------------------------------------------------
 // Cephes-style expf: n = rne(x*log2e); r = x - n*ln2 (two-term); degree-5 polynomial;
 // scale by 2^n.  Clamped to [-87, 88] so 2^n is a normal number.
