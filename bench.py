@@ -49,6 +49,22 @@ def algorithmic_bytes(P, R, N, C=3, F=15, M=1):
     return per
 
 
+def measured_traffic(kernel_stage, F):
+    """HBM bytes per launch of the stage's kernel from the newest profiles/*_pmc_traffic.json (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as MI355X_MICROARCH.md prescribes);
+    None when no summary has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    prefix = {"render_forward": "render_fwd_kernel", "render_backward": "render_bwd_kernel"}[kernel_stage]
+    for k, v in d["kernels"].items():
+        if k.startswith(prefix) and f", {F}" in k:
+            return v["traffic_bytes"], os.path.basename(files[-1])
+    return None, None
+
+
 def device_inputs(sc, cam, dev):
     g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
              rotations=sc.rotations.to(dev), shs=sc.shs.to(dev),
@@ -174,8 +190,10 @@ def main():
         roof = None
         if dom:
             achieved = model[dom] / (avg[dom] * 1e-3) / 1e9
+            traffic, traffic_src = measured_traffic(dom, F) if a.config == 3 else (None, None)
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": int(model[dom]), "avg_launch_ms": round(avg[dom], 4)}
         gpu_ms = sum(avg.values())
         frame = {"algorithmic_bytes": int(model["frame"]),
