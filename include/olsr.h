@@ -143,6 +143,21 @@ int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   float *dL_dscales, float *dL_drotations, float *dL_dtau,
                   float *dL_dtau_sum, void *hip_stream);
 
+/* Adds one view's per-Gaussian gradients into the flat fp32 buffer
+ *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]
+ * that a frame-sharded trainer all-reduces once per optimisation step, and updates the
+ * densification statistics densify[P][2] += {||dL_dmeans2D.xy||, 1} for visible Gaussians and
+ * max_radii[P] = max(max_radii, radii).  No reference counterpart in native code: it is what
+ * autograd's `.grad +=` over the views of BackEnd.map (utils/slam_backend.py:510-670) and
+ * GaussianModel.add_densification_stats (gaussian_splatting/scene/gaussian_model.py:965-969) do
+ * with separate PyTorch kernels. */
+int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, const float *dL_dmeans3D,
+                              const float *dL_dsh, const float *dL_dopacity,
+                              const float *dL_dscales, const float *dL_drotations,
+                              const float *dL_dlanguage, const float *dL_dmeans2D,
+                              const int32_t *radii, float *flat, float *densify,
+                              int32_t *max_radii, void *hip_stream);
+
 /* Near-plane visibility test.  Replaces markVisible / checkFrustum
  * (DGR/rasterize_points.cu:457-476; CR/rasterizer_impl.cu:54-66,141-153).
  * present[P] is one byte per Gaussian (bool). */

@@ -28,6 +28,7 @@ UNITS = [
     ("k_render_bwd.hip", "k_render_bwd_ref.o", ["-DOLSR_BWD_TU_MODE=0"]),
     ("k_render_bwd.hip", "k_render_bwd_exact.o", ["-DOLSR_BWD_TU_MODE=1"]),
     ("k_preprocess_bwd.hip", "k_preprocess_bwd.o", []),
+    ("k_accumulate.hip", "k_accumulate.o", []),
 ]
 HEADERS = ["olsr_device.h", "olsr_state.h", "olsr_kernels.h", os.path.join("..", "..", "include", "olsr.h")]
 

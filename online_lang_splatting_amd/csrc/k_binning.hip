@@ -254,6 +254,8 @@ void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, hi
 // ------------------------------------------------------------------------------- emission
 // duplicateWithKeys (CR/rasterizer_impl.cu:70-111), one thread per depth rank.  The depth half
 // of the reference's key is implied by the emission order; only the tile id is written.
+constexpr u32 EMIT_BIG = 32;  // instances: above this the whole wave writes the Gaussian's keys
+
 template <int TILE>
 __global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict__ order,
                                                    const u32* __restrict__ offsets,
@@ -263,20 +265,42 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict_
                                                    u32* __restrict__ keys, u32* __restrict__ inst_gid,
                                                    u32* __restrict__ inst_start) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P) return;
-  if (counters[2] != 0) return;  // overflow: nothing is emitted
-  const u32 g = order[r];
-  const int rad = radii[g];
-  if (rad > 0) {
-    u32 off = offsets[r] - tiles_touched[g];
-    inst_start[g] = off;
-    const Rect rc = get_rect<TILE>(means2D[2 * (size_t)g], means2D[2 * (size_t)g + 1], rad, gx, gy);
+  if (counters[2] != 0) return;  // overflow: nothing is emitted (uniform)
+  const int lane = threadIdx.x & 63;
+  u32 g = 0, n = 0, off = 0;
+  Rect rc = {0, 0, 0, 0};
+  if (r < P) {
+    g = order[r];
+    const int rad = radii[g];
+    if (rad > 0) {
+      n = tiles_touched[g];
+      off = offsets[r] - n;
+      inst_start[g] = off;
+      rc = get_rect<TILE>(means2D[2 * (size_t)g], means2D[2 * (size_t)g + 1], rad, gx, gy);
+    }
+  }
+  if (n > 0 && n <= EMIT_BIG) {
+    u32 o = off;
     for (int y = rc.y0; y < rc.y1; y++)
       for (int x = rc.x0; x < rc.x1; x++) {
-        keys[off] = (u32)(y * gx + x);
-        inst_gid[off] = g;
-        off++;
+        keys[o] = (u32)(y * gx + x);
+        inst_gid[o] = g;
+        o++;
       }
+  }
+  // near splats cover hundreds of tiles: the wave writes those runs together, coalesced
+  u64 big = ballot(n > EMIT_BIG);
+  while (big) {
+    const int sl = __builtin_ctzll(big);
+    big &= big - 1;
+    const u32 bn = __shfl(n, sl), boff = __shfl(off, sl), bg = __shfl(g, sl);
+    const int x0 = __shfl(rc.x0, sl), y0 = __shfl(rc.y0, sl), x1 = __shfl(rc.x1, sl);
+    const u32 wrect = (u32)(x1 - x0);
+    for (u32 t = (u32)lane; t < bn; t += 64) {
+      const u32 yy = t / wrect, xx = t - yy * wrect;
+      keys[boff + t] = (u32)((y0 + (int)yy) * gx + (x0 + (int)xx));
+      inst_gid[boff + t] = bg;
+    }
   }
 }
 

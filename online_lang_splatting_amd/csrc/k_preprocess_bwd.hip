@@ -56,7 +56,7 @@ __device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
 
 constexpr int RR_THREADS = 256;
 constexpr u32 RR_BIG = 16;      // instances: above this a Gaussian is reduced by a whole wave
-constexpr int RR_BIG_BLOCKS = 1024;  // persistent grid of the wave-per-Gaussian kernel
+constexpr int RR_BIG_BLOCKS = 2048;  // persistent grid of the wave-per-Gaussian kernel (8 waves/SIMD)
 
 template <int F>
 __device__ __forceinline__ void add_instance_rows(const float* __restrict__ rows, u32 u, u32 fl,
@@ -85,7 +85,7 @@ template <int F>
 __global__ __launch_bounds__(RR_THREADS) void row_reduce_small_kernel(
     int P, const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ tiles_touched,
     const int32_t* __restrict__ radii, const uint8_t* __restrict__ flags, const float* __restrict__ rows,
-    float* __restrict__ gacc, u32* __restrict__ big_list, int32_t* __restrict__ big_count) {
+    float* __restrict__ gacc, uint4* __restrict__ big_list, int32_t* __restrict__ big_count) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   constexpr int NP = next_pow2_(NVAL);
@@ -124,17 +124,20 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_small_kernel(
     u32 base = 0;
     if (lane == 0) base = (u32)atomicAdd(big_count, (int)__popcll(bigm));
     base = __shfl(base, 0);
-    if (is_big) big_list[base + (u32)__popcll(bigm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (u32)r;
+    if (is_big)
+      big_list[base + (u32)__popcll(bigm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = make_uint4(idx, n, u0, 0u);
   }
 }
 
 // Pass 2: one wave per large-footprint Gaussian: 64 lanes stride over its instances, then one
-// multi-value butterfly.  Persistent grid; the work count lives on the device.
+// multi-value butterfly.  Persistent grid; the work count lives on the device; the next item's
+// descriptor is fetched while the current one is reduced.
 template <int F>
-__global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(
-    const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ tiles_touched,
-    const uint8_t* __restrict__ flags, const float* __restrict__ rows, float* __restrict__ gacc,
-    const u32* __restrict__ big_list, const int32_t* __restrict__ big_count) {
+__global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const uint8_t* __restrict__ flags,
+                                                                    const float* __restrict__ rows,
+                                                                    float* __restrict__ gacc,
+                                                                    const uint4* __restrict__ big_list,
+                                                                    const int32_t* __restrict__ big_count) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   constexpr int NP = next_pow2_(NVAL);
@@ -143,11 +146,12 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(
   const int wave = (int)(blockIdx.x * (RR_THREADS / 64) + (threadIdx.x >> 6));
   const int nwaves = (int)(gridDim.x * (RR_THREADS / 64));
   const int count = *big_count;
+  if (wave >= count) return;
+  uint4 cur = big_list[wave];
   for (int item = wave; item < count; item += nwaves) {
-    const u32 r = big_list[item];
-    const u32 idx = order[r];
-    const u32 n = tiles_touched[idx];
-    const u32 u0 = offsets[r] - n;
+    const int nxt = item + nwaves;
+    const uint4 next = big_list[nxt < count ? nxt : item];
+    const u32 idx = cur.x, n = cur.y, u0 = cur.z;
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(
     float v = __shfl(acc[0], (lane * G_LANES) & 63);
     if (lane >= NVAL) v = 0.f;
     if (lane < ROW) gacc[(size_t)idx * ROW + lane] = v;
+    cur = next;
   }
 }
 
@@ -589,8 +594,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
   (void)hipMemsetAsync(big_count, 0, sizeof(int32_t), st);
   row_reduce_small_kernel<F><<<(s.P + RR_THREADS - 1) / RR_THREADS, RR_THREADS, 0, st>>>(
       s.P, g.depth_order, g.offsets, g.tiles_touched, radii, b.flags, b.rows, g.gacc, g.big_list, big_count);
-  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(g.depth_order, g.offsets, g.tiles_touched, b.flags,
-                                                                 b.rows, g.gacc, g.big_list, big_count);
+  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(b.flags, b.rows, g.gacc, g.big_list, big_count);
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, 0, st>>>(
       s.P, s.D, s.M, g.gacc, s.means3D, radii, s.shs, g.clamped,
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,

@@ -315,6 +315,22 @@ int olsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
   return OLSR_OK;
 }
 
+int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, const float* dL_dmeans3D, const float* dL_dsh,
+                              const float* dL_dopacity, const float* dL_dscales, const float* dL_drotations,
+                              const float* dL_dlanguage, const float* dL_dmeans2D, const int32_t* radii, float* flat,
+                              float* densify, int32_t* max_radii, void* hip_stream) {
+  if (P < 0 || M < 0 || F < 0) return fail(OLSR_ERR_ARG, "P, M, F must be >= 0");
+  if (P == 0) return OLSR_OK;
+  if (!dL_dmeans3D || !dL_dopacity || !dL_dscales || !dL_drotations || !dL_dmeans2D || !radii || !flat || !densify ||
+      !max_radii || (M > 0 && !dL_dsh) || (F > 0 && !dL_dlanguage))
+    return fail(OLSR_ERR_ARG, "gradient, radii and accumulator pointers must not be NULL");
+  launch_accumulate(P, M, F, dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations, dL_dlanguage, dL_dmeans2D,
+                    radii, flat, densify, max_radii, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("accumulate launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
 const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t F, const char* name) {
   size_t bytes;
   const GeometryState g =

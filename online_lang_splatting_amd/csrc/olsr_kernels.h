@@ -57,4 +57,9 @@ void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const G
                                 hipStream_t st);
 int tau_partial_blocks(int P);
 
+// k_accumulate.hip
+void launch_accumulate(int P, int M, int F, const float* dmeans3D, const float* dsh, const float* dopacity,
+                       const float* dscales, const float* drot, const float* dlang, const float* dmeans2D,
+                       const int32_t* radii, float* flat, float* densify, int32_t* max_radii, hipStream_t st);
+
 }  // namespace olsr

@@ -13,6 +13,7 @@
 //               forward composite) and the partial-gradient rows the backward composite
 //               writes for the per-Gaussian reduction.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -62,7 +63,7 @@ struct GeometryState {
   int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
-  uint32_t* big_list;     // [P] backward scratch: depth ranks of large-footprint Gaussians (count: counters[4])
+  uint4* big_list;        // [P] backward scratch: {id, #instances, first instance} of large-footprint Gaussians (count: counters[4])
   static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
     Carver c(buf);
     GeometryState g;
@@ -86,7 +87,7 @@ struct GeometryState {
     g.counters = c.take<int32_t>(8);
     g.tau_partials = c.take<float>(6 * ((P + 127) / 128) + 6);
     g.gacc = c.take<float>(P * (size_t)grad_row_floats);
-    g.big_list = c.take<uint32_t>(P);
+    g.big_list = c.take<uint4>(P);
     bytes = c.total();
     return g;
   }

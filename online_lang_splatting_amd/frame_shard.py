@@ -75,7 +75,21 @@ class GradientBucket:
         return self.flat[:, self._sl[name]]
 
     def accumulate(self, grads: Dict[str, torch.Tensor], radii: torch.Tensor):
-        """Add one view's gradients (names of the C-ABI / reference backward outputs)."""
+        """Add one view's gradients (names of the C-ABI / reference backward outputs).  On the GPU this
+        is one fused kernel (olsr_accumulate_gradients); the torch formulation below is the CPU path of
+        the gloo tests and the specification the kernel is tested against."""
+        if self.flat.is_cuda:
+            P = self.flat.shape[0]
+
+            def p(t):
+                return t.data_ptr() if t is not None and t.numel() > 0 else None
+            check(lib().olsr_accumulate_gradients(
+                P, self.layout.M, self.layout.F, p(grads["dL_dmeans3D"]), p(grads.get("dL_dsh")),
+                p(grads["dL_dopacity"]), p(grads["dL_dscales"]), p(grads["dL_drotations"]),
+                p(grads.get("dL_dlanguage")), p(grads["dL_dmeans2D"]), radii.data_ptr(), self.flat.data_ptr(),
+                self.densify.data_ptr(), self.max_radii.data_ptr(),
+                C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)))
+            return
         self.view("means3D").add_(grads["dL_dmeans3D"])
         if self.layout.M > 0:
             self.view("sh").add_(grads["dL_dsh"].reshape(grads["dL_dsh"].shape[0], -1))

@@ -145,3 +145,24 @@ def test_full_size_config3_properties(hip):
         assert torch.equal(g1[k], g2[k]), k
         assert bool(torch.isfinite(g1[k]).all()), k
     hip.TILE, hip.BWD_MODE = 15, 0
+
+
+def test_fused_accumulate_matches_torch_formulation(hip):
+    """olsr_accumulate_gradients == GradientBucket's torch specification (the gloo tests' path)."""
+    from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket
+    dev = torch.device(DEV)
+    P, M, F = 1000, 4, 15
+    g = torch.Generator().manual_seed(3)
+    grads = dict(dL_dmeans3D=torch.randn(P, 3, generator=g), dL_dsh=torch.randn(P, M, 3, generator=g),
+                 dL_dopacity=torch.randn(P, 1, generator=g), dL_dscales=torch.randn(P, 3, generator=g),
+                 dL_drotations=torch.randn(P, 4, generator=g), dL_dlanguage=torch.randn(P, F, generator=g),
+                 dL_dmeans2D=torch.randn(P, 3, generator=g))
+    radii = torch.randint(0, 5, (P,), generator=g, dtype=torch.int32)
+    ref = GradientBucket(P, GradLayout(M, F), "cpu")
+    got = GradientBucket(P, GradLayout(M, F), dev)
+    for _ in range(3):
+        ref.accumulate(grads, radii)
+        got.accumulate({k: v.to(dev) for k, v in grads.items()}, radii.to(dev))
+    torch.testing.assert_close(got.flat.cpu(), ref.flat, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got.densify.cpu(), ref.densify, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got.max_radii.cpu(), ref.max_radii)
