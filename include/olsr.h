@@ -123,25 +123,42 @@ int olsr_forward_async(const olsr_scene *scene,
  * (DGR/rasterize_points.cu:243-331,333-455; CR/rasterizer_impl.cu:529-636,638-756).
  * `num_rendered` is the R returned by olsr_forward — or, for buffers filled by
  * olsr_forward_async, the `capacity` that call was given (it fixes the carving of the
- * binning buffer).  Gradient outputs, all fully overwritten:
+ * binning buffer).
+ *
+ * Scratch.  The composite backward writes one partial-gradient row per (instance, 64-pixel
+ * slot) pair that the forward actually blended; the per-Gaussian reduction then sums them in a
+ * fixed order (this replaces the reference's float atomicAdd, CR/backward.cu:1176-1198, and
+ * makes the gradients bit-reproducible).  The number of such pairs, L <= 4 R, is known on the
+ * device after the forward.  Two ways to provide the row buffer, mirroring the forward:
+ *   - scratch_alloc != NULL: the function computes L, synchronises once, and asks the callback
+ *     for olsr_backward_scratch_bytes(L, F) bytes (what the drop-in Python path does);
+ *   - scratch_alloc == NULL: `scratch` holds olsr_backward_scratch_bytes(scratch_rows, F) bytes;
+ *     no synchronisation.  If L > scratch_rows nothing is written and the overflow is reported
+ *     through status_dev.
+ * status_dev (device int32[2], may be NULL) receives {L, overflow flag}.
+ *
+ * Gradient outputs, all fully overwritten:
  *   dL_dmeans2D[P,3]  dL_dcolors[P,3]  dL_dlanguage[P,F]  dL_dopacity[P]
  *   dL_dmeans3D[P,3]  dL_dcov3D[P,6]   dL_dsh[P,M,3]      dL_dscales[P,3]
  *   dL_drotations[P,4]  dL_dtau[P,6]
  * dL_dconic[P,4] and dL_ddepths[P] are the reference's internal buffers
- * (DGR/rasterize_points.cu:390-391); they may be NULL.  The geometry and binning buffers
- * carry scratch regions the backward writes (the reference passes them as char* too).  dL_dtau_sum[6] (may be
- * NULL) receives the sum over P that the Python layer computes at
+ * (DGR/rasterize_points.cu:390-391); they may be NULL.  The geometry and binning buffers carry
+ * scratch regions the backward writes (the reference passes them as char* too).
+ * dL_dtau_sum[6] (may be NULL) receives the sum over P that the Python layer computes at
  * DGR/diff_gaussian_rasterization/__init__.py:383-385. */
+size_t olsr_backward_scratch_bytes(int64_t rows, int32_t F);
 int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   void *geometry_buffer, int32_t num_rendered,
                   void *binning_buffer, const void *image_buffer,
+                  olsr_alloc_fn scratch_alloc, void *scratch_user,
+                  void *scratch, int64_t scratch_rows,
                   const float *dL_dout_color, const float *dL_dout_language,
                   const float *dL_dout_depth,
                   float *dL_dmeans2D, float *dL_dconic, float *dL_dopacity,
                   float *dL_dcolors, float *dL_dlanguage, float *dL_ddepths,
                   float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
                   float *dL_dscales, float *dL_drotations, float *dL_dtau,
-                  float *dL_dtau_sum, void *hip_stream);
+                  float *dL_dtau_sum, int32_t *status_dev, void *hip_stream);
 
 /* Adds one view's per-Gaussian gradients into the flat fp32 buffer
  *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]
@@ -169,7 +186,7 @@ int olsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
  * (or NULL for an unknown name).  Names: geometry — "depths" f32[P], "means2D"
  * f32[P,2], "cov3D" f32[P,6], "conic_opacity" f32[P,4], "rgb" f32[P,3], "clamped"
  * u8[P,3], "tiles_touched" u32[P], "depth_order" u32[P]; binning — "point_list"
- * u32[R]; image — "final_T" f32[H*W], "n_contrib" u32[H*W], "ranges" u32[tiles,2]. */
+ * u32[R], "flags" u8[R], "rowbase" u32[R+1]; image — "final_T" f32[H*W], "n_contrib" u32[H*W], "ranges" u32[tiles,2]. */
 const void *olsr_geometry_field(const void *geometry_buffer, int32_t P, int32_t F, const char *name);
 const void *olsr_binning_field(const void *binning_buffer, int64_t num_rendered, int32_t F,
                                const char *name);

@@ -149,13 +149,16 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
         def p(name):
             t = g.get(name)
             return t.data_ptr() if t is not None and t.numel() > 0 else None
+        scratch = _Resizer(dev)  # sized exactly for the live (instance, slot) rows: one host sync
         check(lib().olsr_backward(
             C.byref(s), rad.data_ptr() if P else None, geomBuffer.data_ptr(), int(R), binningBuffer.data_ptr(),
-            imageBuffer.data_ptr(), dc.data_ptr() if dc is not None else None,
+            imageBuffer.data_ptr(), scratch.cb, None, None, 0, dc.data_ptr() if dc is not None else None,
             dl.data_ptr() if dl is not None else None, dd.data_ptr() if dd is not None else None,
             p("dL_dmeans2D"), p("dL_dconic"), p("dL_dopacity"), p("dL_dcolors"), p("dL_dlanguage"), p("dL_ddepths"),
             p("dL_dmeans3D"), p("dL_dcov3D"), p("dL_dsh"), p("dL_dscales"), p("dL_drotations"), p("dL_dtau"),
-            p("dL_dtau_sum"), _stream(dev)))
+            p("dL_dtau_sum"), None, _stream(dev)))
+        # the scratch tensor may be released now: later work on this stream is ordered after the kernels
+        # that read it, and the caching allocator reuses blocks stream-ordered
     return g
 
 

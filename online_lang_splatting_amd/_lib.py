@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libolsr.so")
 
 # every symbol include/olsr.h declares
 EXPORTS = (
-    "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_forward", "olsr_forward_async",
+    "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_backward_scratch_bytes", "olsr_forward", "olsr_forward_async",
     "olsr_backward", "olsr_accumulate_gradients", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
     "olsr_set_profiling", "olsr_get_stage_times", "olsr_last_error", "olsr_version",
 )
@@ -48,7 +48,9 @@ def lib():
     L.olsr_forward.restype = C.c_int
     L.olsr_forward_async.argtypes = [scene_p, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.olsr_forward_async.restype = C.c_int
-    L.olsr_backward.argtypes = [scene_p, vp, vp, i32, vp, vp] + [vp] * 3 + [vp] * 13 + [vp]
+    L.olsr_backward_scratch_bytes.argtypes, L.olsr_backward_scratch_bytes.restype = [i64, i32], sz
+    L.olsr_backward.argtypes = ([scene_p, vp, vp, i32, vp, vp, _abi.ALLOC_FN, vp, vp, i64] + [vp] * 3 + [vp] * 13
+                                + [vp, vp])
     L.olsr_backward.restype = C.c_int
     L.olsr_accumulate_gradients.argtypes = [i32, i32, i32] + [vp] * 12
     L.olsr_accumulate_gradients.restype = C.c_int

@@ -316,6 +316,91 @@ void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g
                                         g.counters, b.key_a, b.inst_gid, g.inst_start);
 }
 
+// ------------------------------------------------------------------------------- row compaction
+// Exclusive scan of popcount(flags[u] & 15) — how many slot rows each instance owns.  Same
+// three-kernel scan as above, specialised so that a thread fetches its 16 flag bytes with ONE
+// 16-byte load (the flag array is 256-byte aligned and padded to a multiple of 16).
+__device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, int64_t base, int64_t n, u32 (&v)[16]) {
+  uint4 q = make_uint4(0u, 0u, 0u, 0u);
+  if (base + 16 <= n) {
+    q = *reinterpret_cast<const uint4*>(flags + base);
+  } else {
+    u32 w[4] = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < 16; ++k)
+      if (base + k < n) w[k >> 2] |= (u32)flags[base + k] << (8 * (k & 3));
+    q = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  const u32 w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (u32)__popc((w4[k >> 2] >> (8 * (k & 3))) & 0xFu);
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void popc_reduce_kernel(const uint8_t* __restrict__ flags, int64_t n,
+                                                                  u32* __restrict__ partials) {
+  static_assert(SCAN_ITEMS == 16, "one 16-byte load per thread");
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  u32 v[16];
+  load_popc16(flags, base, n, v);
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += v[k];
+  u32 total;
+  block_excl_scan_256(s, &total);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t* __restrict__ flags, int64_t n,
+                                                                 const u32* __restrict__ partials,
+                                                                 u32* __restrict__ out) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  u32 v[16];
+  load_popc16(flags, base, n, v);
+  u32 s = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += v[k];
+  u32 run = block_excl_scan_256(s, nullptr) + partials[blockIdx.x];
+  u32 o[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    o[k] = run;
+    run += v[k];
+  }
+  if (base + 16 <= n) {
+    uint4* dst = reinterpret_cast<uint4*>(out + base);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+    dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+  } else {
+    for (int k = 0; k < 16; ++k)
+      if (base + k < n) out[base + k] = o[k];
+  }
+}
+
+__global__ void rows_finalize_kernel(const u32* partials, int nb, int64_t n, u32* rowbase, long long row_capacity,
+                                     int32_t* counters) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const u32 L = partials[nb];
+    rowbase[n] = L;
+    counters[6] = (int32_t)L;
+    counters[7] = ((long long)L > row_capacity) ? 1 : 0;
+  }
+}
+
+void launch_row_compaction(const uint8_t* flags, int64_t n_host, uint32_t* rowbase, uint32_t* partials,
+                           int64_t row_capacity, int32_t* counters, hipStream_t st) {
+  if (n_host <= 0) {
+    (void)hipMemsetAsync(rowbase, 0, sizeof(u32), st);
+    (void)hipMemsetAsync(counters + 6, 0, 2 * sizeof(int32_t), st);
+    return;
+  }
+  const int nb = scan_blocks(n_host);
+  popc_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, partials);
+  scan_partials_kernel<<<1, 1024, 0, st>>>(partials, nb);
+  popc_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, partials, rowbase);
+  rows_finalize_kernel<<<1, 64, 0, st>>>(partials, nb, n_host, rowbase, (long long)row_capacity, counters);
+}
+
 // ------------------------------------------------------------------------------- ranges
 // identifyTileRanges (CR/rasterizer_impl.cu:116-138); ranges must be zeroed beforehand.
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict__ keys, int64_t n_host,

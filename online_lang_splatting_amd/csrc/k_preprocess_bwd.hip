@@ -4,14 +4,14 @@
 // Replaces the atomicAdd accumulation of CR/backward.cu:1176-1198 together with
 // computeCov2DCUDA (:150-346), preprocessCUDA / language_preprocessCUDA (:418-539, 541-682),
 // computeCov3D (:350-413) and computeColorFromSH (:21-145).  Two kernels:
-//   row_reduce_kernel   — sums, per Gaussian, the partial-gradient rows its (instance, slot)
-//     pairs received from the backward composite.  It walks the Gaussians in DEPTH order, i.e.
-//     in emission order: a Gaussian's rows are one contiguous run, neighbouring lanes read
-//     neighbouring runs, and lanes of a wave have similar footprints (balanced loops).  A
-//     Gaussian covering more than RR_BIG tiles (up to thousands for a near splat) is not looped
-//     over by one lane: it goes to a work list and a second, persistent kernel gives it a whole
-//     wave — 64 lanes stride over its instances, then one multi-value butterfly.  Rows of pairs that were never blended (flag bit clear) are not
-//     read — and were never written.  Fixed summation order: bit-reproducible.
+//   row_reduce_*_kernel — sums, per Gaussian, the partial-gradient rows its (instance, slot)
+//     pairs received from the backward composite.  Rows are compacted in emission (= depth)
+//     order, so a Gaussian's rows are ONE dense run [rowbase[u0], rowbase[u0+n]); the kernels
+//     walk the Gaussians in depth order, neighbouring lanes stream neighbouring runs.  A run
+//     longer than RR_BIG rows (near splats cover thousands of tiles) is not looped over by one
+//     lane: it goes to a work list and a second, persistent kernel gives it a whole wave —
+//     64 lanes stride over the rows, then one multi-value butterfly.  Fixed summation order:
+//     bit-reproducible.
 //   preprocess_bwd_kernel — the analytic chain, one lane per Gaussian in INDEX order so that
 //     every per-Gaussian input and output is a coalesced access; dL_dmean2D / dL_dconic /
 //     dL_dcolor / dL_ddepth are taken from the reduced row in registers and the four reference
@@ -55,89 +55,80 @@ __device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
 }
 
 constexpr int RR_THREADS = 256;
-constexpr u32 RR_BIG = 16;      // instances: above this a Gaussian is reduced by a whole wave
+constexpr u32 RR_BIG = 16;           // rows: above this a Gaussian is reduced by a whole wave
 constexpr int RR_BIG_BLOCKS = 2048;  // persistent grid of the wave-per-Gaussian kernel (8 waves/SIMD)
 
 template <int F>
-__device__ __forceinline__ void add_instance_rows(const float* __restrict__ rows, u32 u, u32 fl,
-                                                  float (&acc)[next_pow2_(10 + F)]) {
+__device__ __forceinline__ void add_row(const float* __restrict__ rows, u32 row, float (&acc)[next_pow2_(10 + F)]) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
+  const float4* p = reinterpret_cast<const float4*>(rows + (size_t)row * ROW);
 #pragma unroll
-  for (int sl = 0; sl < 4; ++sl) {
-    if (!((fl >> sl) & 1u)) continue;
-    const float4* row = reinterpret_cast<const float4*>(rows + ((size_t)u * 4 + sl) * ROW);
-#pragma unroll
-    for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
-      const float4 x = row[v4];
-      if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] += x.x;
-      if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] += x.y;
-      if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] += x.z;
-      if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] += x.w;
-    }
+  for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
+    const float4 x = p[v4];
+    if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] += x.x;
+    if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] += x.y;
+    if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] += x.z;
+    if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] += x.w;
   }
 }
 
-// Pass 1: one lane per Gaussian (depth order) for footprints of <= RR_BIG instances; larger ones
-// are appended to big_list (one aggregated atomic per wave; the list order does not influence
-// any result).
+// Pass 1: one lane per Gaussian (depth order).  Its rows are the dense run
+// [rowbase[u0], rowbase[u0 + n]) — ascending (tile, slot) order.  Runs of more than RR_BIG rows are
+// appended to big_list (one aggregated atomic per wave; the list order influences no result).
 template <int F>
 __global__ __launch_bounds__(RR_THREADS) void row_reduce_small_kernel(
     int P, const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ tiles_touched,
-    const int32_t* __restrict__ radii, const uint8_t* __restrict__ flags, const float* __restrict__ rows,
-    float* __restrict__ gacc, uint4* __restrict__ big_list, int32_t* __restrict__ big_count) {
+    const int32_t* __restrict__ radii, const u32* __restrict__ rowbase, const float* __restrict__ rows,
+    float* __restrict__ gacc, uint4* __restrict__ big_list, int32_t* __restrict__ counters) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   constexpr int NP = next_pow2_(NVAL);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  u32 idx = 0, n = 0, u0 = 0;
-  if (r < P) {
+  u32 idx = 0, first = 0, nrows = 0;
+  bool vis = false;
+  if (r < P && counters[7] == 0) {
     idx = order[r];
     if (radii[idx] > 0) {
-      n = tiles_touched[idx];
-      u0 = offsets[r] - n;
+      vis = true;
+      const u32 n = tiles_touched[idx];
+      const u32 u0 = offsets[r] - n;
+      first = rowbase[u0];
+      nrows = rowbase[u0 + n] - first;
     }
   }
-  if (n > 0 && n <= RR_BIG) {
-    // fetch all slot masks first (independent loads), 4 bits per instance
-    u64 live = 0ull;
-#pragma unroll
-    for (u32 t = 0; t < RR_BIG; ++t)
-      if (t < n) live |= (u64)(flags[u0 + t] & 0xFu) << (4 * t);
+  if (vis && nrows <= RR_BIG) {
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = 0; live != 0ull; ++t, live >>= 4) {  // ascending instance (tile) order
-      const u32 fl = (u32)(live & 0xFull);
-      if (fl) add_instance_rows<F>(rows, u0 + t, fl, acc);
-    }
+    for (u32 t = 0; t < nrows; ++t) add_row<F>(rows, first + t, acc);
     float4* dst = reinterpret_cast<float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
     for (int v4 = 0; v4 < ROW / 4; ++v4)
       dst[v4] = make_float4(4 * v4 + 0 < NVAL ? acc[4 * v4 + 0] : 0.f, 4 * v4 + 1 < NVAL ? acc[4 * v4 + 1] : 0.f,
                             4 * v4 + 2 < NVAL ? acc[4 * v4 + 2] : 0.f, 4 * v4 + 3 < NVAL ? acc[4 * v4 + 3] : 0.f);
   }
-  const bool is_big = n > RR_BIG;
+  const bool is_big = nrows > RR_BIG;
   const u64 bigm = ballot(is_big);
   if (bigm) {
     u32 base = 0;
-    if (lane == 0) base = (u32)atomicAdd(big_count, (int)__popcll(bigm));
+    if (lane == 0) base = (u32)atomicAdd(&counters[4], (int)__popcll(bigm));
     base = __shfl(base, 0);
     if (is_big)
-      big_list[base + (u32)__popcll(bigm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = make_uint4(idx, n, u0, 0u);
+      big_list[base + (u32)__popcll(bigm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] =
+          make_uint4(idx, first, nrows, 0u);
   }
 }
 
-// Pass 2: one wave per large-footprint Gaussian: 64 lanes stride over its instances, then one
-// multi-value butterfly.  Persistent grid; the work count lives on the device; the next item's
-// descriptor is fetched while the current one is reduced.
+// Pass 2: one wave per long run: 64 lanes stride over the rows, then one multi-value butterfly.
+// Persistent grid; the work count lives on the device; the next item's descriptor is fetched while
+// the current one is reduced.
 template <int F>
-__global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const uint8_t* __restrict__ flags,
-                                                                    const float* __restrict__ rows,
+__global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float* __restrict__ rows,
                                                                     float* __restrict__ gacc,
                                                                     const uint4* __restrict__ big_list,
-                                                                    const int32_t* __restrict__ big_count) {
+                                                                    const int32_t* __restrict__ counters) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   constexpr int NP = next_pow2_(NVAL);
@@ -145,20 +136,17 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const uint8_
   const int lane = threadIdx.x & 63;
   const int wave = (int)(blockIdx.x * (RR_THREADS / 64) + (threadIdx.x >> 6));
   const int nwaves = (int)(gridDim.x * (RR_THREADS / 64));
-  const int count = *big_count;
+  const int count = counters[4];
   if (wave >= count) return;
   uint4 cur = big_list[wave];
   for (int item = wave; item < count; item += nwaves) {
     const int nxt = item + nwaves;
     const uint4 next = big_list[nxt < count ? nxt : item];
-    const u32 idx = cur.x, n = cur.y, u0 = cur.z;
+    const u32 idx = cur.x, first = cur.y, nrows = cur.z;
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = (u32)lane; t < n; t += 64) {
-      const u32 fl = flags[u0 + t];
-      if (fl) add_instance_rows<F>(rows, u0 + t, fl, acc);
-    }
+    for (u32 t = (u32)lane; t < nrows; t += 64) add_row<F>(rows, first + t, acc);
     wave_reduce_rec<NP / 2, 32, NP>(acc, lane);
     float v = __shfl(acc[0], (lane * G_LANES) & 63);
     if (lane >= NVAL) v = 0.f;
@@ -568,55 +556,49 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
   }
 }
 
-// one wave: lane l < 6 is unused; 64 lanes stride over the partial rows, fixed order
-__global__ __launch_bounds__(64) void tau_final_kernel(const float* __restrict__ partials, int nb,
-                                                       float* __restrict__ out) {
-  const int lane = threadIdx.x;
-  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int b = lane; b < nb; b += 64)
+// 6 waves, one per tau component: 64 lanes stride over the block partials, fixed-order butterfly
+__global__ __launch_bounds__(384) void tau_final_kernel(const float* __restrict__ partials, int nb,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, comp = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int b = lane; b < nb; b += 64) acc += partials[(size_t)b * 6 + comp];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] += partials[(size_t)b * 6 + i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float v = acc[i];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if (lane == 0) out[i] = v;
-  }
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (lane == 0) out[comp] = acc;
 }
 
 template <int F>
 static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                        const int32_t* radii, const GradOut& o, float* tau_partials, hipStream_t st) {
+                        const float* rows, const int32_t* radii, const GradOut& o, float* tau_partials,
+                        hipStream_t st) {
   const int nb = tau_partial_blocks(s.P);
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
-  int32_t* big_count = &g.counters[4];
-  (void)hipMemsetAsync(big_count, 0, sizeof(int32_t), st);
+  (void)hipMemsetAsync(&g.counters[4], 0, sizeof(int32_t), st);
   row_reduce_small_kernel<F><<<(s.P + RR_THREADS - 1) / RR_THREADS, RR_THREADS, 0, st>>>(
-      s.P, g.depth_order, g.offsets, g.tiles_touched, radii, b.flags, b.rows, g.gacc, g.big_list, big_count);
-  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(b.flags, b.rows, g.gacc, g.big_list, big_count);
+      s.P, g.depth_order, g.offsets, g.tiles_touched, radii, b.rowbase, rows, g.gacc, g.big_list, g.counters);
+  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, g.counters);
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, 0, st>>>(
       s.P, s.D, s.M, g.gacc, s.means3D, radii, s.shs, g.clamped,
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
       o.dL_dtau_sum ? tau_partials : nullptr);
-  if (o.dL_dtau_sum) tau_final_kernel<<<1, 64, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
+  if (o.dL_dtau_sum) tau_final_kernel<<<1, 384, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
 }
 
 void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
-                                const BinningState& b, const int32_t* radii, const GradOut& o, float* tau_partials,
-                                hipStream_t st) {
+                                const BinningState& b, const float* rows, const int32_t* radii, const GradOut& o,
+                                float* tau_partials, hipStream_t st) {
   if (s.P <= 0) {
     if (o.dL_dtau_sum) (void)hipMemsetAsync(o.dL_dtau_sum, 0, 6 * sizeof(float), st);
     return;
   }
   switch (s.F) {
-    case 0: launch_pb_t<0>(s, d, g, b, radii, o, tau_partials, st); break;
-    case 3: launch_pb_t<3>(s, d, g, b, radii, o, tau_partials, st); break;
-    case 15: launch_pb_t<15>(s, d, g, b, radii, o, tau_partials, st); break;
-    case 16: launch_pb_t<16>(s, d, g, b, radii, o, tau_partials, st); break;
-    case 32: launch_pb_t<32>(s, d, g, b, radii, o, tau_partials, st); break;
+    case 0: launch_pb_t<0>(s, d, g, b, rows, radii, o, tau_partials, st); break;
+    case 3: launch_pb_t<3>(s, d, g, b, rows, radii, o, tau_partials, st); break;
+    case 15: launch_pb_t<15>(s, d, g, b, rows, radii, o, tau_partials, st); break;
+    case 16: launch_pb_t<16>(s, d, g, b, rows, radii, o, tau_partials, st); break;
+    case 32: launch_pb_t<32>(s, d, g, b, rows, radii, o, tau_partials, st); break;
     default: break;
   }
 }

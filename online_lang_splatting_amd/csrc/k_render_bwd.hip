@@ -15,9 +15,9 @@
 //   * the per-splat reduction never leaves the wave: ONE multi-value butterfly (N values in
 //     ~N+log2 shuffle-adds instead of 6N) leaves value k in lane k*(64/N), and the wave writes
 //     its own partial-gradient row (instance, slot) with a single coalesced 64..192-byte store;
-//   * no float atomics: rows are indexed by the instance's emission position, so the
-//     per-Gaussian reduction (k_preprocess_bwd.hip) reads a contiguous run of rows and the
-//     gradients are bit-reproducible from run to run.
+//   * no float atomics: rows are compacted in emission order (rowbase = exclusive scan of
+//     popcount(flags)), so the per-Gaussian reduction (k_preprocess_bwd.hip) streams one dense,
+//     contiguous run of rows per Gaussian and the gradients are bit-reproducible from run to run.
 //
 // MODE = OLSR_BWD_REFERENCE reproduces the shipped reference bit-compatibly in structure:
 //   - only the ranks that survive the 225-lane integer-halving tree contribute to
@@ -84,7 +84,8 @@ constexpr int BWD_BATCH = 128;
 template <int TILE, int F, int MODE>
 __global__ __launch_bounds__(256) void render_bwd_kernel(
     const u32* __restrict__ ranges, const u32* __restrict__ point_list, const u32* __restrict__ src,
-    const uint8_t* __restrict__ flags, int W, int H, int gx, int ntiles, const float* __restrict__ bg,
+    const uint8_t* __restrict__ flags, const u32* __restrict__ rowbase, const int32_t* __restrict__ counters, int W,
+    int H, int gx, int ntiles, const float* __restrict__ bg,
     const float* __restrict__ means2D, const float* __restrict__ conic_opacity, const float* __restrict__ colors,
     const float* __restrict__ lang, const float* __restrict__ depths, const float* __restrict__ final_Ts,
     const u32* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_lang,
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   __shared__ float2 s_xy[B];
   __shared__ float4 s_co[B];
   __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
-  __shared__ u32 s_src[B];
+  __shared__ u32 s_row[B];   // first compact row of the instance
   __shared__ u32 s_flag[B];
   __shared__ int s_kmax[4];
 
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   const int bx = tile_id % gx, by = tile_id / gx;
   const u32 r0 = ranges[2 * tile_id], r1 = ranges[2 * tile_id + 1];
   if (r1 <= r0) return;
+  if (counters[7] != 0) return;  // row scratch too small (reported to the caller): write nothing
   const size_t HW = (size_t)H * W;
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
         const u32 gid = point_list[sp];
         if (tid < B) {
           const u32 u = src[sp];
-          s_src[e] = u;
+          s_row[e] = rowbase[u];
           s_flag[e] = flags[u];
           s_xy[e] = reinterpret_cast<const float2*>(means2D)[gid];
           s_co[e] = reinterpret_cast<const float4*>(conic_opacity)[gid];
@@ -308,30 +310,32 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
           }
         }
       }
-      if (lane < ROW) rows[((size_t)s_src[i] * 4 + w) * ROW + lane] = rowval;
+      // compact row index: rows of an instance are consecutive, one per set slot bit
+      if (lane < ROW) rows[((size_t)s_row[i] + (u32)__popc(fl & ((1u << w) - 1u))) * ROW + lane] = rowval;
     }
   }
 }
 
 template <int TILE, int F, int MODE>
 static void launch_bwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                         const ImageState& im, const float* dc, const float* dl, const float* dd, hipStream_t st) {
+                         const ImageState& im, const float* dc, const float* dl, const float* dd, float* rows,
+                         hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
-  render_bwd_kernel<TILE, F, MODE><<<d.ntiles, 256, 0, st>>>(im.ranges, b.point_list, b.src, b.flags, d.W, d.H, d.gx,
-                                                            d.ntiles, s.background, g.means2D, g.conic_opacity, colors,
-                                                            s.language_precomp, g.depths, im.final_T, im.n_contrib, dc,
-                                                            dl, dd, b.rows);
+  render_bwd_kernel<TILE, F, MODE><<<d.ntiles, 256, 0, st>>>(
+      im.ranges, b.point_list, b.src, b.flags, b.rowbase, g.counters, d.W, d.H, d.gx, d.ntiles, s.background,
+      g.means2D, g.conic_opacity, colors, s.language_precomp, g.depths, im.final_T, im.n_contrib, dc, dl, dd, rows);
 }
 
 template <int TILE, int MODE>
 static void launch_bwd_f(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                         const ImageState& im, const float* dc, const float* dl, const float* dd, hipStream_t st) {
+                         const ImageState& im, const float* dc, const float* dl, const float* dd, float* rows,
+                         hipStream_t st) {
   switch (s.F) {
-    case 0: launch_bwd_t<TILE, 0, MODE>(s, d, g, b, im, dc, dl, dd, st); break;
-    case 3: launch_bwd_t<TILE, 3, MODE>(s, d, g, b, im, dc, dl, dd, st); break;
-    case 15: launch_bwd_t<TILE, 15, MODE>(s, d, g, b, im, dc, dl, dd, st); break;
-    case 16: launch_bwd_t<TILE, 16, MODE>(s, d, g, b, im, dc, dl, dd, st); break;
-    case 32: launch_bwd_t<TILE, 32, MODE>(s, d, g, b, im, dc, dl, dd, st); break;
+    case 0: launch_bwd_t<TILE, 0, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
+    case 3: launch_bwd_t<TILE, 3, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
+    case 15: launch_bwd_t<TILE, 15, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
+    case 16: launch_bwd_t<TILE, 16, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
+    case 32: launch_bwd_t<TILE, 32, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
     default: break;
   }
 }
@@ -343,20 +347,20 @@ static void launch_bwd_f(const olsr_scene& s, const FrameDims& d, const Geometry
 #if OLSR_BWD_TU_MODE == 0
 void launch_render_backward_reference(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
                                       const BinningState& b, const ImageState& im, const float* dc, const float* dl,
-                                      const float* dd, hipStream_t st) {
+                                      const float* dd, float* rows, hipStream_t st) {
   if (d.tile == 15)
-    launch_bwd_f<15, OLSR_BWD_REFERENCE>(s, d, g, b, im, dc, dl, dd, st);
+    launch_bwd_f<15, OLSR_BWD_REFERENCE>(s, d, g, b, im, dc, dl, dd, rows, st);
   else
-    launch_bwd_f<16, OLSR_BWD_REFERENCE>(s, d, g, b, im, dc, dl, dd, st);
+    launch_bwd_f<16, OLSR_BWD_REFERENCE>(s, d, g, b, im, dc, dl, dd, rows, st);
 }
 #else
 void launch_render_backward_exact(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
                                   const BinningState& b, const ImageState& im, const float* dc, const float* dl,
-                                  const float* dd, hipStream_t st) {
+                                  const float* dd, float* rows, hipStream_t st) {
   if (d.tile == 15)
-    launch_bwd_f<15, OLSR_BWD_EXACT>(s, d, g, b, im, dc, dl, dd, st);
+    launch_bwd_f<15, OLSR_BWD_EXACT>(s, d, g, b, im, dc, dl, dd, rows, st);
   else
-    launch_bwd_f<16, OLSR_BWD_EXACT>(s, d, g, b, im, dc, dl, dd, st);
+    launch_bwd_f<16, OLSR_BWD_EXACT>(s, d, g, b, im, dc, dl, dd, rows, st);
 }
 #endif
 

@@ -169,7 +169,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     bin_buf = bp.fn ? bp.fn(bp.user, need) : nullptr;
     if (!bin_buf) return fail(OLSR_ERR_ALLOC, "binning allocation callback returned NULL");
   }
-  b = BinningState::carve(bin_buf, (size_t)n_host, grad_row(s.F), bb);
+  b = BinningState::carve(bin_buf, (size_t)n_host, bb);
   const int32_t* n_dev = &g.counters[1];
 
   const uint32_t* sorted_keys = b.key_a;
@@ -219,9 +219,14 @@ size_t olsr_image_bytes(int32_t width, int32_t height, int32_t tile) {
 }
 
 size_t olsr_binning_bytes(int64_t num_rendered, int32_t F) {
+  (void)F;
   size_t bytes = 0;
-  BinningState::carve(nullptr, (size_t)(num_rendered > 0 ? num_rendered : 0), grad_row(supported_F(F) ? F : 0), bytes);
+  BinningState::carve(nullptr, (size_t)(num_rendered > 0 ? num_rendered : 0), bytes);
   return bytes;
+}
+
+size_t olsr_backward_scratch_bytes(int64_t rows, int32_t F) {
+  return align_up((size_t)(rows > 0 ? rows : 0) * (size_t)grad_row(supported_F(F) ? F : 0) * sizeof(float)) + 2 * ALIGN;
 }
 
 int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* geometry_user,
@@ -258,11 +263,12 @@ int olsr_forward_async(const olsr_scene* scene, void* geometry_buffer, void* bin
 }
 
 int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_buffer, int32_t num_rendered,
-                  void* binning_buffer, const void* image_buffer, const float* dL_dout_color,
-                  const float* dL_dout_language, const float* dL_dout_depth, float* dL_dmeans2D, float* dL_dconic,
-                  float* dL_dopacity, float* dL_dcolors, float* dL_dlanguage, float* dL_ddepths, float* dL_dmeans3D,
-                  float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dtau,
-                  float* dL_dtau_sum, void* hip_stream) {
+                  void* binning_buffer, const void* image_buffer, olsr_alloc_fn scratch_alloc, void* scratch_user,
+                  void* scratch, int64_t scratch_rows, const float* dL_dout_color, const float* dL_dout_language,
+                  const float* dL_dout_depth, float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity,
+                  float* dL_dcolors, float* dL_dlanguage, float* dL_ddepths, float* dL_dmeans3D, float* dL_dcov3D,
+                  float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dtau, float* dL_dtau_sum,
+                  int32_t* status_dev, void* hip_stream) {
   int rc = check_scene(scene, true);
   if (rc != OLSR_OK) return rc;
   const olsr_scene& s = *scene;
@@ -272,10 +278,13 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   mark("begin", st);
   if (s.P == 0) {
     if (dL_dtau_sum) HIP_TRY(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), st));
+    if (status_dev) HIP_TRY(hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), st));
     return OLSR_OK;
   }
   if (!radii || !geometry_buffer || !binning_buffer || !image_buffer || num_rendered < 0)
     return fail(OLSR_ERR_ARG, "radii, the three state buffers and num_rendered (>= 0) are required");
+  if (!scratch_alloc && (!scratch || scratch_rows < 0))
+    return fail(OLSR_ERR_ARG, "either a scratch allocation callback or a scratch buffer with its row capacity is required");
   if (!dL_dout_color || !dL_dout_depth || (s.F > 0 && !dL_dout_language))
     return fail(OLSR_ERR_ARG, "upstream gradients must not be NULL");
   if (!dL_dmeans2D || !dL_dopacity || !dL_dcolors || (s.F > 0 && !dL_dlanguage) || !dL_dmeans3D || !dL_dcov3D ||
@@ -285,18 +294,33 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   size_t gb, ib, bb;
   const GeometryState g = GeometryState::carve(geometry_buffer, (size_t)s.P, grad_row(s.F), gb);
   const ImageState im = ImageState::carve(const_cast<void*>(image_buffer), (size_t)d.W * d.H, (size_t)d.ntiles, ib);
-  BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, grad_row(s.F), bb);
+  BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, bb);
   if (tile_sort_where(d.ntiles)) b.src = b.val_b;
 
+  // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended
+  launch_row_compaction(b.flags, num_rendered, b.rowbase, b.scan_partials,
+                        scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, st);
+  STAGE("row_compaction");
+  if (scratch_alloc) {
+    int32_t L = 0;
+    HIP_TRY(hipMemcpyAsync(&L, &g.counters[6], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    scratch_rows = L;
+    scratch = scratch_alloc(scratch_user, olsr_backward_scratch_bytes(L, s.F));
+    if (!scratch) return fail(OLSR_ERR_ALLOC, "backward scratch allocation callback returned NULL");
+  }
+  float* rows = (float*)(((uintptr_t)scratch + ALIGN - 1) / ALIGN * ALIGN);
+
   if (s.bwd_mode == OLSR_BWD_REFERENCE)
-    launch_render_backward_reference(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, st);
+    launch_render_backward_reference(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
   else
-    launch_render_backward_exact(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, st);
+    launch_render_backward_exact(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
   STAGE("render_backward");
   GradOut o{dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dlanguage, dL_ddepths, dL_dmeans3D,
             dL_dcov3D,   dL_dsh,    dL_dscales,  dL_drotations, dL_dtau,    dL_dtau_sum};
-  launch_preprocess_backward(s, d, g, b, radii, o, g.tau_partials, st);
+  launch_preprocess_backward(s, d, g, b, rows, radii, o, g.tau_partials, st);
   STAGE("preprocess_backward");
+  if (status_dev) HIP_TRY(hipMemcpyAsync(status_dev, &g.counters[6], 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   (void)gb;
   (void)ib;
   (void)bb;
@@ -350,12 +374,12 @@ const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t 
 
 const void* olsr_binning_field(const void* binning_buffer, int64_t num_rendered, int32_t F, const char* name) {
   size_t bytes;
-  const BinningState b =
-      BinningState::carve(const_cast<void*>(binning_buffer), (size_t)num_rendered, grad_row(supported_F(F) ? F : 0), bytes);
+  (void)F;
+  const BinningState b = BinningState::carve(const_cast<void*>(binning_buffer), (size_t)num_rendered, bytes);
   if (!std::strcmp(name, "point_list")) return b.point_list;
   if (!std::strcmp(name, "inst_gid")) return b.inst_gid;
   if (!std::strcmp(name, "flags")) return b.flags;
-  if (!std::strcmp(name, "rows")) return b.rows;
+  if (!std::strcmp(name, "rowbase")) return b.rowbase;
   if (!std::strcmp(name, "key_a")) return b.key_a;
   if (!std::strcmp(name, "key_b")) return b.key_b;
   if (!std::strcmp(name, "src")) return b.src;

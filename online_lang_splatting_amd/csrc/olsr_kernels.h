@@ -30,6 +30,10 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, hipStream_t st);
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
                  const BinningState& b, hipStream_t st);
+// exclusive scan of popcount(flags & 15) over [0, n] -> rowbase[0..n]; counters[6] = total live rows,
+// counters[7] = (total > row_capacity)
+void launch_row_compaction(const uint8_t* flags, int64_t n_host, uint32_t* rowbase, uint32_t* partials,
+                           int64_t row_capacity, int32_t* counters, hipStream_t st);
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
                         int ntiles, hipStream_t st);
 
@@ -42,10 +46,10 @@ void launch_render_forward(const olsr_scene& s, const FrameDims& d, const Geomet
 // (two translation units, one per backward mode, so they compile in parallel)
 void launch_render_backward_reference(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
                                       const BinningState& b, const ImageState& im, const float* dL_dcolor,
-                                      const float* dL_dlanguage, const float* dL_ddepth, hipStream_t st);
+                                      const float* dL_dlanguage, const float* dL_ddepth, float* rows, hipStream_t st);
 void launch_render_backward_exact(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
                                   const BinningState& b, const ImageState& im, const float* dL_dcolor,
-                                  const float* dL_dlanguage, const float* dL_ddepth, hipStream_t st);
+                                  const float* dL_dlanguage, const float* dL_ddepth, float* rows, hipStream_t st);
 
 // k_preprocess_bwd.hip
 struct GradOut {
@@ -53,8 +57,8 @@ struct GradOut {
       *dL_dsh, *dL_dscales, *dL_drotations, *dL_dtau, *dL_dtau_sum;
 };
 void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
-                                const BinningState& b, const int32_t* radii, const GradOut& o, float* tau_partials,
-                                hipStream_t st);
+                                const BinningState& b, const float* rows, const int32_t* radii, const GradOut& o,
+                                float* tau_partials, hipStream_t st);
 int tau_partial_blocks(int P);
 
 // k_accumulate.hip

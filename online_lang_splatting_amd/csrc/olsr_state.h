@@ -9,9 +9,10 @@
 //               radix-sort scratch for the P-sized depth sort.
 //   image     — final transmittance, last-contributor index, per-tile ranges.
 //   binning   — per-instance arrays: tile keys (ping/pong), sorted Gaussian list, the
-//               sorted->emission map `src`, per-instance contribution flags (written by the
-//               forward composite) and the partial-gradient rows the backward composite
-//               writes for the per-Gaussian reduction.
+//               sorted->emission map `src`, per-instance slot flags (written by the forward
+//               composite) and `rowbase`, the exclusive scan of popcount(flags) that compacts
+//               the backward's partial-gradient rows.
+//   scratch   — (backward only) the compacted rows [live (instance, slot) pairs][grad_row(F)].
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -60,7 +61,8 @@ struct GeometryState {
   uint32_t* inst_start;   // [P] Gaussian id -> emission index of its first instance
   uint32_t* radix_table;  // [256 * sort_blocks(P)]
   uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
-  int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag
+  int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag,
+                          //      4 = #large-footprint Gaussians, 6 = live rows L, 7 = row-capacity overflow
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
   uint4* big_list;        // [P] backward scratch: {id, #instances, first instance} of large-footprint Gaussians (count: counters[4])
@@ -117,9 +119,9 @@ struct BinningState {
   uint32_t* inst_gid;    // [R] emission index -> Gaussian id
   uint8_t* flags;        // [R] emission index -> bit w: 64-pixel slot w of the tile blended this instance
   uint32_t* radix_table;   // [256 * sort_blocks(R)]
-  uint32_t* scan_partials; // [scan_blocks(table) + 1]
-  float* rows;           // [R][4 slots][grad_row(F)] partial gradients, emission order
-  static BinningState carve(void* buf, size_t R, int grad_row_floats, size_t& bytes) {
+  uint32_t* scan_partials; // [scan_blocks(max(table, R)) + 1]
+  uint32_t* rowbase;     // [R + 1] emission index -> first compact row of the instance (backward)
+  static BinningState carve(void* buf, size_t R, size_t& bytes) {
     Carver c(buf);
     BinningState b;
     b.key_a = c.take<uint32_t>(R);
@@ -128,11 +130,11 @@ struct BinningState {
     b.src = c.take<uint32_t>(R);
     b.point_list = c.take<uint32_t>(R);
     b.inst_gid = c.take<uint32_t>(R);
-    b.flags = c.take<uint8_t>(R);
+    b.flags = c.take<uint8_t>((R + 15) / 16 * 16);
     const size_t table = 256 * (size_t)sort_blocks((long long)R);
     b.radix_table = c.take<uint32_t>(table);
-    b.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)table) + 1);
-    b.rows = c.take<float>(R * 4 * (size_t)grad_row_floats);
+    b.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)(table > R ? table : R)) + 1);
+    b.rowbase = c.take<uint32_t>(R + 1);
     bytes = c.total();
     return b;
   }

@@ -116,9 +116,12 @@ class GradientBucket:
 class RasterWorkspace:
     """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
 
-    def __init__(self, P, W, H, F, M, capacity, device, tile=15, bwd_mode=_abi.BWD_REFERENCE):
+    def __init__(self, P, W, H, F, M, capacity, device, tile=15, bwd_mode=_abi.BWD_REFERENCE, row_capacity=None):
         self.P, self.W, self.H, self.F, self.M = int(P), int(W), int(H), int(F), int(M)
         self.capacity, self.tile, self.bwd_mode = int(capacity), int(tile), int(bwd_mode)
+        # rows of the backward scratch: live (instance, slot) pairs, at most 4 per instance; one per
+        # instance covers ordinary scenes several times over (config 3 needs 0.24), overflow is reported
+        self.row_capacity = int(row_capacity) if row_capacity is not None else self.capacity
         self.device = torch.device(device)
         L = lib()
         u8 = dict(dtype=torch.uint8, device=self.device)
@@ -127,6 +130,8 @@ class RasterWorkspace:
         self.geom = torch.empty(L.olsr_geometry_bytes(P, F), **u8)
         self.img = torch.empty(L.olsr_image_bytes(W, H, tile), **u8)
         self.binning = torch.empty(L.olsr_binning_bytes(self.capacity, F), **u8)
+        self.scratch = torch.empty(L.olsr_backward_scratch_bytes(self.row_capacity, F), **u8)
+        self.bwd_status = torch.zeros(2, **i32)  # {live rows, overflow flag}
         self.out = dict(color=torch.empty(3, H, W, **f32), language=torch.empty(F, H, W, **f32),
                         depth=torch.empty(1, H, W, **f32), opacity=torch.empty(1, H, W, **f32),
                         radii=torch.empty(P, **i32), n_touched=torch.empty(P, **i32))
@@ -142,7 +147,7 @@ class RasterWorkspace:
         self._keep = None
 
     def state_bytes(self):
-        return self.geom.numel() + self.img.numel() + self.binning.numel()
+        return self.geom.numel() + self.img.numel() + self.binning.numel() + self.scratch.numel()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -182,11 +187,17 @@ class RasterWorkspace:
             return t.data_ptr() if t is not None and t.numel() > 0 else None
         check(lib().olsr_backward(
             C.byref(self._scene), self.out["radii"].data_ptr(), self.geom.data_ptr(), self.capacity,
-            self.binning.data_ptr(), self.img.data_ptr(), p(dL_dcolor), p(dL_dlanguage), p(dL_ddepth),
+            self.binning.data_ptr(), self.img.data_ptr(), _abi.ALLOC_FN(0), None, self.scratch.data_ptr(),
+            self.row_capacity, p(dL_dcolor), p(dL_dlanguage), p(dL_ddepth),
             p(g["dL_dmeans2D"]), p(g["dL_dconic"]), p(g["dL_dopacity"]), p(g["dL_dcolors"]), p(g["dL_dlanguage"]),
             p(g["dL_ddepths"]), p(g["dL_dmeans3D"]), p(g["dL_dcov3D"]), p(g["dL_dsh"]), p(g["dL_dscales"]),
-            p(g["dL_drotations"]), p(g["dL_dtau"]), p(g["dL_dtau_sum"]), self._stream()))
+            p(g["dL_drotations"]), p(g["dL_dtau"]), p(g["dL_dtau_sum"]), self.bwd_status.data_ptr(), self._stream()))
         return g
+
+    def backward_status(self):
+        """(live rows L, overflow) of the last backward — synchronises; call outside timed regions."""
+        st = self.bwd_status.cpu()
+        return int(st[0]), bool(st[1])
 
     def rendered(self):
         """(R, overflow) — synchronises; call outside timed regions."""

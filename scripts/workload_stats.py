@@ -21,3 +21,10 @@ kmax = pad.view(gy,15,gx,15).permute(0,2,1,3).reshape(gy*gx,-1).max(1).values
 print(f"kmax mean {kmax.mean():.0f} max {kmax.max():.0f}; mean n_contrib {nc.mean():.0f}; sum kmax {kmax.sum():.0f}")
 tt = G.state_field("geometry", fg["geom"], "tiles_touched", P=P, F=F, dtype=torch.int32, count=P).float()
 print(f"tiles_touched mean {tt.mean():.2f} max {tt.max():.0f} p99 {tt.quantile(0.99):.0f}; visible {(fg['radii']>0).float().mean():.3f}")
+for thr in (8, 16, 32, 64, 128, 256):
+    m = tt > thr
+    print(f"n>{thr}: {int(m.sum())} Gaussians ({m.float().mean().item()*100:.1f}%), instances {int(tt[m].sum())} ({tt[m].sum().item()/R*100:.1f}% of R)")
+livepairs = 0
+fl = flags.to(torch.int32)
+for b in range(4): livepairs += int(((fl >> b) & 1).sum())
+print("live (instance,slot) pairs", livepairs)

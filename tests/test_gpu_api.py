@@ -105,6 +105,20 @@ def test_workspace_async_equals_dropin_path(hip):
     o2 = small.forward()
     R, overflow = small.rendered()
     assert overflow and R == fg["R"] and float(o2["opacity"].abs().max()) == 0.0
+    # backward scratch too small for the live (instance, slot) rows: reported, not a crash
+    L, ov = ws.backward_status()
+    assert not ov and 0 < L <= 4 * fg["R"]
+    tight = RasterWorkspace(sc.P, 320, 240, 15, sc.shs.shape[1], int(fg["R"] * 1.2) + 1000, dev, row_capacity=L - 1)
+    tight.set_scene(**kw)
+    tight.forward()
+    tight.backward(dc, dl, dd)
+    assert tight.backward_status() == (L, True)
+    exact = RasterWorkspace(sc.P, 320, 240, 15, sc.shs.shape[1], int(fg["R"] * 1.2) + 1000, dev, row_capacity=L)
+    exact.set_scene(**kw)
+    exact.forward()
+    g3 = exact.backward(dc, dl, dd)
+    assert exact.backward_status() == (L, False)
+    assert torch.equal(g3["dL_dmeans3D"], gg["dL_dmeans3D"])
 
 
 def test_full_size_config3_properties(hip):
