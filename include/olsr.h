@@ -185,8 +185,9 @@ int olsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
  * benchmark's byte model.  Each returns a device pointer inside the given buffer
  * (or NULL for an unknown name).  Names: geometry — "depths" f32[P], "means2D"
  * f32[P,2], "cov3D" f32[P,6], "conic_opacity" f32[P,4], "rgb" f32[P,3], "clamped"
- * u8[P,3], "tiles_touched" u32[P], "depth_order" u32[P]; binning — "point_list"
- * u32[R], "flags" u8[R], "rowbase" u32[R+1]; image — "final_T" f32[H*W], "n_contrib" u32[H*W], "ranges" u32[tiles,2]. */
+ * u8[P,3], "tiles_touched" u32[P], "depth_order" u32[P]; binning — "src" u32[R]
+ * (sorted position -> emission index), "inst_gid" u32[R] (emission index -> Gaussian id; the
+ * reference's point_list is inst_gid[src]), "flags" u8[R], "rowbase" u32[R+1]; image — "final_T" f32[H*W], "n_contrib" u32[H*W], "ranges" u32[tiles,2]. */
 const void *olsr_geometry_field(const void *geometry_buffer, int32_t P, int32_t F, const char *name);
 const void *olsr_binning_field(const void *binning_buffer, int64_t num_rendered, int32_t F,
                                const char *name);

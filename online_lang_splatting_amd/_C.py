@@ -207,7 +207,13 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 
 def state_field(kind, buf, name, *, P=0, F=0, R=0, W=0, H=0, dtype=torch.float32, count=0):
-    """View into an opaque state buffer (olsr_*_field) as a tensor of `count` elements."""
+    """View into an opaque state buffer (olsr_*_field) as a tensor of `count` elements.
+    "point_list" (sorted position -> Gaussian id, the reference's BinningState::point_list) is not
+    materialised by the library; it is composed here from `src` and `inst_gid`."""
+    if kind == "binning" and name == "point_list":
+        src = state_field("binning", buf, "src", R=R, F=F, dtype=torch.int32, count=count)
+        gid = state_field("binning", buf, "inst_gid", R=R, F=F, dtype=torch.int32, count=count)
+        return gid[src.long()].to(dtype)
     L = lib()
     if kind == "geometry":
         ptr = L.olsr_geometry_field(buf.data_ptr(), P, F, name.encode())

@@ -120,6 +120,8 @@ static void device_scan(Load ld, int64_t n, u32* out, u32* partials, hipStream_t
 }
 
 // ------------------------------------------------------------------------------- radix sort
+// One LSD pass = histogram kernel + scan of the [digit][block] table + scatter kernel.
+// The digit width is chosen per sort (<= 8 bits): a 12-bit tile id is sorted in two 6-bit passes.
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ROUNDS = SORT_CHUNK / SORT_THREADS;  // 16 rounds of 64 per wave
 
@@ -134,7 +136,7 @@ __device__ __forceinline__ int64_t bounded_n(int64_t n_host, const int32_t* n_de
 // table[d * nblk + b] = number of keys of block b whose digit is d
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
                                                                    const int32_t* __restrict__ n_dev, int shift,
-                                                                   u32* __restrict__ table) {
+                                                                   u32 dmask, u32* __restrict__ table) {
   __shared__ u32 hist[256];
   const int64_t n = bounded_n(n_host, n_dev);
   hist[threadIdx.x] = 0;
@@ -143,26 +145,35 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const u32* __r
 #pragma unroll 4
   for (int k = 0; k < SORT_ROUNDS; ++k) {
     const int64_t i = base + (int64_t)k * SORT_THREADS + threadIdx.x;
-    if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 0xFFu], 1u);
+    if (i < n) atomicAdd(&hist[(keys[i] >> shift) & dmask], 1u);
   }
   __syncthreads();
-  table[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x <= dmask) table[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
 }
 
-// Stable scatter.  Wave w of block b owns the contiguous run
-// [b*CHUNK + w*1024, +1024) and walks it in 16 rounds of 64 consecutive keys, so the order
-// inside a block is (wave, round, lane) == ascending input index.
+// Stable scatter.  Wave w of block b owns the contiguous run [b*CHUNK + w*1024, +1024) and walks
+// it in 16 rounds of 64 consecutive keys, so the order inside a block is (wave, round, lane) ==
+// ascending input index.  Ranks inside a round come from 64-bit ballots (match-any over the digit
+// bits).  The block first orders its 4096 pairs by digit in LDS, then writes every digit's run
+// with consecutive lanes -> coalesced stores instead of 4-byte scatters.
+template <int DB>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, int64_t n_host,
     const int32_t* __restrict__ n_dev, int shift, const u32* __restrict__ table, u32* __restrict__ keys_out,
-    u32* __restrict__ vals_out, const u32* __restrict__ gather, u32* __restrict__ gather_out) {
-  __shared__ u32 cnt[4][256];
+    u32* __restrict__ vals_out) {
+  constexpr u32 NB = 1u << DB;
+  constexpr u32 DMASK = NB - 1u;
+  __shared__ u32 cnt[4][NB];     // per-wave digit counts -> per-wave local starts
+  __shared__ u32 gbase[NB];      // global start of this block's run of digit d
+  __shared__ u32 dstart[NB + 1]; // local start of digit d inside the block
+  __shared__ u32 ex_key[SORT_CHUNK];
+  __shared__ u32 ex_val[SORT_CHUNK];
   const int64_t n = bounded_n(n_host, n_dev);
   const int lane = lane_id(), w = threadIdx.x >> 6;
-  const int64_t wbase = (int64_t)blockIdx.x * SORT_CHUNK + (int64_t)w * (SORT_CHUNK / 4);
+  const int64_t bbase = (int64_t)blockIdx.x * SORT_CHUNK;
+  const int64_t wbase = bbase + (int64_t)w * (SORT_CHUNK / 4);
   u32 key[SORT_ROUNDS], val[SORT_ROUNDS];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) cnt[i][threadIdx.x] = 0;
+  for (u32 i = threadIdx.x; i < 4 * NB; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < SORT_ROUNDS; ++r) {
@@ -170,16 +181,22 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const bool valid = i < n;
     key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
     val[r] = valid ? (vals_in ? vals_in[i] : (u32)i) : 0u;
-    if (valid) atomicAdd(&cnt[w][(key[r] >> shift) & 0xFFu], 1u);
+    if (valid) atomicAdd(&cnt[w][(key[r] >> shift) & DMASK], 1u);
   }
   __syncthreads();
-  {  // thread t owns digit t: turn per-wave counts into per-wave starting positions
-    u32 run = table[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32 c = cnt[i][threadIdx.x];
-      cnt[i][threadIdx.x] = run;
-      run += c;
+  {  // thread d owns digit d: block-local exclusive prefix in (digit, wave) order
+    const u32 d = threadIdx.x;
+    u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (d < NB) { c0 = cnt[0][d]; c1 = cnt[1][d]; c2 = cnt[2][d]; c3 = cnt[3][d]; }
+    const u32 tot = c0 + c1 + c2 + c3;
+    const u32 start = block_excl_scan_256(tot, nullptr);
+    if (d < NB) {
+      dstart[d] = start;
+      cnt[0][d] = start;
+      cnt[1][d] = start + c0;
+      cnt[2][d] = start + c0 + c1;
+      cnt[3][d] = start + c0 + c1 + c2;
+      gbase[d] = table[(size_t)d * gridDim.x + blockIdx.x];
     }
   }
   __syncthreads();
@@ -189,44 +206,62 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   for (int r = 0; r < SORT_ROUNDS; ++r) {
     const int64_t i = wbase + r * 64 + lane;
     const bool valid = i < n;
-    const u32 d = (key[r] >> shift) & 0xFFu;
+    const u32 d = (key[r] >> shift) & DMASK;
     u64 peers = ballot(valid);
 #pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
+    for (int bit = 0; bit < DB; ++bit) {
       const bool one = (d >> bit) & 1u;
-      const u64 b = ballot(one);
-      peers &= one ? b : ~b;
+      const u64 bm = ballot(one);
+      peers &= one ? bm : ~bm;
     }
     if (valid) {
       const u32 rank = (u32)__popcll(peers & lt_mask);
-      const u32 count = (u32)__popcll(peers);
       const u32 start = my[d];
-      const u32 pos = start + rank;
-      if (rank == 0) my[d] = start + count;
-      keys_out[pos] = key[r];
-      if (vals_out) vals_out[pos] = val[r];
-      if (gather) gather_out[pos] = gather[val[r]];
+      if (rank == 0) my[d] = start + (u32)__popcll(peers);
+      ex_key[start + rank] = key[r];
+      ex_val[start + rank] = val[r];
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  const int64_t rem = n - bbase;
+  const u32 nvalid = rem >= SORT_CHUNK ? (u32)SORT_CHUNK : (rem > 0 ? (u32)rem : 0u);
+#pragma unroll 4
+  for (int k = 0; k < SORT_ROUNDS; ++k) {
+    const u32 slot = (u32)k * SORT_THREADS + threadIdx.x;
+    if (slot < nvalid) {
+      const u32 kk = ex_key[slot];
+      const u32 d = (kk >> shift) & DMASK;
+      const u32 pos = gbase[d] + (slot - dstart[d]);
+      keys_out[pos] = kk;
+      vals_out[pos] = ex_val[slot];
+    }
   }
 }
 
 int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
-                      const uint32_t* final_gather, uint32_t* final_gather_out, hipStream_t st) {
+                      hipStream_t st) {
   if (n_host <= 0) return 0;
   const int nblk = sort_blocks(n_host);
   const int passes = (bits + 7) / 8;
+  const int db = (bits + passes - 1) / passes;  // digit width, <= 8
   u32 *kin = b.key_a, *kout = b.key_b, *vin = b.val_a, *vout = b.val_b;
   int where = 0;
   for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
-    const bool last = (p == passes - 1);
-    radix_hist_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, n_host, n_dev, shift, b.table);
-    device_scan<LoadPlain, false>(LoadPlain{b.table}, (int64_t)256 * nblk, b.table, b.partials, st);
+    const int shift = db * p;
+    radix_hist_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, n_host, n_dev, shift, (1u << db) - 1u, b.table);
+    device_scan<LoadPlain, false>(LoadPlain{b.table}, (int64_t)(1 << db) * nblk, b.table, b.partials, st);
     const u32* vsrc = (p == 0 && vals_in_identity) ? nullptr : vin;
-    radix_scatter_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, vsrc, n_host, n_dev, shift, b.table, kout, vout,
-                                                        last ? final_gather : nullptr,
-                                                        last ? final_gather_out : nullptr);
+#define OLSR_SCATTER(DBV)                                                                                      \
+  case DBV:                                                                                                    \
+    radix_scatter_kernel<DBV><<<nblk, SORT_THREADS, 0, st>>>(kin, vsrc, n_host, n_dev, shift, b.table, kout, vout); \
+    break;
+    switch (db) {
+      OLSR_SCATTER(1) OLSR_SCATTER(2) OLSR_SCATTER(3) OLSR_SCATTER(4)
+      OLSR_SCATTER(5) OLSR_SCATTER(6) OLSR_SCATTER(7) OLSR_SCATTER(8)
+      default: break;
+    }
+#undef OLSR_SCATTER
     u32* t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
     where ^= 1;

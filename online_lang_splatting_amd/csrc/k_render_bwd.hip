@@ -83,7 +83,7 @@ constexpr int BWD_BATCH = 128;
 
 template <int TILE, int F, int MODE>
 __global__ __launch_bounds__(256) void render_bwd_kernel(
-    const u32* __restrict__ ranges, const u32* __restrict__ point_list, const u32* __restrict__ src,
+    const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src,
     const uint8_t* __restrict__ flags, const u32* __restrict__ rowbase, const int32_t* __restrict__ counters, int W,
     int H, int gx, int ntiles, const float* __restrict__ bg,
     const float* __restrict__ means2D, const float* __restrict__ conic_opacity, const float* __restrict__ colors,
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
       const int e = tid & (B - 1);
       if (e < cnt) {
         const u32 sp = r0 + (u32)(kstart - e);
-        const u32 gid = point_list[sp];
+        const u32 u = src[sp];        // emission index of the instance
+        const u32 gid = inst_gid[u];  // its Gaussian
         if (tid < B) {
-          const u32 u = src[sp];
           s_row[e] = rowbase[u];
           s_flag[e] = flags[u];
           s_xy[e] = reinterpret_cast<const float2*>(means2D)[gid];
@@ -322,7 +322,7 @@ static void launch_bwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                          hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
   render_bwd_kernel<TILE, F, MODE><<<d.ntiles, 256, 0, st>>>(
-      im.ranges, b.point_list, b.src, b.flags, b.rowbase, g.counters, d.W, d.H, d.gx, d.ntiles, s.background,
+      im.ranges, b.inst_gid, b.src, b.flags, b.rowbase, g.counters, d.W, d.H, d.gx, d.ntiles, s.background,
       g.means2D, g.conic_opacity, colors, s.language_precomp, g.depths, im.final_T, im.n_contrib, dc, dl, dd, rows);
 }
 

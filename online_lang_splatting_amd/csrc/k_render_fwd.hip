@@ -28,7 +28,7 @@ constexpr int FWD_BATCH = 128;
 
 template <int TILE, int F>
 __global__ __launch_bounds__(256) void render_fwd_kernel(
-    const u32* __restrict__ ranges, const u32* __restrict__ point_list, const u32* __restrict__ src, int W, int H,
+    const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
@@ -73,10 +73,11 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
       const int e = tid & (B - 1);
       if (e < cnt) {
         const u32 sp = r0 + (u32)base + (u32)e;
-        const u32 gid = point_list[sp];
+        const u32 u = src[sp];        // emission index of the instance
+        const u32 gid = inst_gid[u];  // its Gaussian
         if (tid < B) {
           s_id[e] = gid;
-          s_src[e] = src[sp];
+          s_src[e] = u;
           s_flag[e] = 0;
           s_touch[e] = 0;
           const float2 m = reinterpret_cast<const float2*>(means2D)[gid];
@@ -168,7 +169,7 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                          const ImageState& im, float* out_color, float* out_language, float* out_depth,
                          float* out_opacity, int32_t* n_touched, hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
-  render_fwd_kernel<TILE, F><<<d.ntiles, 256, 0, st>>>(im.ranges, b.point_list, b.src, d.W, d.H, d.gx, d.ntiles,
+  render_fwd_kernel<TILE, F><<<d.ntiles, 256, 0, st>>>(im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles,
                                                        g.means2D, g.conic_opacity, g.depths, colors,
                                                        s.language_precomp, s.background, im.final_T, im.n_contrib,
                                                        out_color, out_language, out_depth, out_opacity, n_touched,

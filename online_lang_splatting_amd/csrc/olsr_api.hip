@@ -146,7 +146,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     launch_preprocess(s, d, g, radii, st);
     STAGE("preprocess");
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
-    launch_radix_sort(sb, s.P, nullptr, 32, false, nullptr, nullptr, st);
+    launch_radix_sort(sb, s.P, nullptr, 32, false, st);
     STAGE("depth_sort");
     launch_instance_offsets(g, s.P, bp.capacity >= 0 ? bp.capacity : 0x7FFFFFFFLL, st);
     STAGE("instance_offsets");
@@ -177,12 +177,11 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     launch_emit(s, d, g, radii, b, st);
     HIP_TRY(hipMemsetAsync(b.flags, 0, (size_t)n_host, st));
     STAGE("emit");
-    SortBuffers sb{b.key_a, b.key_b, b.src, b.val_b, b.radix_table, b.scan_partials};
-    const int where = launch_radix_sort(sb, n_host, n_dev, tile_bits(d.ntiles), true, b.inst_gid, b.point_list, st);
-    if (where) {
-      sorted_keys = b.key_b;
-      b.src = b.val_b;
-    }
+    // arrange the value ping-pong so that the last pass always lands in b.src
+    const bool odd = tile_sort_where(d.ntiles) != 0;
+    SortBuffers sb{b.key_a, b.key_b, odd ? b.val_b : b.src, odd ? b.src : b.val_b, b.radix_table, b.scan_partials};
+    const int where = launch_radix_sort(sb, n_host, n_dev, tile_bits(d.ntiles), true, st);
+    if (where) sorted_keys = b.key_b;
     STAGE("tile_sort");
   }
   launch_tile_ranges(sorted_keys, (s.P > 0) ? n_host : 0, n_dev, im.ranges, d.ntiles, st);
@@ -295,7 +294,6 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   const GeometryState g = GeometryState::carve(geometry_buffer, (size_t)s.P, grad_row(s.F), gb);
   const ImageState im = ImageState::carve(const_cast<void*>(image_buffer), (size_t)d.W * d.H, (size_t)d.ntiles, ib);
   BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, bb);
-  if (tile_sort_where(d.ntiles)) b.src = b.val_b;
 
   // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended
   launch_row_compaction(b.flags, num_rendered, b.rowbase, b.scan_partials,
@@ -376,7 +374,6 @@ const void* olsr_binning_field(const void* binning_buffer, int64_t num_rendered,
   size_t bytes;
   (void)F;
   const BinningState b = BinningState::carve(const_cast<void*>(binning_buffer), (size_t)num_rendered, bytes);
-  if (!std::strcmp(name, "point_list")) return b.point_list;
   if (!std::strcmp(name, "inst_gid")) return b.inst_gid;
   if (!std::strcmp(name, "flags")) return b.flags;
   if (!std::strcmp(name, "rowbase")) return b.rowbase;

@@ -19,14 +19,14 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // k_binning.hip
-// Stable LSD radix sort of (key, val) on `bits` low bits of key, 8 bits per pass.
+// Stable LSD radix sort of (key, val) on `bits` low bits of key, ceil(bits/8) passes of equal digit width.
 // n_dev (nullable) bounds the element count on the device; n_host sizes the grid.
 struct SortBuffers {
   uint32_t *key_a, *key_b, *val_a, *val_b, *table, *partials;
 };
 // Returns 0 if the result ends in (key_a,val_a), 1 if in (key_b,val_b).
 int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
-                      const uint32_t* final_gather, uint32_t* final_gather_out, hipStream_t st);
+                      hipStream_t st);
 void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, hipStream_t st);
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
                  const BinningState& b, hipStream_t st);

@@ -114,8 +114,7 @@ struct BinningState {
   uint32_t* key_a;       // [R] tile id per instance in emission order (ping)
   uint32_t* key_b;       // [R] (pong)
   uint32_t* val_b;       // [R] emission index after pass 1
-  uint32_t* src;         // [R] sorted position -> emission index
-  uint32_t* point_list;  // [R] sorted position -> Gaussian id
+  uint32_t* src;         // [R] sorted position -> emission index (final result of the tile sort)
   uint32_t* inst_gid;    // [R] emission index -> Gaussian id
   uint8_t* flags;        // [R] emission index -> bit w: 64-pixel slot w of the tile blended this instance
   uint32_t* radix_table;   // [256 * sort_blocks(R)]
@@ -128,7 +127,6 @@ struct BinningState {
     b.key_b = c.take<uint32_t>(R);
     b.val_b = c.take<uint32_t>(R);
     b.src = c.take<uint32_t>(R);
-    b.point_list = c.take<uint32_t>(R);
     b.inst_gid = c.take<uint32_t>(R);
     b.flags = c.take<uint8_t>((R + 15) / 16 * 16);
     const size_t table = 256 * (size_t)sort_blocks((long long)R);
