@@ -124,6 +124,7 @@ static void device_scan(Load ld, int64_t n, u32* out, u32* partials, hipStream_t
 // The digit width is chosen per sort (<= 8 bits): a 12-bit tile id is sorted in two 6-bit passes.
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ROUNDS = SORT_CHUNK / SORT_THREADS;  // 16 rounds of 64 per wave
+constexpr int SELF_SCAN_MAX_BLOCKS = 48;                // <= 196 k keys: scatter blocks scan the table themselves
 
 __device__ __forceinline__ int64_t bounded_n(int64_t n_host, const int32_t* n_dev) {
   if (n_dev) {
@@ -156,7 +157,11 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const u32* __r
 // ascending input index.  Ranks inside a round come from 64-bit ballots (match-any over the digit
 // bits).  The block first orders its 4096 pairs by digit in LDS, then writes every digit's run
 // with consecutive lanes -> coalesced stores instead of 4-byte scatters.
-template <int DB>
+//
+// SELF_SCAN: for short inputs (few blocks) the table arrives RAW from the histogram kernel and each
+// block derives its own bases — digit totals (row sums), their exclusive prefix, and the prefix of
+// its row up to its own column — saving the three launches of the device-wide scan per pass.
+template <int DB, bool SELF_SCAN>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, int64_t n_host,
     const int32_t* __restrict__ n_dev, int shift, const u32* __restrict__ table, u32* __restrict__ keys_out,
@@ -190,13 +195,28 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     if (d < NB) { c0 = cnt[0][d]; c1 = cnt[1][d]; c2 = cnt[2][d]; c3 = cnt[3][d]; }
     const u32 tot = c0 + c1 + c2 + c3;
     const u32 start = block_excl_scan_256(tot, nullptr);
+    u32 gb = 0;
+    if constexpr (SELF_SCAN) {
+      u32 row_total = 0, row_before = 0;
+      if (d < NB) {
+        const u32* row = table + (size_t)d * gridDim.x;
+        for (u32 bb = 0; bb < gridDim.x; ++bb) {
+          const u32 c = row[bb];
+          row_before += (bb < blockIdx.x) ? c : 0u;
+          row_total += c;
+        }
+      }
+      gb = block_excl_scan_256(row_total, nullptr) + row_before;
+    } else {
+      if (d < NB) gb = table[(size_t)d * gridDim.x + blockIdx.x];
+    }
     if (d < NB) {
       dstart[d] = start;
       cnt[0][d] = start;
       cnt[1][d] = start + c0;
       cnt[2][d] = start + c0 + c1;
       cnt[3][d] = start + c0 + c1 + c2;
-      gbase[d] = table[(size_t)d * gridDim.x + blockIdx.x];
+      gbase[d] = gb;
     }
   }
   __syncthreads();
@@ -250,11 +270,18 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
   for (int p = 0; p < passes; ++p) {
     const int shift = db * p;
     radix_hist_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, n_host, n_dev, shift, (1u << db) - 1u, b.table);
-    device_scan<LoadPlain, false>(LoadPlain{b.table}, (int64_t)(1 << db) * nblk, b.table, b.partials, st);
+    const bool self_scan = nblk <= SELF_SCAN_MAX_BLOCKS;
+    if (!self_scan)
+      device_scan<LoadPlain, false>(LoadPlain{b.table}, (int64_t)(1 << db) * nblk, b.table, b.partials, st);
     const u32* vsrc = (p == 0 && vals_in_identity) ? nullptr : vin;
-#define OLSR_SCATTER(DBV)                                                                                      \
-  case DBV:                                                                                                    \
-    radix_scatter_kernel<DBV><<<nblk, SORT_THREADS, 0, st>>>(kin, vsrc, n_host, n_dev, shift, b.table, kout, vout); \
+#define OLSR_SCATTER(DBV)                                                                                       \
+  case DBV:                                                                                                     \
+    if (self_scan)                                                                                              \
+      radix_scatter_kernel<DBV, true><<<nblk, SORT_THREADS, 0, st>>>(kin, vsrc, n_host, n_dev, shift, b.table,  \
+                                                                     kout, vout);                               \
+    else                                                                                                        \
+      radix_scatter_kernel<DBV, false><<<nblk, SORT_THREADS, 0, st>>>(kin, vsrc, n_host, n_dev, shift, b.table, \
+                                                                      kout, vout);                              \
     break;
     switch (db) {
       OLSR_SCATTER(1) OLSR_SCATTER(2) OLSR_SCATTER(3) OLSR_SCATTER(4)
