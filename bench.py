@@ -147,11 +147,10 @@ def main():
 
     def one_step():
         # every rank renders exactly one view per step (weak scaling): its own
-        step.bucket.zero_()
         ws.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
         out = ws.forward()
         g = ws.backward(dc, dl, dd)
-        step.bucket.accumulate(g, out["radii"])
+        step.bucket.accumulate(g, out["radii"], first=True)  # one view per rank per step
         step.bucket.all_reduce()
 
     for _ in range(a.warmup):

@@ -164,11 +164,13 @@ int olsr_backward(const olsr_scene *scene, const int32_t *radii,
  *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]
  * that a frame-sharded trainer all-reduces once per optimisation step, and updates the
  * densification statistics densify[P][2] += {||dL_dmeans2D.xy||, 1} for visible Gaussians and
- * max_radii[P] = max(max_radii, radii).  No reference counterpart in native code: it is what
+ * max_radii[P] = max(max_radii, radii).  With assign != 0 the accumulators are overwritten
+ * instead (first view of a step; saves zero-filling them).  No reference counterpart in native code: it is what
  * autograd's `.grad +=` over the views of BackEnd.map (utils/slam_backend.py:510-670) and
  * GaussianModel.add_densification_stats (gaussian_splatting/scene/gaussian_model.py:965-969) do
  * with separate PyTorch kernels. */
-int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, const float *dL_dmeans3D,
+int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, int32_t assign,
+                              const float *dL_dmeans3D,
                               const float *dL_dsh, const float *dL_dopacity,
                               const float *dL_dscales, const float *dL_drotations,
                               const float *dL_dlanguage, const float *dL_dmeans2D,

@@ -52,7 +52,7 @@ def lib():
     L.olsr_backward.argtypes = ([scene_p, vp, vp, i32, vp, vp, _abi.ALLOC_FN, vp, vp, i64] + [vp] * 3 + [vp] * 13
                                 + [vp, vp])
     L.olsr_backward.restype = C.c_int
-    L.olsr_accumulate_gradients.argtypes = [i32, i32, i32] + [vp] * 12
+    L.olsr_accumulate_gradients.argtypes = [i32, i32, i32, i32] + [vp] * 12
     L.olsr_accumulate_gradients.restype = C.c_int
     L.olsr_mark_visible.argtypes, L.olsr_mark_visible.restype = [i32, vp, vp, vp, vp, vp], C.c_int
     L.olsr_geometry_field.argtypes, L.olsr_geometry_field.restype = [vp, i32, i32, C.c_char_p], vp

@@ -45,6 +45,21 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* total) {
   return base + incl - v;
 }
 
+// Sum of partials[0 .. b) computed by the whole block (the per-chunk totals are few: one per 4096
+// elements), which saves the separate single-block scan launch between reduce and apply.
+__device__ __forceinline__ u32 block_prefix_of_partials(const u32* __restrict__ partials, int b) {
+  __shared__ u32 red[4];
+  u32 s = 0;
+  for (int j = threadIdx.x; j < b; j += SCAN_THREADS) s += partials[j];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const u32 tot = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return tot;
+}
+
 struct LoadPlain {
   const u32* p;
   __device__ __forceinline__ u32 operator()(int64_t i) const { return p[i]; }
@@ -68,29 +83,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(Load ld, int6
   if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of partials[0..nb) in place; partials[nb] = grand total
-__global__ __launch_bounds__(1024) void scan_partials_kernel(u32* partials, int nb) {
-  __shared__ u32 wsum[16];
-  __shared__ u32 carry_s;
-  const int lane = lane_id(), w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
-    const int i = base + threadIdx.x;
-    const u32 v = (i < nb) ? partials[i] : 0;
-    const u32 incl = wave_incl_scan(v);
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    u32 off = carry_s;
-    for (int k = 0; k < w; ++k) off += wsum[k];
-    if (i < nb) partials[i] = off + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = off + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partials[nb] = carry_s;
-}
-
 template <class Load, bool INCLUSIVE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(Load ld, int64_t n, const u32* partials, u32* out) {
   const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
@@ -101,7 +93,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(Load ld, int64
     v[k] = (base + k < n) ? ld(base + k) : 0;
     s += v[k];
   }
-  u32 run = block_excl_scan_256(s, nullptr) + partials[blockIdx.x];
+  u32 run = block_excl_scan_256(s, nullptr) + block_prefix_of_partials(partials, blockIdx.x);
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     if (INCLUSIVE) run += v[k];
@@ -115,7 +107,6 @@ static void device_scan(Load ld, int64_t n, u32* out, u32* partials, hipStream_t
   if (n <= 0) return;
   const int nb = scan_blocks(n);
   scan_reduce_kernel<Load><<<nb, SCAN_THREADS, 0, st>>>(ld, n, partials);
-  scan_partials_kernel<<<1, 1024, 0, st>>>(partials, nb);
   scan_apply_kernel<Load, INCLUSIVE><<<nb, SCAN_THREADS, 0, st>>>(ld, n, partials, out);
 }
 
@@ -297,20 +288,26 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 }
 
 // ------------------------------------------------------------------------------- offsets
-__global__ void finalize_counts_kernel(const u32* offsets, int P, long long capacity, int32_t* counters) {
+__global__ void finalize_counts_kernel(const u32* offsets, int P, long long capacity, int32_t* counters,
+                                       int32_t* num_rendered_dev) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const u32 R = (P > 0) ? offsets[P - 1] : 0u;
     const bool ok = (long long)R <= capacity && R <= 0x7FFFFFFFu;
     counters[0] = (int32_t)R;
     counters[1] = ok ? (int32_t)R : 0;
     counters[2] = ok ? 0 : 1;
+    if (num_rendered_dev) {
+      num_rendered_dev[0] = (int32_t)R;
+      num_rendered_dev[1] = ok ? 0 : 1;
+    }
   }
 }
 
 // cub::DeviceScan::InclusiveSum over tiles_touched (CR/rasterizer_impl.cu:451), taken in depth order
-void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, hipStream_t st) {
+void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, int32_t* num_rendered_dev,
+                             hipStream_t st) {
   device_scan<LoadGather, true>(LoadGather{g.tiles_touched, g.depth_order}, (int64_t)P, g.offsets, g.scan_partials, st);
-  finalize_counts_kernel<<<1, 64, 0, st>>>(g.offsets, P, (long long)capacity, g.counters);
+  finalize_counts_kernel<<<1, 64, 0, st>>>(g.offsets, P, (long long)capacity, g.counters, num_rendered_dev);
 }
 
 // ------------------------------------------------------------------------------- emission
@@ -420,7 +417,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t*
   u32 s = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s += v[k];
-  u32 run = block_excl_scan_256(s, nullptr) + partials[blockIdx.x];
+  u32 run = block_excl_scan_256(s, nullptr) + block_prefix_of_partials(partials, blockIdx.x);
   u32 o[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -439,28 +436,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t*
   }
 }
 
-__global__ void rows_finalize_kernel(const u32* partials, int nb, int64_t n, u32* rowbase, long long row_capacity,
-                                     int32_t* counters) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const u32 L = partials[nb];
+__global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* partials, int nb, int64_t n,
+                                                                    u32* rowbase, long long row_capacity,
+                                                                    int32_t* counters, int32_t* status_dev) {
+  const u32 L = block_prefix_of_partials(partials, nb);
+  if (threadIdx.x == 0) {
+    const int32_t ov = ((long long)L > row_capacity) ? 1 : 0;
     rowbase[n] = L;
     counters[6] = (int32_t)L;
-    counters[7] = ((long long)L > row_capacity) ? 1 : 0;
+    counters[7] = ov;
+    if (status_dev) {
+      status_dev[0] = (int32_t)L;
+      status_dev[1] = ov;
+    }
   }
 }
 
 void launch_row_compaction(const uint8_t* flags, int64_t n_host, uint32_t* rowbase, uint32_t* partials,
-                           int64_t row_capacity, int32_t* counters, hipStream_t st) {
+                           int64_t row_capacity, int32_t* counters, int32_t* status_dev, hipStream_t st) {
   if (n_host <= 0) {
     (void)hipMemsetAsync(rowbase, 0, sizeof(u32), st);
     (void)hipMemsetAsync(counters + 6, 0, 2 * sizeof(int32_t), st);
+    if (status_dev) (void)hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), st);
     return;
   }
   const int nb = scan_blocks(n_host);
   popc_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, partials);
-  scan_partials_kernel<<<1, 1024, 0, st>>>(partials, nb);
   popc_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, partials, rowbase);
-  rows_finalize_kernel<<<1, 64, 0, st>>>(partials, nb, n_host, rowbase, (long long)row_capacity, counters);
+  rows_finalize_kernel<<<1, SCAN_THREADS, 0, st>>>(partials, nb, n_host, rowbase, (long long)row_capacity, counters,
+                                                   status_dev);
 }
 
 // ------------------------------------------------------------------------------- ranges

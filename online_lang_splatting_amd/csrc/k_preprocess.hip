@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int32_t* __restrict__ radii,
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, u32* __restrict__ sort_key,
-    u32* __restrict__ sort_val, int prefiltered) {
+    u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P) return;
+  n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
   tiles_touched[idx] = 0;
   sort_key[idx] = 0xFFFFFFFFu;
@@ -141,14 +142,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
 }
 
 void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometryState& g, int32_t* radii,
-                       hipStream_t st) {
+                       int32_t* n_touched, hipStream_t st) {
   if (s.P <= 0) return;
   const int nb = (s.P + 255) / 256;
 #define OLSR_PRE_ARGS                                                                                                 \
   s.P, s.D, s.M, s.means3D, s.scales, s.scale_modifier, s.rotations, s.opacities, s.shs, g.clamped, s.cov3D_precomp,  \
       s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched, g.key_a,   \
-      g.val_a, s.prefiltered
+      g.val_a, n_touched, s.prefiltered
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

@@ -556,15 +556,18 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
   }
 }
 
-// 6 waves, one per tau component: 64 lanes stride over the block partials, fixed-order butterfly
-__global__ __launch_bounds__(384) void tau_final_kernel(const float* __restrict__ partials, int nb,
+// one block per tau component: 256 threads stride over the block partials, fixed-order reduction
+__global__ __launch_bounds__(256) void tau_final_kernel(const float* __restrict__ partials, int nb,
                                                         float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, comp = threadIdx.x >> 6;
+  __shared__ float red[4];
+  const int comp = blockIdx.x;
   float acc = 0.f;
-  for (int b = lane; b < nb; b += 64) acc += partials[(size_t)b * 6 + comp];
+  for (int b = threadIdx.x; b < nb; b += 256) acc += partials[(size_t)b * 6 + comp];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-  if (lane == 0) out[comp] = acc;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[comp] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 template <int F>
@@ -583,7 +586,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
       o.dL_dtau_sum ? tau_partials : nullptr);
-  if (o.dL_dtau_sum) tau_final_kernel<<<1, 384, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
+  if (o.dL_dtau_sum) tau_final_kernel<<<6, 256, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
 }
 
 void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,

@@ -137,18 +137,17 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     return fail(OLSR_ERR_ARG, "output image pointers must not be NULL");
   if (s.P > 0 && (!radii || !n_touched)) return fail(OLSR_ERR_ARG, "radii and n_touched must not be NULL");
 
-  if (s.P > 0) HIP_TRY(hipMemsetAsync(n_touched, 0, sizeof(int32_t) * (size_t)s.P, st));
   HIP_TRY(hipMemsetAsync(g.counters, 0, sizeof(int32_t) * 8, st));
 
   int64_t n_host = 0;
   BinningState b{};
   if (s.P > 0) {
-    launch_preprocess(s, d, g, radii, st);
+    launch_preprocess(s, d, g, radii, n_touched, st);
     STAGE("preprocess");
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
     launch_radix_sort(sb, s.P, nullptr, 32, false, st);
     STAGE("depth_sort");
-    launch_instance_offsets(g, s.P, bp.capacity >= 0 ? bp.capacity : 0x7FFFFFFFLL, st);
+    launch_instance_offsets(g, s.P, bp.capacity >= 0 ? bp.capacity : 0x7FFFFFFFLL, num_rendered_dev, st);
     STAGE("instance_offsets");
   }
 
@@ -189,10 +188,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, st);
   STAGE("render_forward");
 
-  if (num_rendered_dev) {
-    HIP_TRY(hipMemcpyAsync(num_rendered_dev, &g.counters[0], sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(num_rendered_dev + 1, &g.counters[2], sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-  }
+  if (num_rendered_dev && s.P == 0) HIP_TRY(hipMemsetAsync(num_rendered_dev, 0, 2 * sizeof(int32_t), st));
   (void)gb;
   (void)ib;
   (void)bb;
@@ -297,7 +293,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
 
   // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended
   launch_row_compaction(b.flags, num_rendered, b.rowbase, b.scan_partials,
-                        scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, st);
+                        scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, status_dev, st);
   STAGE("row_compaction");
   if (scratch_alloc) {
     int32_t L = 0;
@@ -318,7 +314,6 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
             dL_dcov3D,   dL_dsh,    dL_dscales,  dL_drotations, dL_dtau,    dL_dtau_sum};
   launch_preprocess_backward(s, d, g, b, rows, radii, o, g.tau_partials, st);
   STAGE("preprocess_backward");
-  if (status_dev) HIP_TRY(hipMemcpyAsync(status_dev, &g.counters[6], 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   (void)gb;
   (void)ib;
   (void)bb;
@@ -337,7 +332,8 @@ int olsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
   return OLSR_OK;
 }
 
-int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, const float* dL_dmeans3D, const float* dL_dsh,
+int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, int32_t assign, const float* dL_dmeans3D,
+                              const float* dL_dsh,
                               const float* dL_dopacity, const float* dL_dscales, const float* dL_drotations,
                               const float* dL_dlanguage, const float* dL_dmeans2D, const int32_t* radii, float* flat,
                               float* densify, int32_t* max_radii, void* hip_stream) {
@@ -346,7 +342,7 @@ int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, const float* dL_d
   if (!dL_dmeans3D || !dL_dopacity || !dL_dscales || !dL_drotations || !dL_dmeans2D || !radii || !flat || !densify ||
       !max_radii || (M > 0 && !dL_dsh) || (F > 0 && !dL_dlanguage))
     return fail(OLSR_ERR_ARG, "gradient, radii and accumulator pointers must not be NULL");
-  launch_accumulate(P, M, F, dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations, dL_dlanguage, dL_dmeans2D,
+  launch_accumulate(P, M, F, assign != 0, dL_dmeans3D, dL_dsh, dL_dopacity, dL_dscales, dL_drotations, dL_dlanguage, dL_dmeans2D,
                     radii, flat, densify, max_radii, (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("accumulate launch: ") + hipGetErrorString(e));

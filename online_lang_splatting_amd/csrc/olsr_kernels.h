@@ -15,7 +15,7 @@ struct FrameDims {
 
 // k_preprocess.hip
 void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometryState& g, int32_t* radii,
-                       hipStream_t st);
+                       int32_t* n_touched, hipStream_t st);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // k_binning.hip
@@ -27,13 +27,14 @@ struct SortBuffers {
 // Returns 0 if the result ends in (key_a,val_a), 1 if in (key_b,val_b).
 int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
                       hipStream_t st);
-void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, hipStream_t st);
+void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, int32_t* num_rendered_dev,
+                             hipStream_t st);
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
                  const BinningState& b, hipStream_t st);
 // exclusive scan of popcount(flags & 15) over [0, n] -> rowbase[0..n]; counters[6] = total live rows,
 // counters[7] = (total > row_capacity)
 void launch_row_compaction(const uint8_t* flags, int64_t n_host, uint32_t* rowbase, uint32_t* partials,
-                           int64_t row_capacity, int32_t* counters, hipStream_t st);
+                           int64_t row_capacity, int32_t* counters, int32_t* status_dev, hipStream_t st);
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
                         int ntiles, hipStream_t st);
 
@@ -62,8 +63,9 @@ void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const G
 int tau_partial_blocks(int P);
 
 // k_accumulate.hip
-void launch_accumulate(int P, int M, int F, const float* dmeans3D, const float* dsh, const float* dopacity,
-                       const float* dscales, const float* drot, const float* dlang, const float* dmeans2D,
-                       const int32_t* radii, float* flat, float* densify, int32_t* max_radii, hipStream_t st);
+void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, const float* dsh,
+                       const float* dopacity, const float* dscales, const float* drot, const float* dlang,
+                       const float* dmeans2D, const int32_t* radii, float* flat, float* densify, int32_t* max_radii,
+                       hipStream_t st);
 
 }  // namespace olsr

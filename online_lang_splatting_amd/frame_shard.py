@@ -74,8 +74,8 @@ class GradientBucket:
     def view(self, name):
         return self.flat[:, self._sl[name]]
 
-    def accumulate(self, grads: Dict[str, torch.Tensor], radii: torch.Tensor):
-        """Add one view's gradients (names of the C-ABI / reference backward outputs).  On the GPU this
+    def accumulate(self, grads: Dict[str, torch.Tensor], radii: torch.Tensor, first: bool = False):
+        """Add one view's gradients (first=True: overwrite instead, so zero_() can be skipped) (names of the C-ABI / reference backward outputs).  On the GPU this
         is one fused kernel (olsr_accumulate_gradients); the torch formulation below is the CPU path of
         the gloo tests and the specification the kernel is tested against."""
         if self.flat.is_cuda:
@@ -84,12 +84,14 @@ class GradientBucket:
             def p(t):
                 return t.data_ptr() if t is not None and t.numel() > 0 else None
             check(lib().olsr_accumulate_gradients(
-                P, self.layout.M, self.layout.F, p(grads["dL_dmeans3D"]), p(grads.get("dL_dsh")),
+                P, self.layout.M, self.layout.F, 1 if first else 0, p(grads["dL_dmeans3D"]), p(grads.get("dL_dsh")),
                 p(grads["dL_dopacity"]), p(grads["dL_dscales"]), p(grads["dL_drotations"]),
                 p(grads.get("dL_dlanguage")), p(grads["dL_dmeans2D"]), radii.data_ptr(), self.flat.data_ptr(),
                 self.densify.data_ptr(), self.max_radii.data_ptr(),
                 C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)))
             return
+        if first:
+            self.zero_()
         self.view("means3D").add_(grads["dL_dmeans3D"])
         if self.layout.M > 0:
             self.view("sh").add_(grads["dL_dsh"].reshape(grads["dL_dsh"].shape[0], -1))
@@ -221,9 +223,11 @@ class FrameShardedStep:
         cameras[v]: viewmatrix, projmatrix, projmatrix_raw, campos (device tensors), tanfovx, tanfovy.
         cotangents(v, outputs) -> (dL_dcolor, dL_dlanguage, dL_ddepth): the caller's loss gradient."""
         ws = self.ws
-        self.bucket.zero_()
         self.pose_grads.clear()
-        for v in views_of_rank(len(cameras), self.rank, self.world):
+        mine = views_of_rank(len(cameras), self.rank, self.world)
+        if not mine:
+            self.bucket.zero_()
+        for n_done, v in enumerate(mine):
             cam = cameras[v]
             ws.set_scene(sh_degree=sh_degree, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
                          projmatrix_raw=cam["projmatrix_raw"], campos=cam["campos"], tanfovx=cam["tanfovx"],
@@ -231,7 +235,7 @@ class FrameShardedStep:
             out = ws.forward()
             dc, dl, dd = cotangents(v, out)
             g = ws.backward(dc, dl, dd)
-            self.bucket.accumulate(g, out["radii"])
+            self.bucket.accumulate(g, out["radii"], first=(n_done == 0))
             self.pose_grads[v] = g["dL_dtau_sum"].clone()  # [rho | theta], stays on the owning rank
         self.bucket.all_reduce(self.group)
         return self.bucket

@@ -40,7 +40,7 @@ def test_buffer_sizes(L):
     assert 0 < g1 < g2
     assert g2 >= 500000 * (4 + 8 + 16 + 24 + 12 + 3 + 4 * 6)
     assert L.olsr_image_bytes(1200, 680, 15) >= 1200 * 680 * 8 + 80 * 46 * 8
-    assert L.olsr_binning_bytes(1 << 20, 15) >= (1 << 20) * (6 * 4 + 1 + 4)
+    assert L.olsr_binning_bytes(1 << 20, 15) >= (1 << 20) * (5 * 4 + 1 + 4)  # keys x2, val, src, inst_gid, flags, rowbase
     # backward scratch: one row per live (instance, slot) pair, row stride = 10+F floats padded to 16
     s0, s15, s32 = (L.olsr_backward_scratch_bytes(1 << 20, F) for F in (0, 15, 32))
     assert s15 - s0 == (1 << 20) * 4 * (32 - 16) and s32 - s15 == (1 << 20) * 4 * (48 - 32)
