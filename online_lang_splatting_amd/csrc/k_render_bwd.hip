@@ -12,9 +12,10 @@
 //     slots blended it (flags[] bit w).  A wave skips instances its slot never touched with a
 //     uniform branch, and the four waves of a tile only meet when the next batch of 128 list
 //     entries is staged into LDS;
-//   * the per-splat reduction never leaves the wave: ONE multi-value butterfly (N values in
-//     ~N+log2 shuffle-adds instead of 6N) leaves value k in lane k*(64/N), and the wave writes
-//     its own partial-gradient row (instance, slot) with a single coalesced 64..192-byte store;
+//   * the per-splat reduction never leaves the wave and never touches LDS: gfx950's
+//     v_permlane32_swap / v_permlane16_swap fold the lane dimension for two values per swap,
+//     DPP row rotations finish inside rows of 16 (10 instructions per 4 values), and the wave
+//     writes its own partial-gradient row (instance, slot) with one coalesced 64..192-byte store;
 //   * no float atomics: rows are compacted in emission order (rowbase = exclusive scan of
 //     popcount(flags)), so the per-Gaussian reduction (k_preprocess_bwd.hip) streams one dense,
 //     contiguous run of rows per Gaussian and the gradients are bit-reproducible from run to run.
@@ -45,40 +46,6 @@ __device__ __forceinline__ bool ref_survives(int rank) {
   }
 }
 
-constexpr int next_pow2(int v) {
-  int p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-
-// Sum N per-lane values across the wave.  On return lane l holds (in v[0]) the wave total of
-// value index l / (64 / N); all 64/N lanes of a group hold the same total.
-// Step (H, M): lanes with bit M set keep the upper H values and send the lower H (and vice
-// versa), halving the live values; once one value is left the remaining lane bits are folded
-// with plain xor-shuffles.  Written as a template recursion so that every register-array index
-// is a compile-time constant (a runtime-indexed private array is lowered to select chains).
-template <int H, int M, int N>
-__device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
-  if constexpr (H >= 1) {
-    const bool upper = (lane & M) != 0;
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-      const float send = upper ? v[i] : v[i + H];
-      const float keep = upper ? v[i + H] : v[i];
-      v[i] = keep + __shfl_xor(send, M);
-    }
-    wave_reduce_rec<H / 2, M / 2, N>(v, lane);
-  } else if constexpr (M >= 1) {
-    v[0] += __shfl_xor(v[0], M);
-    wave_reduce_rec<0, M / 2, N>(v, lane);
-  }
-}
-template <int N>
-__device__ __forceinline__ void wave_reduce_multi(float (&v)[N], int lane) {
-  static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "N must be a power of two <= 64");
-  wave_reduce_rec<N / 2, 32, N>(v, lane);
-}
-
 constexpr int BWD_BATCH = 128;
 
 template <int TILE, int F, int MODE>
@@ -95,8 +62,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   constexpr int ROW = grad_row(F);
   constexpr bool REF = (MODE == OLSR_BWD_REFERENCE);
   constexpr int NV = REF ? 10 : 10 + F;  // values that go through the wave reduction
-  constexpr int NP = next_pow2(NV);
-  constexpr int G_LANES = 64 / NP;        // lanes per value group after the butterfly
+  constexpr int NG = (NV + 3) / 4;       // groups of four values reduced together (wave_reduce4)
   constexpr int FX = (F > 0) ? F : 1;
   constexpr int B = BWD_BATCH;
   static_assert(ROW <= 64, "one lane per row element");
@@ -224,9 +190,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
       const float alpha = fminf_ref(0.99f, co.w * G);
       skip |= alpha < 1.0f / 255.0f;
 
-      float sum[NP];
+      float sum[4 * NG];
 #pragma unroll
-      for (int v = 0; v < NP; ++v) sum[v] = 0.f;
+      for (int v = 0; v < 4 * NG; ++v) sum[v] = 0.f;
       float lang0[FX];  // REF: rank 0's language partials (lane 0 of wave 0)
 #pragma unroll
       for (int ch = 0; ch < FX; ++ch) lang0[ch] = 0.f;
@@ -295,17 +261,25 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
         }
       }
 
-      // One multi-value butterfly; afterwards lane l holds the wave total of value l / G_LANES.
-      wave_reduce_multi<NP>(sum, lane);
-      // Transpose into row order: lane j (< NV) fetches value j from lane j * G_LANES.
-      float rowval = __shfl(sum[0], (lane * G_LANES) & 63);
+      // Wave reduction, four values per permlane-swap tree (olsr_device.h); the totals of group g sit
+      // in the four 16-lane rows of red[g].  Lane j (< NV) then fetches value j into row order.
+      float rowval = 0.f;
+      {
+        const int src_lane = reduce4_lane(lane & 3);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const float red = wave_reduce4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
+          const float pulled = __shfl(red, src_lane);
+          rowval = ((lane >> 2) == g) ? pulled : rowval;
+        }
+      }
       if (lane >= NV) rowval = 0.f;
       if constexpr (REF && F > 0) {
         // language gradients come from tile rank 0 only (lane 0 of wave 0): broadcast and place
         if (w == 0) {
 #pragma unroll
           for (int ch = 0; ch < F; ++ch) {
-            const float v = __shfl(lang0[ch], 0);
+            const float v = lane_read(lang0[ch], 0);
             rowval = (lane == 10 + ch) ? v : rowval;
           }
         }

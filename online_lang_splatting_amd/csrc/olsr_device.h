@@ -24,30 +24,45 @@ __device__ __forceinline__ bool wave_all(bool p) { return ballot(!p) == 0ull; }
 __device__ __forceinline__ float bits2f(u32 u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ u32 f2bits(float f) { return __builtin_bit_cast(u32, f); }
 
-// ---- DPP wave reduction --------------------------------------------------------------------
-// Sum over the 64 lanes with data-parallel-primitive row operations (no LDS traffic): xor-1 and
-// xor-2 inside quads, half-mirror and mirror inside each row of 16, then row_bcast:15 / :31 to
-// chain the four rows.  The total lands in lane 63.  Fixed order => bit-reproducible.
-template <int CTRL, int ROW_MASK = 0xf>
+// ---- gfx950 wave reduction of four values at once -----------------------------------------------
+// v_permlane32_swap / v_permlane16_swap (new in gfx950) exchange the upper half of one VGPR with the
+// lower half of another (halves of 32 lanes, resp. rows of 16 inside each half).  One swap + one add
+// folds the lane dimension in half for TWO values at once, with no select and no LDS permute:
+//     (a, b) -> a' = {a.lo, b.lo}, b' = {a.hi, b.hi};  a' + b' = { a[l] + a[l+32] | b[l] + b[l+32] }.
+// Two levels leave one register holding four values, one per row of 16 lanes; four DPP row
+// rotations finish the sum inside each row.  10 instructions per 4 values (vs 24 for four plain
+// 6-step reductions), fixed order => bit-reproducible.
+// On return every lane of row 0 holds sum(a), row 1 sum(c), row 2 sum(b), row 3 sum(d).
+template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v += dpp_mov<0xB1>(v);        // quad_perm:[1,0,3,2]
-  v += dpp_mov<0x4E>(v);        // quad_perm:[2,3,0,1]
-  v += dpp_mov<0x141>(v);       // row_half_mirror
-  v += dpp_mov<0x140>(v);       // row_mirror
-  v += dpp_mov<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
-  v += dpp_mov<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
-  return v;
+// (the two results are copied to scalars before the bit cast: casting the vector elements in place
+//  made this clang add r[0] to itself — verified with scripts/probe/reduce4_probe.hip)
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                  false, false);
+  const unsigned x = r[0], y = r[1];
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
 }
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                  false, false);
+  const unsigned x = r[0], y = r[1];
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d) {
+  float t = swap16_add(swap32_add(a, b), swap32_add(c, d));
+  t += dpp_mov<0x128>(t);  // row_ror:8
+  t += dpp_mov<0x124>(t);  // row_ror:4
+  t += dpp_mov<0x122>(t);  // row_ror:2
+  t += dpp_mov<0x121>(t);  // row_ror:1
+  return t;
+}
+// lane that holds value i (0..3) of a wave_reduce4 result: rows are ordered a, c, b, d
+__device__ __forceinline__ int reduce4_lane(int i) { return 16 * (((i & 1) << 1) | ((i >> 1) & 1)); }
 __device__ __forceinline__ float lane_read(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-// put a wave-uniform value into one lane of `row` (this clang has no writelane builtin; a
-// compare + select with a scalar source is what it lowers to anyway)
-__device__ __forceinline__ float lane_write(float row, float uniform_value, int lane, int my_lane) {
-  return (my_lane == lane) ? uniform_value : row;
 }
 
 // ---- pinned exp --------------------------------------------------------------------------
