@@ -495,4 +495,31 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
   tile_ranges_kernel<<<nb, 256, 0, st>>>(sorted_keys, n_host, n_dev, ranges);
 }
 
+// ------------------------------------------------------------------------------- tile order
+// Longest-processing-time-first inside each XCD chunk.  xcd_remap gives XCD x the contiguous
+// tiles [start_x, start_x + len_x); workgroup b = 8k + x of the backward composite takes the k-th
+// heaviest tile of chunk x, so stragglers start early while neighbouring tiles still share an L2.
+// Rank sort (len <= a few thousand): rank = #tiles heavier, ties by index -> a permutation.
+__global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
+                                                         int ntiles) {
+  const int x = blockIdx.x;  // XCD
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  const int len = q + (x < r ? 1 : 0);
+  for (int i = threadIdx.x; i < len; i += blockDim.x) {
+    const u32 wi = work[start + i];
+    int rank = 0;
+    for (int j = 0; j < len; ++j) {
+      const u32 wj = work[start + j];
+      rank += (wj > wi) || (wj == wi && j < i);
+    }
+    order[start + rank] = (u32)(start + i);
+  }
+}
+
+void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st) {
+  if (ntiles <= 0) return;
+  tile_order_kernel<<<8, 256, 0, st>>>(tile_work, tile_order, ntiles);
+}
+
 }  // namespace olsr

@@ -51,8 +51,8 @@ constexpr int BWD_BATCH = 128;
 template <int TILE, int F, int MODE>
 __global__ __launch_bounds__(256) void render_bwd_kernel(
     const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src,
-    const uint8_t* __restrict__ flags, const u32* __restrict__ rowbase, const int32_t* __restrict__ counters, int W,
-    int H, int gx, int ntiles, const float* __restrict__ bg,
+    const uint8_t* __restrict__ flags, const u32* __restrict__ rowbase, const int32_t* __restrict__ counters,
+    const u32* __restrict__ tile_order, int W, int H, int gx, int ntiles, const float* __restrict__ bg,
     const float* __restrict__ means2D, const float* __restrict__ conic_opacity, const float* __restrict__ colors,
     const float* __restrict__ lang, const float* __restrict__ depths, const float* __restrict__ final_Ts,
     const u32* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_lang,
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   __shared__ u32 s_flag[B];
   __shared__ int s_kmax[4];
 
-  const int tile_id = xcd_remap((int)blockIdx.x, ntiles);
+  // workgroup b runs on XCD b % 8 and takes the (b / 8)-th heaviest tile of that XCD's chunk
+  const int tile_id = (int)tile_order[xcd_remap((int)blockIdx.x, ntiles)];
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int bx = tile_id % gx, by = tile_id / gx;
@@ -296,7 +297,8 @@ static void launch_bwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                          hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
   render_bwd_kernel<TILE, F, MODE><<<d.ntiles, 256, 0, st>>>(
-      im.ranges, b.inst_gid, b.src, b.flags, b.rowbase, g.counters, d.W, d.H, d.gx, d.ntiles, s.background,
+      im.ranges, b.inst_gid, b.src, b.flags, b.rowbase, g.counters, im.tile_order, d.W, d.H, d.gx, d.ntiles,
+      s.background,
       g.means2D, g.conic_opacity, colors, s.language_precomp, g.depths, im.final_T, im.n_contrib, dc, dl, dd, rows);
 }
 

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
-    float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags) {
+    float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
+    u32* __restrict__ tile_work) {
   constexpr int BS = TILE * TILE;
   constexpr int FR = feat_row(F);
   constexpr int NA = 4 + F;  // r g b depth lang[F]
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   __shared__ u32 s_src[B];
   __shared__ u32 s_flag[B];
   __shared__ u32 s_touch[B];
+  __shared__ u32 s_work;
 
   const int tile_id = xcd_remap((int)blockIdx.x, ntiles);
   const int tid = threadIdx.x;
@@ -59,6 +61,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   const bool inside = (rank < BS) && (px < W) && (py < H);
   const float pixfx = (float)px, pixfy = (float)py;
   bool done = !inside;
+  if (tid == 0) s_work = 0;
+  u32 my_work = 0;  // live (instance, slot) pairs flushed by this thread
   float T = 1.0f;
   u32 last_contributor = 0;
   float acc[NA];
@@ -143,10 +147,21 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
     if (tid < cnt) {
       const u32 fl = s_flag[tid];
       if (fl) flags[s_src[tid]] = (uint8_t)fl;
+      my_work += (u32)__popc(fl);
       const u32 tc = s_touch[tid];
       if (tc) atomicAdd(&n_touched[s_id[tid]], (int)tc);
     }
   }
+
+  // backward work estimate of this tile: the number of (instance, slot) pairs it will visit
+  if (tid < B) {
+    u32 wsum = my_work;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wsum += __shfl_xor(wsum, m);
+    if ((tid & 63) == 0 && wsum) atomicAdd(&s_work, wsum);
+  }
+  __syncthreads();
+  if (tid == 0) tile_work[tile_id] = s_work;
 
   if (inside) {
     const size_t HW = (size_t)H * W;
@@ -173,7 +188,8 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                                                        g.means2D, g.conic_opacity, g.depths, colors,
                                                        s.language_precomp, s.background, im.final_T, im.n_contrib,
                                                        out_color, out_language, out_depth, out_opacity, n_touched,
-                                                       b.flags);
+                                                       b.flags, im.tile_work);
+  launch_tile_order(im.tile_work, im.tile_order, d.ntiles, st);
 }
 
 template <int TILE>

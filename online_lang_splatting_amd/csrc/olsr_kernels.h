@@ -35,6 +35,8 @@ void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g
 // counters[7] = (total > row_capacity)
 void launch_row_compaction(const uint8_t* flags, int64_t n_host, uint32_t* rowbase, uint32_t* partials,
                            int64_t row_capacity, int32_t* counters, int32_t* status_dev, hipStream_t st);
+// backward launch order: inside each XCD's contiguous chunk of tiles, heaviest (most live pairs) first
+void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st);
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
                         int ntiles, hipStream_t st);
 

@@ -99,12 +99,16 @@ struct ImageState {
   float* final_T;       // [H*W]
   uint32_t* n_contrib;  // [H*W]
   uint32_t* ranges;     // [tiles][2]
+  uint32_t* tile_work;  // [tiles] live (instance, slot) pairs of the tile (written by the forward composite)
+  uint32_t* tile_order; // [tiles] backward launch order: per XCD chunk, heaviest tile first
   static ImageState carve(void* buf, size_t N, size_t tiles, size_t& bytes) {
     Carver c(buf);
     ImageState s;
     s.final_T = c.take<float>(N);
     s.n_contrib = c.take<uint32_t>(N);
     s.ranges = c.take<uint32_t>(2 * tiles);
+    s.tile_work = c.take<uint32_t>(tiles);
+    s.tile_order = c.take<uint32_t>(tiles);
     bytes = c.total();
     return s;
   }
