@@ -12,10 +12,17 @@ gradient buffer.  With N > 1 (one process per GPU, torch.distributed over RCCL) 
 renders its own viewpoint of the same Gaussians per step and the step ends with the one
 all-reduce of the shared-Gaussian gradient buffer (frame sharding, weak scaling).
 
+Frames are independent (the views of a mapping iteration), so `--streams S` (default 3) keeps S
+frames in flight on S HIP streams with S workspaces (frame k on stream k mod S): the small binning
+kernels of one frame overlap the compositing kernels of another, and with N > 1 the all-reduce of
+one frame overlaps the compute of the next.  The timed region still issues exactly K steps.
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against the 8 TB/s HBM
 peak using the algorithmic byte model of DESIGN.md §6 and its duration measured with HIP
-events on the launch stream over the timed region; `cpu_baseline` is the CPU oracle (a port —
-the reference has no CPU path) on one full frame of the same workload.
+events on the launch stream over the timed region (with S > 1 kernels of different frames share
+the GPU, so that duration includes co-scheduling); `isolated` repeats the measurement afterwards
+with ONE frame in flight — clean per-kernel durations and the single-frame latency;
+`cpu_baseline` is the CPU oracle (a port — the reference has no CPU path) on one full frame.
 """
 import argparse
 import json
@@ -29,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from online_lang_splatting_amd import _abi, _lib  # noqa: E402
-from online_lang_splatting_amd.frame_shard import FrameShardedStep, RasterWorkspace  # noqa: E402
+from online_lang_splatting_amd.frame_shard import FrameLanes  # noqa: E402
 from online_lang_splatting_amd.scene import CONFIGS, arc_cameras, make_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -98,6 +105,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="reference", choices=["reference", "exact"])
+    ap.add_argument("--streams", type=int, default=3, help="frames in flight per GPU (workspaces on separate HIP streams)")
+    ap.add_argument("--isolated-steps", type=int, default=20, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,61 +148,67 @@ def main():
     R = int(r[0])
     del r
     capacity = int(R * 1.25) + (1 << 16)
-    ws = RasterWorkspace(P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode)
-    step = FrameShardedStep(ws, rank=rank, world=world)
+    lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode)
 
-    def cot(_v, _out):
-        return dc, dl, dd
-
-    def one_step():
+    def one_step(lane):
         # every rank renders exactly one view per step (weak scaling): its own
-        ws.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
-        out = ws.forward()
-        g = ws.backward(dc, dl, dd)
-        step.bucket.accumulate(g, out["radii"], first=True)  # one view per rank per step
-        step.bucket.all_reduce()
+        ws, bucket, stream = lane
+        with torch.cuda.stream(stream):
+            ws.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
+            out = ws.forward()
+            g = ws.backward(dc, dl, dd)
+            bucket.accumulate(g, out["radii"], first=True)
+            bucket.all_reduce()
 
-    for _ in range(a.warmup):
-        one_step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    _lib.set_profiling(rank == 0)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    stages = _lib.stage_times() if rank == 0 else []
-    _lib.set_profiling(False)
+    def timed(nsteps, warmup, pick):
+        for _ in range(warmup):
+            one_step(pick())
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        _lib.set_profiling(rank == 0)
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            one_step(pick())
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        st = _lib.stage_times() if rank == 0 else []
+        _lib.set_profiling(False)
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per = {}
+        for name, ms in st:
+            per.setdefault(name, []).append(ms)
+        return float(t.item()), {k: sum(v) / len(v) for k, v in per.items()}
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    Rr, overflow = ws.rendered()
+    elapsed, avg = timed(a.steps, a.warmup, lanes.next_lane)
+    iso = None
+    if a.isolated_steps > 0 and len(lanes) > 1:
+        iso = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
+    ws0 = lanes.lanes[0][0]
+    Rr, overflow = ws0.rendered()
+    L_rows, row_overflow = ws0.backward_status()
 
     if rank == 0:
         frames = world * a.steps
         fps = frames / elapsed
-        per_stage = {}
-        for name, ms in stages:
-            per_stage.setdefault(name, []).append(ms)
-        avg = {k: sum(v) / len(v) for k, v in per_stage.items()}
         N = W * H
         model = algorithmic_bytes(P, Rr, N, 3, F, M)
-        comp = {k: avg[k] for k in ("render_forward", "render_backward") if k in avg}
-        dom = max(comp, key=comp.get) if comp else None
-        roof = None
-        if dom:
-            achieved = model[dom] / (avg[dom] * 1e-3) / 1e9
+        def roofline_of(av):
+            comp = {k: av[k] for k in ("render_forward", "render_backward") if k in av}
+            if not comp:
+                return None
+            dom = max(comp, key=comp.get)
+            achieved = model[dom] / (av[dom] * 1e-3) / 1e9
             traffic, traffic_src = measured_traffic(dom, F) if a.config == 3 else (None, None)
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": int(model[dom]), "avg_launch_ms": round(avg[dom], 4)}
+                    "algorithmic_bytes_per_launch": int(model[dom]), "avg_launch_ms": round(av[dom], 4)}
+        roof = roofline_of(avg)
         gpu_ms = sum(avg.values())
         frame = {"algorithmic_bytes": int(model["frame"]),
                  "achieved_GBs_wall": round(model["frame"] * fps / world / 1e9, 2),
@@ -209,12 +224,20 @@ def main():
                                    f"language channels, forward+backward, tile 15, backward mode {a.mode}",
                        "P": P, "width": W, "height": H, "F": F, "R": Rr, "R_over_P": round(Rr / max(P, 1), 3),
                        "views_per_step": world, "parallelism": f"frame-shard x{world}",
-                       "capacity_overflow": overflow},
+                       "frames_in_flight_per_gpu": len(lanes), "live_gradient_rows": L_rows,
+                       "capacity_overflow": bool(overflow or row_overflow)},
             "roofline": roof,
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "frame_model": frame,
             "target": {"fps": 40.0, "met": fps / world >= 40.0},
         }
+        if iso is not None:
+            iso_el, iso_avg = iso
+            out["isolated"] = {"frames_in_flight_per_gpu": 1, "steps": a.isolated_steps,
+                               "value": round(world * a.isolated_steps / iso_el, 3), "unit": "frames/s",
+                               "ms_per_frame": round(1e3 * iso_el / a.isolated_steps, 4),
+                               "roofline": roofline_of(iso_avg),
+                               "stage_ms": {k: round(v, 4) for k, v in iso_avg.items()}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, a.config)
         print(json.dumps(out), flush=True)

@@ -207,6 +207,34 @@ class RasterWorkspace:
         return int(r[0]), bool(r[1])
 
 
+class FrameLanes:
+    """Several frames in flight on one GPU: `n` independent RasterWorkspaces, each with its own HIP
+    stream and gradient bucket.  The views of a mapping step are independent, and the ~40 small
+    binning kernels of one frame leave most of the 256 CUs idle — a second and third frame on other
+    streams fill them (measured on config 3: 705 -> 913 -> 1005 frames/s for 1 / 2 / 3 lanes)."""
+
+    def __init__(self, n, P, W, H, F, M, capacity, device, **kw):
+        self.device = torch.device(device)
+        self.lanes = []
+        for i in range(max(1, int(n))):
+            ws = RasterWorkspace(P, W, H, F, M, capacity, device, **kw)
+            stream = torch.cuda.current_stream(self.device) if i == 0 else torch.cuda.Stream(self.device)
+            self.lanes.append((ws, GradientBucket(P, GradLayout(M, F), device), stream))
+        self._next = 0
+
+    def __len__(self):
+        return len(self.lanes)
+
+    def next_lane(self):
+        lane = self.lanes[self._next % len(self.lanes)]
+        self._next += 1
+        return lane
+
+    def synchronize(self):
+        for _, _, st in self.lanes:
+            st.synchronize()
+
+
 class FrameShardedStep:
     """One optimisation step's worth of rasterization, sharded by viewpoint over the ranks of a
     torch.distributed group (one process per GPU).  `cameras` is the full list of views of the step
