@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="reference", choices=["reference", "exact"])
+    ap.add_argument("--binning", default="ellipse", choices=["ellipse", "rect"],
+                    help="ellipse: exact tile lists (default); rect: the reference's bounding-square lists")
     ap.add_argument("--streams", type=int, default=3, help="frames in flight per GPU (workspaces on separate HIP streams)")
     ap.add_argument("--isolated-steps", type=int, default=20, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
@@ -134,6 +136,8 @@ def main():
 
     # size the instance capacity from one synchronous forward of this rank's view
     from online_lang_splatting_amd import _C
+    binning = _abi.BINNING_ELLIPSE if a.binning == "ellipse" else _abi.BINNING_RECT
+    _C.BINNING = binning
     my_view = rank % len(cams)
     c0 = cam_dev[my_view]
     r = _C.rasterize_language_gaussians(g_dev["bg"], g_dev["means3D"], torch.empty(0, device=dev), g_dev["language"],
@@ -147,8 +151,9 @@ def main():
                                g_dev["shs"], sc.sh_degree, c0["campos"], False, False)
     R = int(r[0])
     del r
+    _C.BINNING = _abi.BINNING_ELLIPSE
     capacity = int(R * 1.25) + (1 << 16)
-    lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode)
+    lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning)
 
     def one_step(lane):
         # every rank renders exactly one view per step (weak scaling): its own
@@ -190,13 +195,15 @@ def main():
         iso = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
     ws0 = lanes.lanes[0][0]
     Rr, overflow = ws0.rendered()
+    # the reference's num_rendered (bounding-square instances) of this view: the R of the byte model
+    R_ref = int(_C.state_field("geometry", ws0.geom, "counters", P=P, F=F, dtype=torch.int32, count=8)[3])
     L_rows, row_overflow = ws0.backward_status()
 
     if rank == 0:
         frames = world * a.steps
         fps = frames / elapsed
         N = W * H
-        model = algorithmic_bytes(P, Rr, N, 3, F, M)
+        model = algorithmic_bytes(P, R_ref, N, 3, F, M)
         def roofline_of(av):
             comp = {k: av[k] for k in ("render_forward", "render_backward") if k in av}
             if not comp:
@@ -222,7 +229,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{a.config - 1}]: {P} Gaussians, {W}x{H}, RGB+depth+{F} "
                                    f"language channels, forward+backward, tile 15, backward mode {a.mode}",
-                       "P": P, "width": W, "height": H, "F": F, "R": Rr, "R_over_P": round(Rr / max(P, 1), 3),
+                       "P": P, "width": W, "height": H, "F": F, "R": R_ref, "R_over_P": round(R_ref / max(P, 1), 3),
+                       "binning": a.binning, "R_binned": Rr,
                        "views_per_step": world, "parallelism": f"frame-shard x{world}",
                        "frames_in_flight_per_gpu": len(lanes), "live_gradient_rows": L_rows,
                        "capacity_overflow": bool(overflow or row_overflow)},

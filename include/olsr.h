@@ -48,6 +48,17 @@ extern "C" {
  * resize functionals of CR/rasterizer.h:34-36 and DGR/rasterize_points.cu:27-33. */
 typedef void *(*olsr_alloc_fn)(void *user, size_t nbytes);
 
+/* How Gaussians are binned into tiles.
+ *   OLSR_BINNING_RECT     every tile of the reference's bounding square (getRect, CR/auxiliary.h:46-56):
+ *                         instance lists, num_rendered and n_contrib equal the reference's bit for bit.
+ *   OLSR_BINNING_ELLIPSE  only the tiles that the ellipse alpha >= 1/255 can reach (a subset of the
+ *                         square, same order).  The dropped (tile, Gaussian) pairs blend no pixel in the
+ *                         forward and are whole-tile skips in the backward, so every image, radii,
+ *                         n_touched and every gradient is unchanged; num_rendered and the state buffers'
+ *                         list positions (n_contrib) count the kept pairs. */
+#define OLSR_BINNING_RECT 0
+#define OLSR_BINNING_ELLIPSE 1
+
 /* Per-call scene description shared by forward and backward.
  * Replaces the positional argument lists of
  *   CudaRasterizer::Rasterizer::forward / backward           CR/rasterizer.h:33-104
@@ -67,7 +78,7 @@ typedef struct olsr_scene {
   float tan_fovx;
   float tan_fovy;
   float scale_modifier;
-  float _pad0;
+  int32_t binning;     /* OLSR_BINNING_RECT or OLSR_BINNING_ELLIPSE (used by forward only) */
   const float *background;       /* [3] */
   const float *means3D;          /* [P,3] */
   const float *shs;              /* [P,M,3] or NULL */

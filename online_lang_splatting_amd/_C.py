@@ -8,6 +8,8 @@ plumbing); all arithmetic happens behind the C-ABI of include/olsr.h in libolsr.
 Knobs the reference fixes at compile time (CR/config.h:15-18) are module attributes:
   TILE      logical tile edge, 15 (reference) or 16
   BWD_MODE  _abi.BWD_REFERENCE (bug-compatible, default) or _abi.BWD_EXACT (true gradient)
+  BINNING   _abi.BINNING_ELLIPSE (default: exact tile lists, identical outputs) or _abi.BINNING_RECT
+            (the reference's bounding-square lists, bit-identical num_rendered / point_list / n_contrib)
 The number of language channels is taken from language.shape[1] (supported: 3, 15, 16, 32).
 """
 import ctypes as C
@@ -19,6 +21,7 @@ from ._lib import check, lib
 
 TILE = 15
 BWD_MODE = _abi.BWD_REFERENCE
+BINNING = _abi.BINNING_ELLIPSE
 
 
 def _stream(device):
@@ -61,7 +64,7 @@ def _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_m
     M = sh_.shape[1] if sh_ is not None else 0
     s = _abi.make_scene(P=means3D.shape[0], D=degree, M=M, F=F, width=W, height=H, tile=TILE,
                         prefiltered=prefiltered, debug=debug, bwd_mode=BWD_MODE, tan_fovx=tan_fovx, tan_fovy=tan_fovy,
-                        scale_modifier=scale_modifier, background=bg_, means3D=m_, shs=sh_, colors_precomp=col_,
+                        scale_modifier=scale_modifier, binning=BINNING, background=bg_, means3D=m_, shs=sh_, colors_precomp=col_,
                         language_precomp=lang_, opacities=op_, scales=sc_, rotations=rot_, cov3D_precomp=cov_,
                         viewmatrix=v_, projmatrix=p_, projmatrix_raw=pr_, cam_pos=cp_)
     return s, keep

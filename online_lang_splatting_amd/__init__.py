@@ -7,13 +7,13 @@ top-level shim package re-exports the same names).
 Importing this package loads no native code; the first rasterizer call loads libolsr.so and
 raises if it is missing (there is no CPU fallback).
 """
-from ._abi import BWD_EXACT, BWD_REFERENCE  # noqa: F401
+from ._abi import BINNING_ELLIPSE, BINNING_RECT, BWD_EXACT, BWD_REFERENCE  # noqa: F401
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
                          LanguageGaussianRasterizer, rasterize_gaussians, rasterize_language_gaussians)
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "LanguageGaussianRasterizer",
            "rasterize_gaussians", "rasterize_language_gaussians", "BWD_REFERENCE", "BWD_EXACT", "set_backward_mode",
-           "set_tile"]
+           "set_tile", "BINNING_RECT", "BINNING_ELLIPSE", "set_binning"]
 
 
 def set_backward_mode(mode):
@@ -22,6 +22,16 @@ def set_backward_mode(mode):
     if mode not in (BWD_REFERENCE, BWD_EXACT):
         raise ValueError("mode must be BWD_REFERENCE or BWD_EXACT")
     _C.BWD_MODE = mode
+
+
+def set_binning(binning):
+    """BINNING_ELLIPSE (default): a Gaussian is listed only in the tiles its alpha >= 1/255 ellipse reaches —
+    identical images and gradients, about half the instances.  BINNING_RECT: the reference's bounding-square
+    lists (getRect, CR/auxiliary.h:46-56), for bit-identical num_rendered / point lists."""
+    from . import _C
+    if binning not in (BINNING_RECT, BINNING_ELLIPSE):
+        raise ValueError("binning must be BINNING_RECT or BINNING_ELLIPSE")
+    _C.BINNING = binning
 
 
 def set_tile(tile):

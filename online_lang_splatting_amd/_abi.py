@@ -13,6 +13,9 @@ OLSR_ERR_CAPACITY = -4
 BWD_REFERENCE = 0
 BWD_EXACT = 1
 
+BINNING_RECT = 0     # every tile of the reference's bounding square (bit-identical instance lists)
+BINNING_ELLIPSE = 1  # only tiles the alpha >= 1/255 ellipse reaches (identical outputs, shorter lists)
+
 SUPPORTED_F = (0, 3, 15, 16, 32)
 SUPPORTED_TILES = (15, 16)
 
@@ -38,7 +41,7 @@ class OlsrScene(C.Structure):
         ("tan_fovx", C.c_float),
         ("tan_fovy", C.c_float),
         ("scale_modifier", C.c_float),
-        ("_pad0", C.c_float),
+        ("binning", C.c_int32),
         ("background", _fp),
         ("means3D", _fp),
         ("shs", _fp),
@@ -65,13 +68,14 @@ def _ptr(t):
 
 
 def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode, tan_fovx, tan_fovy,
-               scale_modifier, background, means3D, shs, colors_precomp, language_precomp, opacities,
+               scale_modifier, binning=BINNING_RECT, background, means3D, shs, colors_precomp, language_precomp, opacities,
                scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos):
     s = OlsrScene()
     s.P, s.D, s.M, s.F = int(P), int(D), int(M), int(F)
     s.width, s.height, s.tile = int(width), int(height), int(tile)
     s.prefiltered, s.debug, s.bwd_mode = int(bool(prefiltered)), int(bool(debug)), int(bwd_mode)
     s.tan_fovx, s.tan_fovy, s.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
+    s.binning = int(binning)
     s.background = _ptr(background)
     s.means3D = _ptr(means3D)
     s.shs = _ptr(shs)

@@ -289,8 +289,14 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 
 // ------------------------------------------------------------------------------- offsets
 __global__ void finalize_counts_kernel(const u32* offsets, int P, long long capacity, int32_t* counters,
-                                       int32_t* num_rendered_dev) {
+                                       int32_t* num_rendered_dev, const u32* rect_partials, int nparts) {
+  // the reference's num_rendered (rect binning): sum of preprocess' per-block partials
+  u32 rect = 0;
+  for (int i = threadIdx.x; i < nparts; i += 64) rect += rect_partials[i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) rect += __shfl_xor(rect, m);
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    counters[3] = (int32_t)rect;
     const u32 R = (P > 0) ? offsets[P - 1] : 0u;
     const bool ok = (long long)R <= capacity && R <= 0x7FFFFFFFu;
     counters[0] = (int32_t)R;
@@ -307,7 +313,8 @@ __global__ void finalize_counts_kernel(const u32* offsets, int P, long long capa
 void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, int32_t* num_rendered_dev,
                              hipStream_t st) {
   device_scan<LoadGather, true>(LoadGather{g.tiles_touched, g.depth_order}, (int64_t)P, g.offsets, g.scan_partials, st);
-  finalize_counts_kernel<<<1, 64, 0, st>>>(g.offsets, P, (long long)capacity, g.counters, num_rendered_dev);
+  finalize_counts_kernel<<<1, 64, 0, st>>>(g.offsets, P, (long long)capacity, g.counters, num_rendered_dev,
+                                           reinterpret_cast<const u32*>(g.tau_partials), (P + 255) / 256);
 }
 
 // ------------------------------------------------------------------------------- emission
@@ -320,45 +327,118 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict_
                                                    const u32* __restrict__ offsets,
                                                    const u32* __restrict__ tiles_touched,
                                                    const float* __restrict__ means2D, const int32_t* __restrict__ radii,
+                                                   const float* __restrict__ conic_opacity,
+                                                   const float* __restrict__ cull_t2, int ellipse, int W, int H,
                                                    int gx, int gy, const int32_t* __restrict__ counters,
                                                    u32* __restrict__ keys, u32* __restrict__ inst_gid,
                                                    u32* __restrict__ inst_start) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (counters[2] != 0) return;  // overflow: nothing is emitted (uniform)
   const int lane = threadIdx.x & 63;
+  // Depth ranks are dealt round-robin to the waves (wave v takes ranks v, v + NW, ...): the nearest
+  // Gaussians are the largest, and contiguous ranks would put 64 of them — each one a serial
+  // whole-wave job below — into the same few waves while the rest of the grid idles.
+  const int nw = (int)(gridDim.x * (blockDim.x >> 6));
+  const int wv = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const int r = lane * nw + wv;
   u32 g = 0, n = 0, off = 0;
   Rect rc = {0, 0, 0, 0};
+  float mx = 0.f, my = 0.f;
+  int rad = 0;
   if (r < P) {
     g = order[r];
-    const int rad = radii[g];
+    rad = radii[g];
     if (rad > 0) {
       n = tiles_touched[g];
       off = offsets[r] - n;
       inst_start[g] = off;
-      rc = get_rect<TILE>(means2D[2 * (size_t)g], means2D[2 * (size_t)g + 1], rad, gx, gy);
+      mx = means2D[2 * (size_t)g];
+      my = means2D[2 * (size_t)g + 1];
+      rc = get_rect<TILE>(mx, my, rad, gx, gy);
     }
   }
+  if (!ellipse) {
+    if (n > 0 && n <= EMIT_BIG) {
+      u32 o = off;
+      for (int y = rc.y0; y < rc.y1; y++)
+        for (int x = rc.x0; x < rc.x1; x++) {
+          keys[o] = (u32)(y * gx + x);
+          inst_gid[o] = g;
+          o++;
+        }
+    }
+    // near splats cover hundreds of tiles: the wave writes those runs together, coalesced
+    u64 big = ballot(n > EMIT_BIG);
+    while (big) {
+      const int sl = __builtin_ctzll(big);
+      big &= big - 1;
+      const u32 bn = __shfl(n, sl), boff = __shfl(off, sl), bg = __shfl(g, sl);
+      const int x0 = __shfl(rc.x0, sl), y0 = __shfl(rc.y0, sl), x1 = __shfl(rc.x1, sl);
+      const u32 wrect = (u32)(x1 - x0);
+      for (u32 t = (u32)lane; t < bn; t += 64) {
+        const u32 yy = t / wrect, xx = t - yy * wrect;
+        keys[boff + t] = (u32)((y0 + (int)yy) * gx + (x0 + (int)xx));
+        inst_gid[boff + t] = bg;
+      }
+    }
+    return;
+  }
+  // exact binning: the same row spans preprocess counted (same function, same inputs)
+  float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+  float t2 = -1.f;
+  if (n > 0) {
+    co = reinterpret_cast<const float4*>(conic_opacity)[g];
+    t2 = cull_t2[g];
+  }
   if (n > 0 && n <= EMIT_BIG) {
+    const CullEllipse e = cull_setup(mx, my, co.x, co.y, co.z, t2, rad);
     u32 o = off;
-    for (int y = rc.y0; y < rc.y1; y++)
-      for (int x = rc.x0; x < rc.x1; x++) {
+    int ya, yb;
+    cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
+    for (int y = ya; y < yb; y++) {
+      int xa, xb;
+      cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
+      for (int x = xa; x < xb; x++) {
         keys[o] = (u32)(y * gx + x);
         inst_gid[o] = g;
         o++;
       }
+    }
   }
-  // near splats cover hundreds of tiles: the wave writes those runs together, coalesced
   u64 big = ballot(n > EMIT_BIG);
   while (big) {
     const int sl = __builtin_ctzll(big);
     big &= big - 1;
-    const u32 bn = __shfl(n, sl), boff = __shfl(off, sl), bg = __shfl(g, sl);
-    const int x0 = __shfl(rc.x0, sl), y0 = __shfl(rc.y0, sl), x1 = __shfl(rc.x1, sl);
-    const u32 wrect = (u32)(x1 - x0);
-    for (u32 t = (u32)lane; t < bn; t += 64) {
-      const u32 yy = t / wrect, xx = t - yy * wrect;
-      keys[boff + t] = (u32)((y0 + (int)yy) * gx + (x0 + (int)xx));
-      inst_gid[boff + t] = bg;
+    const u32 boff = __shfl(off, sl), bg = __shfl(g, sl);
+    const int x0 = __shfl(rc.x0, sl), x1 = __shfl(rc.x1, sl);
+    int y0 = __shfl(rc.y0, sl), y1 = __shfl(rc.y1, sl);
+    const CullEllipse e = cull_setup(__shfl(mx, sl), __shfl(my, sl), __shfl(co.x, sl), __shfl(co.y, sl),
+                                     __shfl(co.z, sl), __shfl(t2, sl), __shfl(rad, sl));
+    cull_rows<TILE>(e, y0, y1, y0, y1);
+    // lane l evaluates rows y0 + l, y0 + l + 64, ...; a wave scan turns the spans into offsets
+    u32 run = 0;
+    for (int yb = y0; yb < y1; yb += 64) {
+      const int y = yb + lane;
+      int xa = 0, xb = 0;
+      if (y < y1) cull_row_span<TILE>(e, x0, x1, y, W, H, xa, xb);
+      const u32 cnt = (u32)(xb - xa);
+      u32 incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const u32 v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+      }
+      const u32 total = __shfl(incl, 63);
+      const u32 excl = incl - cnt;
+      const int rows = min(64, y1 - yb);
+      for (int rr = 0; rr < rows; ++rr) {  // the wave writes row rr's span together
+        const u32 c_r = __shfl(cnt, rr), e_r = __shfl(excl, rr);
+        const int xa_r = __shfl(xa, rr);
+        for (u32 t = (u32)lane; t < c_r; t += 64) {
+          keys[boff + run + e_r + t] = (u32)((yb + rr) * gx + xa_r + (int)t);
+          inst_gid[boff + run + e_r + t] = bg;
+        }
+      }
+      run += total;
     }
   }
 }
@@ -367,12 +447,15 @@ void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g
                  const BinningState& b, hipStream_t st) {
   if (s.P <= 0) return;
   const int nb = (s.P + 255) / 256;
+  const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
   if (d.tile == 15)
-    emit_kernel<15><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii, d.gx, d.gy,
-                                        g.counters, b.key_a, b.inst_gid, g.inst_start);
+    emit_kernel<15><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii,
+                                        g.conic_opacity, g.cull_t2, ellipse, d.W, d.H, d.gx, d.gy, g.counters, b.key_a,
+                                        b.inst_gid, g.inst_start);
   else
-    emit_kernel<16><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii, d.gx, d.gy,
-                                        g.counters, b.key_a, b.inst_gid, g.inst_start);
+    emit_kernel<16><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii,
+                                        g.conic_opacity, g.cull_t2, ellipse, d.W, d.H, d.gx, d.gy, g.counters, b.key_a,
+                                        b.inst_gid, g.inst_start);
 }
 
 // ------------------------------------------------------------------------------- row compaction

@@ -66,18 +66,18 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float m
   cov3D[5] = Sigma.c[2][2];
 }
 
+// One Gaussian; returns the area of the reference's tile rectangle (0 when culled).
 template <int TILE>
-__global__ __launch_bounds__(256) void preprocess_kernel(
-    int P, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales, float scale_modifier,
+__device__ __forceinline__ u32 preprocess_one(
+    int idx, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales, float scale_modifier,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     uint8_t* __restrict__ clamped, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, int W,
     int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int32_t* __restrict__ radii,
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
-    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, u32* __restrict__ sort_key,
-    u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= P) return;
+    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float* __restrict__ cull_t2,
+    u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
+    int ellipse) {
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
   tiles_touched[idx] = 0;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
       printf("Point is filtered although prefiltered is set. This shouldn't happen!");
       __builtin_trap();
     }
-    return;
+    return 0;
   }
   const f4 p_hom = transformPoint4x4(p_orig, projmatrix);
   const float p_w = 1.0f / (p_hom.w + 0.0000001f);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   cov2d_common(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, ci);
   const float cx = ci.cov.c[0][0] + 0.3f, cy = ci.cov.c[0][1], cz = ci.cov.c[1][1] + 0.3f;
   const float det = (cx * cz - cy * cy);
-  if (det == 0.0f) return;
+  if (det == 0.0f) return 0;
   const float det_inv = 1.f / det;
   const f3 conic = {cz * det_inv, -cy * det_inv, cx * det_inv};
 
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   const float pix_x = ndc2Pix(p_proj.x, W), pix_y = ndc2Pix(p_proj.y, H);
   const int irad = f2i_sat(my_radius);
   const Rect rc = get_rect<TILE>(pix_x, pix_y, irad, gx, gy);
-  if ((rc.x1 - rc.x0) * (rc.y1 - rc.y0) == 0) return;
+  const u32 area = (u32)((rc.y1 - rc.y0) * (rc.x1 - rc.x0));
+  if (area == 0) return 0;
 
   if (colors_precomp == nullptr) {
     const f3 c = color_from_sh(idx, D, M, p_orig, cam_pos, shs, clamped);
@@ -131,14 +132,62 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     rgb[3 * (size_t)idx + 1] = c.y;
     rgb[3 * (size_t)idx + 2] = c.z;
   }
+  const float opacity = opacities[idx];
   depths[idx] = p_view.z;
   radii[idx] = irad;
   means2D[2 * (size_t)idx + 0] = pix_x;
   means2D[2 * (size_t)idx + 1] = pix_y;
-  float4 co = make_float4(conic.x, conic.y, conic.z, opacities[idx]);
+  float4 co = make_float4(conic.x, conic.y, conic.z, opacity);
   reinterpret_cast<float4*>(conic_opacity)[idx] = co;
-  tiles_touched[idx] = (u32)((rc.y1 - rc.y0) * (rc.x1 - rc.x0));
   sort_key[idx] = f2bits(p_view.z);
+
+  u32 count = area;
+  if (ellipse) {
+    // exact binning: count, per tile row of the rect, the tile columns the alpha-floor ellipse reaches
+    const float t2 = cull_threshold(conic.x, conic.y, conic.z, opacity, irad, TILE);
+    cull_t2[idx] = t2;
+    count = 0;
+    if (t2 >= 0.0f) {
+      const CullEllipse e = cull_setup(pix_x, pix_y, conic.x, conic.y, conic.z, t2, irad);
+      int ya, yb;
+      cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
+      for (int ty = ya; ty < yb; ++ty) {
+        int xa, xb;
+        cull_row_span<TILE>(e, rc.x0, rc.x1, ty, W, H, xa, xb);
+        count += (u32)(xb - xa);
+      }
+    }
+  }
+  tiles_touched[idx] = count;
+  return area;
+}
+
+template <int TILE>
+__global__ __launch_bounds__(256) void preprocess_kernel(
+    int P, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+    uint8_t* __restrict__ clamped, const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, int W,
+    int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int32_t* __restrict__ radii,
+    float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
+    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float* __restrict__ cull_t2,
+    u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
+    int ellipse, u32* __restrict__ rect_partials) {
+  __shared__ u32 s_area[4];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 area = 0;
+  if (idx < P)
+    area = preprocess_one<TILE>(idx, D, M, orig_points, scales, scale_modifier, rotations, opacities, shs, clamped,
+                                cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, W, H, tan_fovx,
+                                tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy,
+                                tiles_touched, cull_t2, sort_key, sort_val, n_touched, prefiltered, ellipse);
+  // instances of the reference's rect binning (its num_rendered): one partial per block, summed by
+  // finalize_counts_kernel (7.8 k same-address atomics would cost more than the whole kernel)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) area += __shfl_xor(area, m);
+  if ((threadIdx.x & 63) == 0) s_area[threadIdx.x >> 6] = area;
+  __syncthreads();
+  if (threadIdx.x == 0) rect_partials[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
 }
 
 void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometryState& g, int32_t* radii,
@@ -148,8 +197,9 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
 #define OLSR_PRE_ARGS                                                                                                 \
   s.P, s.D, s.M, s.means3D, s.scales, s.scale_modifier, s.rotations, s.opacities, s.shs, g.clamped, s.cov3D_precomp,  \
       s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
-      d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched, g.key_a,   \
-      g.val_a, n_touched, s.prefiltered
+      d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
+      g.cull_t2, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
+      reinterpret_cast<u32*>(g.tau_partials)
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

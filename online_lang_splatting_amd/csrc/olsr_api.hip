@@ -77,6 +77,8 @@ int check_scene(const olsr_scene* s, bool backward) {
   if (s->P < 0) return fail(OLSR_ERR_ARG, "P must be >= 0");
   if (s->width <= 0 || s->height <= 0) return fail(OLSR_ERR_ARG, "image size must be positive");
   if (s->tile != 15 && s->tile != 16) return fail(OLSR_ERR_ARG, "tile must be 15 or 16");
+  if (!backward && s->binning != OLSR_BINNING_RECT && s->binning != OLSR_BINNING_ELLIPSE)
+    return fail(OLSR_ERR_ARG, "binning must be OLSR_BINNING_RECT or OLSR_BINNING_ELLIPSE");
   if (!supported_F(s->F)) return fail(OLSR_ERR_ARG, "F (language channels) must be one of 0, 3, 15, 16, 32");
   if (s->D < 0 || s->D > 3) return fail(OLSR_ERR_ARG, "SH degree must be 0..3");
   if (s->P == 0) return OLSR_OK;

@@ -111,6 +111,133 @@ __device__ __forceinline__ Rect get_rect(float px, float py, int max_radius, int
   return r;
 }
 
+// ---- exact tile binning (OLSR_BINNING_ELLIPSE) ---------------------------------------------
+// The reference bins a Gaussian into every tile of the square that bounds a circle of radius
+// ceil(3 sqrt(lambda_max)) (get_rect).  A pixel can only blend the Gaussian if
+//   alpha = opacity * exp(power) >= 1/255  <=>  q(d) = a dx^2 + 2 b dx dy + c dy^2 <= 2 ln(255 opacity),
+// an ellipse that is usually much smaller than that square (anisotropy, low opacity).  The tiles
+// the ellipse misses contribute nothing in the forward and are "whole tile skips" in the
+// backward (CR/backward.cu:1087-1093), so dropping them changes no output bit.
+//
+// Everything here is CONSERVATIVE interval arithmetic in fp32: every rounding is covered by an
+// explicit outward pad, so a tile is dropped only if no pixel of it can pass the composite's own
+// fp32 alpha test.  The parity suite checks exactly that (bit-identical images, n_touched and
+// flags against the reference binning).
+//
+// cull_threshold: 2 * (L + margins), L = ln(255 opacity).  2e-3 + 1e-4|L| covers __logf, the pinned
+// exp and the opacity product; 5e-7 (a + c + |b|) D^2 bounds the rounding of the three products
+// and two sums of the composite's `power` at distances up to D = radius + TILE + 1.  Negative:
+// no pixel can pass.
+__device__ __forceinline__ float cull_threshold(float a, float b, float c, float opacity, int radius, int tile) {
+  const float o255 = 255.0f * opacity;
+  if (!(o255 > 0.0f)) return -1.0f;
+  const float L = __logf(o255);
+  const float D = (float)radius + (float)tile + 1.0f;
+  const float thr = L + 2e-3f + 1e-4f * fabsf(L) + 5e-7f * (a + c + fabsf(b)) * D * D;
+  if (!(thr >= 0.0f)) return -1.0f;
+  return 2.0f * thr * (1.0f + 1e-6f);
+}
+
+struct CullEllipse {
+  float px, py, b, inv_a, A, det_lo, xstar, ystar, ymax;
+  bool exact;  // false: degenerate / out-of-range conic, every row keeps its full rect span
+};
+__device__ __forceinline__ CullEllipse cull_setup(float px, float py, float a, float b, float c, float t2, int radius) {
+  CullEllipse e;
+  e.px = px;
+  e.py = py;
+  e.b = b;
+  // a c - b^2 with Kahan's fused difference of products (relative error <= 2 ulp), rounded down
+  const float w = b * b;
+  const float err = __builtin_fmaf(-b, b, w);
+  const float det = __builtin_fmaf(a, c, -w) + err;
+  e.det_lo = det * (1.0f - 4e-7f);
+  e.exact = (e.det_lo > 0.0f) && (a > 1e-30f) && (c > 1e-30f) && (t2 >= 0.0f) && (t2 < 1e6f) && (a < 1e6f) &&
+            (c < 1e6f) && (radius < (1 << 20)) && (fabsf(px) < 1e7f) && (fabsf(py) < 1e7f);
+  // v_rcp_f32 / v_sqrt_f32 are accurate to 1 ulp; the outward factors cover that
+  e.inv_a = e.exact ? __builtin_amdgcn_rcpf(a) : 0.0f;
+  e.A = a * t2 * (1.0f + 4e-7f);  // upper bound of a * t2
+  const float inv_det = e.exact ? __builtin_amdgcn_rcpf(e.det_lo) * (1.0f + 4e-7f) : 0.0f;
+  e.xstar = e.exact ? __builtin_amdgcn_sqrtf(t2 * c * inv_det) * (1.0f + 1e-6f) : 0.0f;  // rightmost point, rounded out
+  e.ystar = e.exact ? -b * __builtin_amdgcn_rcpf(c) * e.xstar : 0.0f;                    // its dy
+  e.ymax = e.exact ? __builtin_amdgcn_sqrtf(e.A * inv_det) * (1.0f + 1e-6f) : 3e38f;     // topmost point, rounded out
+  return e;
+}
+// Tile rows [ya, yb) of the reference rect rows [ry0, ry1) that the ellipse's y extent can reach; rows
+// outside hold no instance.
+template <int TILE>
+__device__ __forceinline__ void cull_rows(const CullEllipse& e, int ry0, int ry1, int& ya, int& yb) {
+  ya = ry0;
+  yb = ry1;
+  if (!e.exact || !(e.ymax < 1e7f)) return;
+  const float pad = 1e-2f + 4e-7f * (fabsf(e.py) + e.ymax);
+  const float lo = floorf((e.py - e.ymax - pad) / (float)TILE), hi = floorf((e.py + e.ymax + pad) / (float)TILE);
+  // tile row t covers pixel rows [t * TILE, t * TILE + TILE - 1]: a point below row t's last pixel row and
+  // above row t+1's first one belongs to neither, so flooring is conservative on both ends
+  ya = max(ry0, (int)fmaxf(lo, -1.0f));
+  yb = min(ry1, (int)fminf(hi, 1e6f) + 1);
+  if (yb < ya) yb = ya;
+}
+
+// Tile columns [xa, xb) of tile row ty (inside the reference rect columns [rx0, rx1)) that hold at
+// least one pixel column of ellipse ∩ band, the band being the continuous range of the row's pixel
+// rows.  ellipse ∩ band is convex: its projection on x is one interval, and every tile column that
+// overlaps the interval is hit.
+template <int TILE>
+__device__ __forceinline__ void cull_row_span(const CullEllipse& e, int rx0, int rx1, int ty, int W, int H, int& xa,
+                                              int& xb) {
+  xa = rx0;
+  xb = rx1;
+  if (!e.exact) return;
+  const float y_lo = (float)(ty * TILE), y_hi = (float)min(ty * TILE + TILE - 1, H - 1);
+  const float pad_y = 1e-3f + 2e-7f * (fabsf(e.py) + y_hi);
+  const float dy0 = (y_lo - e.py) - pad_y, dy1 = (y_hi - e.py) + pad_y;  // band, widened
+  // discriminants at the band edges, rounded up
+  const float disc0 = (e.A - e.det_lo * dy0 * dy0 * (1.0f - 4e-7f)) + 2e-7f * e.A;
+  const float disc1 = (e.A - e.det_lo * dy1 * dy1 * (1.0f - 4e-7f)) + 2e-7f * e.A;
+  if (!(disc0 == disc0) || !(disc1 == disc1)) return;  // NaN: keep the full span
+  float hi = -3e38f, lo = 3e38f;
+  bool any = false;
+  if (disc0 >= 0.0f) {
+    const float s = __builtin_amdgcn_sqrtf(disc0) * (1.0f + 4e-7f), bd = e.b * dy0;
+    const float m = 1e-6f * (fabsf(bd) + s) * e.inv_a;
+    hi = (s - bd) * e.inv_a + m;
+    lo = (-s - bd) * e.inv_a - m;
+    any = true;
+  }
+  if (disc1 >= 0.0f) {
+    const float s = __builtin_amdgcn_sqrtf(disc1) * (1.0f + 4e-7f), bd = e.b * dy1;
+    const float m = 1e-6f * (fabsf(bd) + s) * e.inv_a;
+    hi = fmaxf(hi, (s - bd) * e.inv_a + m);
+    lo = fminf(lo, (-s - bd) * e.inv_a - m);
+    any = true;
+  }
+  const float pad_s = 1e-3f + 1e-5f * fabsf(e.ystar);
+  if (dy0 <= e.ystar + pad_s && e.ystar - pad_s <= dy1) {
+    hi = fmaxf(hi, e.xstar);
+    any = true;
+  }
+  if (dy0 <= -e.ystar + pad_s && -e.ystar - pad_s <= dy1) {
+    lo = fminf(lo, -e.xstar);
+    any = true;
+  }
+  if (!(hi == hi) || !(lo == lo)) return;  // NaN: keep the full span
+  if (!any || hi < lo) {                    // the band misses the ellipse
+    xb = xa;
+    return;
+  }
+  // integer pixel columns inside [px + lo, px + hi], padded, clipped to the image
+  const float pad_x = 1e-3f + 2e-7f * (fabsf(e.px) + fmaxf(fabsf(hi), fabsf(lo)));
+  const float Xlo = fmaxf(ceilf(e.px + lo - pad_x), 0.0f), Xhi = fminf(floorf(e.px + hi + pad_x), (float)(W - 1));
+  if (Xhi < Xlo) {
+    xb = xa;
+    return;
+  }
+  xa = max(rx0, (int)Xlo / TILE);
+  xb = min(rx1, (int)Xhi / TILE + 1);
+  if (xb < xa) xb = xa;
+}
+
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 

@@ -51,7 +51,8 @@ struct GeometryState {
   float* cov3D;           // [P][6]
   float* rgb;             // [P][3]
   uint8_t* clamped;       // [P][3]
-  uint32_t* tiles_touched;  // [P]
+  uint32_t* tiles_touched;  // [P] instances the Gaussian emits (rect area, or the exact tile count)
+  float* cull_t2;         // [P] 2 * inflated alpha-floor threshold of the exact binning (cull_threshold)
   uint32_t* key_a;        // [P] depth keys (ping)
   uint32_t* key_b;        // [P] (pong)
   uint32_t* val_a;        // [P] Gaussian ids (ping)
@@ -62,6 +63,7 @@ struct GeometryState {
   uint32_t* radix_table;  // [256 * sort_blocks(P)]
   uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
   int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag,
+                          //      3 = instances of the reference's rect binning (== R unless OLSR_BINNING_ELLIPSE),
                           //      4 = #large-footprint Gaussians, 6 = live rows L, 7 = row-capacity overflow
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
@@ -76,6 +78,7 @@ struct GeometryState {
     g.rgb = c.take<float>(3 * P);
     g.clamped = c.take<uint8_t>(3 * P);
     g.tiles_touched = c.take<uint32_t>(P);
+    g.cull_t2 = c.take<float>(P);
     g.key_a = c.take<uint32_t>(P);
     g.key_b = c.take<uint32_t>(P);
     g.val_a = c.take<uint32_t>(P);

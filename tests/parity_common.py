@@ -36,10 +36,13 @@ def fwd_args(sc, dev=None, colors_precomp=None, cov3D_precomp=None, scale_modifi
     return a
 
 
-def run_backend(C, sc, dev=None, seed=0, tile=15, mode=0, **kw):
-    """Forward + backward through backend module C (oracle_C or the product _C).  Returns (fwd dict, grads dict)."""
+def run_backend(C, sc, dev=None, seed=0, tile=15, mode=0, binning=1, **kw):
+    """Forward + backward through backend module C (oracle_C or the product _C).  Returns (fwd dict, grads dict).
+    `binning` (product only; the oracle always bins like the reference): 1 = exact ellipse lists (the
+    product's default), 0 = the reference's bounding-square lists."""
     C.TILE = tile
     C.BWD_MODE = mode
+    C.BINNING = binning
     F = sc.F
     a = fwd_args(sc, dev, **kw)
     if F > 0:

@@ -19,32 +19,75 @@ RTOL = 1e-4
 DEV = "cuda:0"
 
 
-def _check(hip, oracle, sc, seed=0, tile=15, mode=0, **kw):
+def _tile_pairs(hip, f, sc, tile):
+    """(tile * P + Gaussian) per sorted list position, and the per-position blend flags."""
+    W, H, F, R = sc.camera.width, sc.camera.height, sc.F, f["R"]
+    hip.TILE = tile
+    pl = hip.state_field("binning", f["binning"], "point_list", R=R, F=F, dtype=torch.int32, count=R).long()
+    src = hip.state_field("binning", f["binning"], "src", R=R, F=F, dtype=torch.int32, count=R).long()
+    fl = hip.state_field("binning", f["binning"], "flags", R=R, F=F, dtype=torch.uint8, count=R)
+    nt = ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
+    rg = hip.state_field("image", f["img"], "ranges", W=W, H=H, dtype=torch.int32, count=2 * nt).view(-1, 2).long()
+    lens = rg[:, 1] - rg[:, 0]
+    assert int(lens.sum()) == R
+    tile_of = torch.repeat_interleave(torch.arange(nt, device=pl.device), lens)
+    # list positions of tile t are ranges[t]; walk them tile by tile
+    starts = torch.repeat_interleave(rg[:, 0], lens)
+    pos = starts + (torch.arange(R, device=pl.device) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens))
+    return tile_of * max(sc.P, 1) + pl[pos], fl[src[pos]], pos
+
+
+COMPOSITE_GRADS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dlanguage", "dL_ddepths")
+
+
+def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, **kw):
+    """Oracle vs the HIP library in both binning modes.
+    RECT: images, counters AND the instance lists equal the reference's bit for bit.
+    ELLIPSE (the product's default): identical images / radii / n_touched / final_T, gradients to RTOL,
+    and every tile list is the RECT list minus instances that blend nothing, in the same order."""
     fo, go = run_backend(oracle, sc, None, seed, tile, mode, **kw)
-    fg, gg = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, **kw)
+    fr, gr = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, binning=_abi.BINNING_RECT, **kw)
+    fg, gg = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, binning=_abi.BINNING_ELLIPSE, **kw)
     torch.cuda.synchronize()
     P, F = sc.P, sc.F
-    assert fg["R"] == fo["R"]
-    assert torch.equal(fg["radii"].cpu(), fo["radii"])
-    assert torch.equal(fg["n_touched"].cpu(), fo["n_touched"])
-    for k in ("color", "language", "depth", "opacity"):
-        if fo[k] is not None and fo[k].numel():
-            assert torch.equal(fg[k].cpu(), fo[k]), f"forward {k} not bit-identical (rel {rel_err(fg[k], fo[k])[0]:.2e})"
+    W, H = sc.camera.width, sc.camera.height
+    assert fr["R"] == fo["R"]
+    assert fg["R"] <= fo["R"]
+    for f_, g_, name in ((fr, gr, "rect"), (fg, gg, "ellipse")):
+        assert torch.equal(f_["radii"].cpu(), fo["radii"]), name
+        assert torch.equal(f_["n_touched"].cpu(), fo["n_touched"]), name
+        for k in ("color", "language", "depth", "opacity"):
+            if fo[k] is not None and fo[k].numel():
+                assert torch.equal(f_[k].cpu(), fo[k]), \
+                    f"{name}: forward {k} not bit-identical (rel {rel_err(f_[k], fo[k])[0]:.2e})"
+        if P:
+            hip.TILE = tile
+            ft = hip.state_field("image", f_["img"], "final_T", W=W, H=H, dtype=torch.float32, count=W * H)
+            assert torch.equal(ft.cpu(), oracle.get_field(fo["geom"], "final_T")), name
+            cnt = hip.state_field("geometry", f_["geom"], "counters", P=P, F=F, dtype=torch.int32, count=8).cpu()
+            assert int(cnt[0]) == f_["R"] and int(cnt[3]) == fo["R"], name  # [3]: the reference's num_rendered
+        for k in go:
+            if go[k].numel() and (grad_keys is None or k in grad_keys):
+                r, e = rel_err(g_[k], go[k])
+                assert r <= RTOL, f"{name}: {k}: rel {r:.2e} abs {e:.2e}"
+        if P and grad_keys is None:
+            r, _ = rel_err(g_["dL_dtau_sum"], go["dL_dtau"].double().sum(0).float())
+            assert r <= RTOL, name
     if fo["R"] > 0:
-        pl = hip.state_field("binning", fg["binning"], "point_list", R=fg["R"], F=F, dtype=torch.int32, count=fg["R"])
+        pl = hip.state_field("binning", fr["binning"], "point_list", R=fr["R"], F=F, dtype=torch.int32, count=fr["R"])
         assert torch.equal(pl.cpu(), oracle.get_field(fo["geom"], "point_list"))
-        W, H = sc.camera.width, sc.camera.height
-        nc = hip.state_field("image", fg["img"], "n_contrib", W=W, H=H, dtype=torch.int32, count=W * H)
+        nc = hip.state_field("image", fr["img"], "n_contrib", W=W, H=H, dtype=torch.int32, count=W * H)
         assert torch.equal(nc.cpu(), oracle.get_field(fo["geom"], "n_contrib"))
-        ft = hip.state_field("image", fg["img"], "final_T", W=W, H=H, dtype=torch.float32, count=W * H)
-        assert torch.equal(ft.cpu(), oracle.get_field(fo["geom"], "final_T"))
-    for k in go:
-        if go[k].numel():
-            r, e = rel_err(gg[k], go[k])
-            assert r <= RTOL, f"{k}: rel {r:.2e} abs {e:.2e}"
-    if P:
-        r, _ = rel_err(gg["dL_dtau_sum"], go["dL_dtau"].double().sum(0).float())
-        assert r <= RTOL
+        # exact lists: an order-preserving sub-list of the reference's that keeps every blending instance
+        kr, flr, _ = _tile_pairs(hip, fr, sc, tile)
+        if fg["R"] > 0:
+            ke, fle, _ = _tile_pairs(hip, fg, sc, tile)
+            keep = torch.isin(kr, ke)
+            assert int(keep.sum()) == ke.numel() and torch.equal(kr[keep], ke)
+            assert torch.equal(flr[keep], fle)
+        else:
+            keep = torch.zeros_like(kr, dtype=torch.bool)
+        assert int((flr[~keep] != 0).sum()) == 0
     oracle.release(fo["geom"])
     return fg, gg
 
@@ -119,6 +162,28 @@ def test_huge_and_tiny_gaussians(hip, oracle):
     _check(hip, oracle, sc, seed=7)
     sc = make_scene(6000, 120, 90, 15, seed=62, scale_mult=0.05)
     _check(hip, oracle, sc, seed=8)
+
+
+def test_needles_and_faint_splats_exact_binning(hip, oracle):
+    """Stress of the exact tile lists: 1000:1 needles at every orientation (the alpha-floor ellipse is a
+    sliver of the reference's bounding square) and opacities around the 1/255 floor.  _check asserts that
+    no instance that blends a pixel under the reference binning is missing from the exact lists.
+    For the needles only the composite's own gradients are compared: behind them the backward of the 2D
+    covariance inverse (CR/backward.cu:213-236) cancels terms of order 1e8 down to order 1e3, which turns
+    the 1e-7 summation-order noise of ANY implementation (the reference's float atomics included) into
+    errors of tens of percent in dL_dmeans3D / dL_dscales — there is no reproducible value to match."""
+    sc = make_scene(4000, 240, 165, 15, seed=64)
+    sc.scales[:, 0] *= 25.0
+    sc.scales[:, 1] *= 0.04
+    _check(hip, oracle, sc, seed=10, grad_keys=COMPOSITE_GRADS)
+    sc = make_scene(4000, 240, 165, 15, seed=65, scale_mult=3.0)
+    g = torch.Generator().manual_seed(65)
+    sc.opacities[:] = (torch.rand(sc.P, 1, generator=g) * 0.02).reshape(sc.opacities.shape)  # 0 .. 5/255
+    _check(hip, oracle, sc, seed=11, mode=_abi.BWD_EXACT)
+    cam = default_camera(240, 165, yaw_deg=-14.0, tx=-0.3)
+    sc = make_scene(3000, 240, 165, 15, seed=66, camera=cam, scale_mult=6.0)
+    sc.scales[:, 2] *= 0.02
+    _check(hip, oracle, sc, seed=12, tile=16, grad_keys=COMPOSITE_GRADS)
 
 
 def test_transparent_scene_walks_whole_lists(hip, oracle):
