@@ -585,24 +585,28 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
 // Rank sort (len <= a few thousand): rank = #tiles heavier, ties by index -> a permutation.
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
                                                          int ntiles) {
-  const int x = blockIdx.x;  // XCD
+  extern __shared__ u32 s_work[];  // the chunk's weights
+  const int x = blockIdx.x;        // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   const int len = q + (x < r ? 1 : 0);
-  for (int i = threadIdx.x; i < len; i += blockDim.x) {
-    const u32 wi = work[start + i];
-    int rank = 0;
-    for (int j = 0; j < len; ++j) {
-      const u32 wj = work[start + j];
-      rank += (wj > wi) || (wj == wi && j < i);
-    }
-    order[start + rank] = (u32)(start + i);
+  for (int j = threadIdx.x; j < len; j += blockDim.x) s_work[j] = work[start + j];
+  __syncthreads();
+  const int i = blockIdx.y * blockDim.x + threadIdx.x;  // one tile per thread
+  if (i >= len) return;
+  const u32 wi = s_work[i];
+  int rank = 0;
+  for (int j = 0; j < len; ++j) {  // wave-uniform LDS broadcast reads
+    const u32 wj = s_work[j];
+    rank += (wj > wi) || (wj == wi && j < i);
   }
+  order[start + rank] = (u32)(start + i);
 }
 
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st) {
   if (ntiles <= 0) return;
-  tile_order_kernel<<<8, 256, 0, st>>>(tile_work, tile_order, ntiles);
+  const int len = (ntiles >> 3) + 1;
+  tile_order_kernel<<<dim3(8, (len + 255) / 256), 256, sizeof(u32) * (size_t)len, st>>>(tile_work, tile_order, ntiles);
 }
 
 }  // namespace olsr

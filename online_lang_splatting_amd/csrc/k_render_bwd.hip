@@ -14,8 +14,14 @@
 //     entries is staged into LDS;
 //   * the per-splat reduction never leaves the wave and never touches LDS: gfx950's
 //     v_permlane32_swap / v_permlane16_swap fold the lane dimension for two values per swap,
-//     DPP row rotations finish inside rows of 16 (10 instructions per 4 values), and the wave
-//     writes its own partial-gradient row (instance, slot) with one coalesced 64..192-byte store;
+//     DPP row rotations finish inside rows of 16 (10 instructions per 4 values).  The totals are
+//     not gathered into consecutive lanes: the lane that already holds total j stores row element
+//     j (12 lanes for the 10 reference-mode values), so the row costs one store and no permute;
+//   * the kernel is VALU-issue bound, so the per-visit instruction count is what is tuned: the
+//     skip-dependent values are three masked factors (G, dL_dalpha, alpha*T) instead of ~30
+//     zero-initialised registers, the language dot product runs on packed fp32 FMAs, 1/(1-alpha)
+//     is v_rcp + one Newton step, and the reference-mode language row (tile rank 0 only) is ONE
+//     scalar broadcast times a per-lane constant;
 //   * no float atomics: rows are compacted in emission order (rowbase = exclusive scan of
 //     popcount(flags)), so the per-Gaussian reduction (k_preprocess_bwd.hip) streams one dense,
 //     contiguous run of rows per Gaussian and the gradients are bit-reproducible from run to run.
@@ -62,8 +68,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   constexpr int ROW = grad_row(F);
   constexpr bool REF = (MODE == OLSR_BWD_REFERENCE);
   constexpr int NV = REF ? 10 : 10 + F;  // values that go through the wave reduction
-  constexpr int NG = (NV + 3) / 4;       // groups of four values reduced together (wave_reduce4)
+  constexpr int NG4_ = NV / 4;           // groups of four values reduced together (wave_reduce4)
+  constexpr int REM = (NV % 4 == 3) ? 0 : NV % 4;  // 1-2 left-over values: wave_reduce2
+  constexpr int NG4 = NG4_ + ((NV % 4 == 3) ? 1 : 0);  // (three left over: a four-tree with one zero)
+  constexpr int NVP = 4 * NG4 + (REM ? 2 : 0);    // sum[] entries incl. zero padding
   constexpr int FX = (F > 0) ? F : 1;
+  constexpr int F2 = (F + 1) / 2;        // packed pairs of language channels
+  constexpr int F2X = (F2 > 0) ? F2 : 1;
   constexpr int B = BWD_BATCH;
   static_assert(ROW <= 64, "one lane per row element");
 
@@ -118,6 +129,39 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   float A_f = 0.f, D_last = 0.f, dLf[FX];
 #pragma unroll
   for (int ch = 0; ch < FX; ++ch) dLf[ch] = (F > 0 && inside) ? dL_dpixels_lang[ch * HW + pix] : 0.f;
+  v2f dLf2[F2X];  // the same cotangents in pairs, for packed fp32 math
+#pragma unroll
+  for (int k2 = 0; k2 < F2X; ++k2) {
+    dLf2[k2].x = (2 * k2 < F) ? dLf[(2 * k2 < F) ? 2 * k2 : 0] : 0.f;
+    dLf2[k2].y = (2 * k2 + 1 < F) ? dLf[(2 * k2 + 1 < F) ? 2 * k2 + 1 : 0] : 0.f;
+  }
+
+  // ---- which row element this lane stores ----------------------------------------------------
+  // wave_reduce4 leaves the totals of group g in the four 16-lane rows of its result (row r holds
+  // value perm(r)), wave_reduce2 in rows 1 and 3.  The lane with (lane & 15) == g stores group g's
+  // total of its row; the remaining row elements (reference mode: the language channels) are dealt
+  // to the free lanes in ascending order.
+  const int lg = lane & 15, lr = lane >> 4;
+  int role = -1;
+  if (lg < NG4) role = 4 * lg + (((lr & 1) << 1) | (lr >> 1));
+  if (REM > 0 && lg == NG4 && (lr & 1)) role = 4 * NG4 + (lr >> 1);
+  if (role >= NV) role = -1;
+  bool lang_lane = false;
+  float dLf0_lane = 0.f;
+  if constexpr (REF && F > 0) {
+    const u64 freem = ballot(role < 0);
+    const int nth = (int)__popcll(freem & ((1ull << lane) - 1ull));
+    if (role < 0 && nth < F) {
+      role = 10 + nth;
+      lang_lane = true;
+    }
+#pragma unroll
+    for (int ch = 0; ch < F; ++ch) {
+      const float v = lane_read(dLf[ch], 0);  // the tile's rank-0 pixel (wave 0, lane 0)
+      if (lang_lane && role == 10 + ch) dLf0_lane = v;
+    }
+    if (w != 0) dLf0_lane = 0.f;
+  }
 
   // entries at list positions >= max(last_contributor) are skipped by every pixel of the tile
   int kmax = last_contributor;
@@ -149,6 +193,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
           fr[3] = depths[gid];
 #pragma unroll
           for (int ch = 0; ch < F; ++ch) fr[4 + ch] = lang[(size_t)gid * F + ch];
+#pragma unroll
+          for (int ch = 4 + F; ch < FR; ++ch) fr[ch] = 0.f;  // the packed dot product reads the padding
         }
       }
     }
@@ -164,8 +210,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
       float D_cur = 0.f;
       if constexpr (F > 0) {
 #pragma clang fp contract(fast)
+        const v2f* fr2 = reinterpret_cast<const v2f*>(fr + 4);
+        v2f acc2 = {0.f, 0.f};
 #pragma unroll
-        for (int ch = 0; ch < F; ++ch) D_cur += fr[4 + ch] * dLf[ch];
+        for (int k = 0; k < F2; ++k) acc2 += fr2[k] * dLf2[k];
+        D_cur = acc2.x + acc2.y;
       }
       if (REF && !mine) {
         // every pixel of this slot skips, but the tile does not: only the unguarded language
@@ -191,15 +240,12 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
       const float alpha = fminf_ref(0.99f, co.w * G);
       skip |= alpha < 1.0f / 255.0f;
 
-      float sum[4 * NG];
-#pragma unroll
-      for (int v = 0; v < 4 * NG; ++v) sum[v] = 0.f;
-      float lang0[FX];  // REF: rank 0's language partials (lane 0 of wave 0)
-#pragma unroll
-      for (int ch = 0; ch < FX; ++ch) lang0[ch] = 0.f;
-
       // -- value path: FMA contraction allowed (rounding differs from the oracle by ~1 ulp per
-      //    operation; no decision depends on these values)
+      //    operation; no decision depends on these values).  Everything a skipping pixel must not
+      //    contribute hangs off three factors that are zero for it.
+      float f_dcd = 0.f;  // alpha * T        (dchannel_dcolor)
+      float f_dLa = 0.f;  // dL_dalpha
+      float sum[NVP];
       {
 #pragma clang fp contract(fast)
         const float la = last_alpha, one_m_la = 1.f - last_alpha;
@@ -208,9 +254,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
           D_last = D_cur;
         }
         if (!skip) {
-          const float one_m_alpha = 1.f - alpha;
-          T = T / one_m_alpha;
-          const float dchannel_dcolor = alpha * T;
+          const float one_m_alpha = 1.f - alpha;  // in [0.01, 1]
+          float inv = __builtin_amdgcn_rcpf(one_m_alpha);
+          inv = __builtin_fmaf(__builtin_fmaf(-one_m_alpha, inv, 1.0f), inv, inv);
+          T = T * inv;
           float dL_dalpha = 0.0f;
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
@@ -232,61 +279,61 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
           }
           dL_dalpha *= T;
           last_alpha = alpha;
-          if (has_bg) dL_dalpha += (-T_final / one_m_alpha) * bg_dot;
-
-          if (surv) {
-            const float dL_dG = co.w * dL_dalpha;
-            const float gdx = G * dx;
-            const float gdy = G * dy;
-            const float dG_ddelx = -gdx * co.x - gdy * co.y;
-            const float dG_ddely = -gdy * co.z - gdx * co.y;
-            sum[0] = dL_dG * dG_ddelx * ddelx_dx;
-            sum[1] = dL_dG * dG_ddely * ddely_dy;
-            sum[2] = -0.5f * gdx * dx * dL_dG;
-            sum[3] = -0.5f * gdx * dy * dL_dG;
-            sum[4] = -0.5f * gdy * dy * dL_dG;
-            sum[5] = G * dL_dalpha;
-            sum[6] = dchannel_dcolor * dLc[0];
-            sum[7] = dchannel_dcolor * dLc[1];
-            sum[8] = dchannel_dcolor * dLc[2];
-            sum[9] = dchannel_dcolor * dLd;
-            if constexpr (!REF && F > 0) {
+          if (has_bg) dL_dalpha += (-T_final * inv) * bg_dot;
+          f_dcd = alpha * T;
+          f_dLa = dL_dalpha;
+        }
+        // reference mode: only the ranks that survive its 225-lane tree contribute to these ten sums
+        const float Gm = (skip || !surv) ? 0.f : G;  // (G of a skipping pixel may be huge: keep it out of products)
+        const float s_dLa = surv ? f_dLa : 0.f;
+        const float s_dcd = surv ? f_dcd : 0.f;
+        const float dL_dG = co.w * s_dLa;
+        const float gdx = Gm * dx;
+        const float gdy = Gm * dy;
+        const float dG_ddelx = -gdx * co.x - gdy * co.y;
+        const float dG_ddely = -gdy * co.z - gdx * co.y;
+        sum[0] = dL_dG * dG_ddelx * ddelx_dx;
+        sum[1] = dL_dG * dG_ddely * ddely_dy;
+        sum[2] = -0.5f * gdx * dx * dL_dG;
+        sum[3] = -0.5f * gdx * dy * dL_dG;
+        sum[4] = -0.5f * gdy * dy * dL_dG;
+        sum[5] = Gm * s_dLa;
+        sum[6] = s_dcd * dLc[0];
+        sum[7] = s_dcd * dLc[1];
+        sum[8] = s_dcd * dLc[2];
+        sum[9] = s_dcd * dLd;
+        if constexpr (!REF && F > 0) {
 #pragma unroll
-              for (int ch = 0; ch < F; ++ch) sum[10 + ch] = dchannel_dcolor * dLf[ch];
-            }
-          }
-          if constexpr (REF && F > 0) {
-#pragma unroll
-            for (int ch = 0; ch < F; ++ch) lang0[ch] = dchannel_dcolor * dLf[ch];
+          for (int k2 = 0; k2 < F2; ++k2) {
+            const v2f pr = dLf2[k2] * s_dcd;
+            sum[10 + 2 * k2] = pr.x;
+            if (10 + 2 * k2 + 1 < NVP) sum[10 + 2 * k2 + 1] = pr.y;
           }
         }
+#pragma unroll
+        for (int v = NV; v < NVP; ++v) sum[v] = 0.f;
       }
 
-      // Wave reduction, four values per permlane-swap tree (olsr_device.h); the totals of group g sit
-      // in the four 16-lane rows of red[g].  Lane j (< NV) then fetches value j into row order.
+      // Wave reduction (olsr_device.h): four values per permlane-swap tree, the 1-2 left over in a
+      // two-value tree.  Total j ends up in the lanes whose role is j (role_of below); that lane stores it.
       float rowval = 0.f;
-      {
-        const int src_lane = reduce4_lane(lane & 3);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          const float red = wave_reduce4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
-          const float pulled = __shfl(red, src_lane);
-          rowval = ((lane >> 2) == g) ? pulled : rowval;
-        }
+      for (int g = 0; g < NG4; ++g) {
+        const float red = wave_reduce4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
+        rowval = (lg == g) ? red : rowval;
       }
-      if (lane >= NV) rowval = 0.f;
+      if constexpr (REM > 0) {
+        const float red = wave_reduce2(sum[4 * NG4], REM > 1 ? sum[4 * NG4 + 1] : 0.f);
+        rowval = (lg == NG4) ? red : rowval;
+      }
       if constexpr (REF && F > 0) {
-        // language gradients come from tile rank 0 only (lane 0 of wave 0): broadcast and place
-        if (w == 0) {
-#pragma unroll
-          for (int ch = 0; ch < F; ++ch) {
-            const float v = lane_read(lang0[ch], 0);
-            rowval = (lane == 10 + ch) ? v : rowval;
-          }
-        }
+        // language gradients come from tile rank 0 only (lane 0 of wave 0): one broadcast, times the
+        // lane's own dL_dF[role - 10] of that pixel (zero in every other wave)
+        const float dcd0 = lane_read(f_dcd, 0);
+        rowval = lang_lane ? dcd0 * dLf0_lane : rowval;
       }
       // compact row index: rows of an instance are consecutive, one per set slot bit
-      if (lane < ROW) rows[((size_t)s_row[i] + (u32)__popc(fl & ((1u << w) - 1u))) * ROW + lane] = rowval;
+      if (role >= 0) rows[((size_t)s_row[i] + (u32)__popc(fl & ((1u << w) - 1u))) * ROW + role] = rowval;
     }
   }
 }

@@ -59,6 +59,19 @@ __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d
   t += dpp_mov<0x121>(t);  // row_ror:1
   return t;
 }
+// Two values: one swap folds the halves (lanes 0-31 carry a, 32-63 carry b), four row rotations and
+// one row_bcast:15 into rows 1 and 3 finish.  On return row 1 holds sum(a), row 3 sum(b).
+__device__ __forceinline__ float wave_reduce2(float a, float b) {
+  float t = swap32_add(a, b);
+  t += dpp_mov<0x128>(t);  // row_ror:8
+  t += dpp_mov<0x124>(t);  // row_ror:4
+  t += dpp_mov<0x122>(t);  // row_ror:2
+  t += dpp_mov<0x121>(t);  // row_ror:1
+  // row_bcast:15, rows 1 and 3 only: lane 15 of the previous row (a full row sum) is added
+  t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x142, 0xa, 0xf, false));
+  return t;
+}
+typedef float v2f __attribute__((ext_vector_type(2)));
 // lane that holds value i (0..3) of a wave_reduce4 result: rows are ordered a, c, b, d
 __device__ __forceinline__ int reduce4_lane(int i) { return 16 * (((i & 1) << 1) | ((i >> 1) & 1)); }
 __device__ __forceinline__ float lane_read(float v, int lane) {
