@@ -65,9 +65,11 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   u32 my_work = 0;  // live (instance, slot) pairs flushed by this thread
   float T = 1.0f;
   u32 last_contributor = 0;
-  float acc[NA];
+  // r g b depth lang[F] in pairs: the accumulation runs on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32)
+  constexpr int NA2 = (NA + 1) / 2;
+  v2f acc2[NA2];
 #pragma unroll
-  for (int k = 0; k < NA; ++k) acc[k] = 0.0f;
+  for (int k = 0; k < NA2; ++k) acc2[k] = v2f{0.0f, 0.0f};
 
   for (int base = 0; base < n; base += B) {
     // also the barrier that separates the previous batch's flush from this batch's staging
@@ -100,6 +102,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
           fr[3] = depths[gid];
 #pragma unroll
           for (int ch = 0; ch < F; ++ch) fr[4 + ch] = lang[(size_t)gid * F + ch];
+#pragma unroll
+          for (int ch = 4 + F; ch < FR; ++ch) fr[ch] = 0.f;  // read by the packed accumulation
         }
       }
     }
@@ -126,9 +130,12 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
         const bool contrib = ok && !term;
         done = done || term;
         if (contrib) {
-          const float* fr = &s_feat[j * FR];
+          // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
+          // reference's expression (CR/forward.cu:479-484), and what the oracle restates
+          const v2f* fr2 = reinterpret_cast<const v2f*>(&s_feat[j * FR]);
+          const v2f a2 = {alpha, alpha}, T2 = {T, T};
 #pragma unroll
-          for (int k = 0; k < NA; ++k) acc[k] += fr[k] * alpha * T;
+          for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
           T = test_T;
           last_contributor = (u32)(base + j + 1);
         }
@@ -168,6 +175,12 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
     const u32 p = (u32)W * (u32)py + (u32)px;
     final_T[p] = T;
     n_contrib[p] = last_contributor;
+    float acc[2 * NA2];
+#pragma unroll
+    for (int k = 0; k < NA2; ++k) {
+      acc[2 * k] = acc2[k].x;
+      acc[2 * k + 1] = acc2[k].y;
+    }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) out_color[ch * HW + p] = acc[ch] + T * bg[ch];
     out_depth[p] = acc[3];

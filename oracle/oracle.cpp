@@ -16,7 +16,8 @@
 //   DGR = /root/reference/submodules/diff-gaussian-rasterization
 //
 // Numerics: strict IEEE fp32, built with -ffp-contract=off (no implicit FMA), in the
-// reference's source operation order.  glm matrix products follow glm's left-to-right
+// reference's source operation order; the one FMA nvcc's default contraction makes on the
+// forward's hot accumulation is written explicitly (see forward()).  glm matrix products follow glm's left-to-right
 // accumulation.  `exp` is the one libm call on a decision path; the CUDA libm bits are
 // unobtainable here, so the oracle pins exp to a fully specified fp32 routine
 // (oracle_expf below, Cephes-style, <= 1 ulp typical) that the HIP kernels restate
@@ -397,9 +398,12 @@ static void render_forward(const olsr_scene& s, State& st, float* out_color, flo
           if (alpha < 1.0f / 255.0f) continue;
           const float test_T = T * (1 - alpha);
           if (test_T < 0.0001f) break;  // done = true
-          for (int ch = 0; ch < 3; ch++) C[ch] += features[(size_t)id * 3 + ch] * alpha * T;
-          for (int ch = 0; ch < F; ch++) L[ch] += lang[(size_t)id * F + ch] * alpha * T;
-          D += st.depths[id] * alpha * T;
+          // `C += f * alpha * T` (CR/forward.cu:479-484): the reference is built by nvcc with its default
+          // --fmad=true, which contracts the last product into the sum, fma(f * alpha, T, C).  Written
+          // out because this file is built with -ffp-contract=off.
+          for (int ch = 0; ch < 3; ch++) C[ch] = std::fmaf(features[(size_t)id * 3 + ch] * alpha, T, C[ch]);
+          for (int ch = 0; ch < F; ch++) L[ch] = std::fmaf(lang[(size_t)id * F + ch] * alpha, T, L[ch]);
+          D = std::fmaf(st.depths[id] * alpha, T, D);
           if (test_T > 0.5f) {
 #pragma omp atomic
             n_touched[id] += 1;
