@@ -12,7 +12,7 @@ gradient buffer.  With N > 1 (one process per GPU, torch.distributed over RCCL) 
 renders its own viewpoint of the same Gaussians per step and the step ends with the one
 all-reduce of the shared-Gaussian gradient buffer (frame sharding, weak scaling).
 
-Frames are independent (the views of a mapping iteration), so `--streams S` (default 3) keeps S
+Frames are independent (the views of a mapping iteration), so `--streams S` (default 4) keeps S
 frames in flight on S HIP streams with S workspaces (frame k on stream k mod S): the small binning
 kernels of one frame overlap the compositing kernels of another, and with N > 1 the all-reduce of
 one frame overlaps the compute of the next.  The timed region still issues exactly K steps.
@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--mode", default="reference", choices=["reference", "exact"])
     ap.add_argument("--binning", default="ellipse", choices=["ellipse", "rect"],
                     help="ellipse: exact tile lists (default); rect: the reference's bounding-square lists")
-    ap.add_argument("--streams", type=int, default=3, help="frames in flight per GPU (workspaces on separate HIP streams)")
+    ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (workspaces on separate HIP streams)")
     ap.add_argument("--isolated-steps", type=int, default=20, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
 

@@ -12,7 +12,8 @@
 //   * inside a batch the four waves run free: no barrier per splat, a wave leaves the batch as
 //     soon as its 64 pixels are saturated (64-bit ballots), the workgroup stops staging when
 //     all four are;
-//   * n_touched is counted with per-wave popcounts and ONE integer atomic per (splat, batch);
+//   * n_touched is counted with per-wave popcounts (each wave owns one byte of the splat's LDS
+//     record: no LDS atomics) and ONE global integer atomic per (splat, batch);
 //   * the kernel records, per (tile, splat) instance, WHICH 64-pixel slots blended it
 //     (flags[] bit w, indexed by emission position).  The backward composite visits only those
 //     (instance, slot) pairs, and "flags != 0" is exactly the tile-wide
@@ -45,8 +46,9 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
   __shared__ u32 s_id[B];
   __shared__ u32 s_src[B];
-  __shared__ u32 s_flag[B];
-  __shared__ u32 s_touch[B];
+  // per staged splat, one byte per wave: bit 7 = the wave's slot blended it, bits 0-6 = how many of its
+  // pixels counted it as touched (<= 64); each wave writes only its own byte
+  __shared__ u32 s_hit[B];
   __shared__ u32 s_work;
 
   const int tile_id = xcd_remap((int)blockIdx.x, ntiles);
@@ -84,8 +86,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
         if (tid < B) {
           s_id[e] = gid;
           s_src[e] = u;
-          s_flag[e] = 0;
-          s_touch[e] = 0;
+          s_hit[e] = 0;
           const float2 m = reinterpret_cast<const float2*>(means2D)[gid];
           const float4 c = reinterpret_cast<const float4*>(conic_opacity)[gid];
           // alpha = o * exp(power) can only reach 1/255 if power >= -ln(255 o).  Keep a margin far
@@ -142,20 +143,19 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
         const u64 cb = ballot(contrib);
         if (cb != 0ull) {
           const u32 tc = (u32)__popcll(ballot(contrib && test_T > 0.5f));
-          if ((tid & 63) == 0) {
-            atomicOr(&s_flag[j], 1u << w);
-            if (tc) atomicAdd(&s_touch[j], tc);
-          }
+          if ((tid & 63) == 0) reinterpret_cast<uint8_t*>(s_hit)[4 * j + w] = (uint8_t)(0x80u | tc);
         }
         if (wave_all(done)) break;
       }
     }
     __syncthreads();
     if (tid < cnt) {
-      const u32 fl = s_flag[tid];
+      const u32 hit = s_hit[tid];
+      const u32 fl = ((hit >> 7) & 1u) | ((hit >> 14) & 2u) | ((hit >> 21) & 4u) | ((hit >> 28) & 8u);
       if (fl) flags[s_src[tid]] = (uint8_t)fl;
       my_work += (u32)__popc(fl);
-      const u32 tc = s_touch[tid];
+      // tc of a wave is <= 64 = 0x40: with bit 7 set a full wave reads 0xC0, so mask 0x7F keeps all 7 bits
+      const u32 tc = (hit & 0x7Fu) + ((hit >> 8) & 0x7Fu) + ((hit >> 16) & 0x7Fu) + ((hit >> 24) & 0x7Fu);
       if (tc) atomicAdd(&n_touched[s_id[tid]], (int)tc);
     }
   }
