@@ -40,7 +40,10 @@ for k in sorted(set(fetch) | set(write)):
 json.dump(dict(tag=tag, formula="(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch (MI355X_MICROARCH.md HBM section)",
                kernels=out), open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "stats", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
-if os.path.exists(os.path.join(src, "bench.json")):
-    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+if os.path.exists(os.path.join(src, "stats1", "s_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "stats1", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_1_in_flight.csv"))
+for name in ("bench", "bench_cfg1", "bench_cfg2", "bench_cfg5"):
+    if os.path.exists(os.path.join(src, name + ".json")) and os.path.getsize(os.path.join(src, name + ".json")):
+        shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_us"])[:12]:
     print(f"{k:40s} {v['avg_us']:9.2f} us  traffic {v['traffic_bytes']/1e6:9.1f} MB")
