@@ -318,108 +318,107 @@ void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, in
 }
 
 // ------------------------------------------------------------------------------- emission
-// duplicateWithKeys (CR/rasterizer_impl.cu:70-111), one thread per depth rank.  The depth half
-// of the reference's key is implied by the emission order; only the tile id is written.
-constexpr u32 EMIT_BIG = 32;  // instances: above this the whole wave writes the Gaussian's keys
+// duplicateWithKeys (CR/rasterizer_impl.cu:70-111).  The depth half of the reference's key is implied
+// by the emission order; only the tile id is written.
+//   emit_kernel      one thread per depth rank; a Gaussian with <= EMIT_BIG instances is written by its
+//                    lane (consecutive ranks own adjacent output runs), larger ones go to a work list
+//                    (one aggregated atomic per wave; the list order influences no result);
+//   emit_big_kernel  persistent grid, one wave per listed Gaussian: near splats cover hundreds to
+//                    thousands of tiles and cluster at the front of the depth order, so they are dealt
+//                    to all waves of the chip and written with coalesced stores.
+constexpr u32 EMIT_BIG = 32;
+constexpr int EMIT_BIG_BLOCKS = 512;
+constexpr int EMIT_THREADS = 1024;  // one list atomic per 1024 Gaussians
 
 template <int TILE>
-__global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict__ order,
-                                                   const u32* __restrict__ offsets,
-                                                   const u32* __restrict__ tiles_touched,
-                                                   const float* __restrict__ means2D, const int32_t* __restrict__ radii,
-                                                   const float* __restrict__ conic_opacity,
-                                                   const float* __restrict__ cull_t2, int ellipse, int W, int H,
-                                                   int gx, int gy, const int32_t* __restrict__ counters,
-                                                   u32* __restrict__ keys, u32* __restrict__ inst_gid,
-                                                   u32* __restrict__ inst_start) {
+__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(int P, const u32* __restrict__ order,
+                                                            const u32* __restrict__ offsets,
+                                                            const float4* __restrict__ emit_rec, int ellipse, int W,
+                                                            int H, int gx, int gy, int32_t* __restrict__ counters,
+                                                            u32* __restrict__ keys, u32* __restrict__ inst_gid,
+                                                            u32* __restrict__ inst_start,
+                                                            uint4* __restrict__ big_list) {
   if (counters[2] != 0) return;  // overflow: nothing is emitted (uniform)
-  const int lane = threadIdx.x & 63;
-  // Depth ranks are dealt round-robin to the waves (wave v takes ranks v, v + NW, ...): the nearest
-  // Gaussians are the largest, and contiguous ranks would put 64 of them — each one a serial
-  // whole-wave job below — into the same few waves while the rest of the grid idles.
-  const int nw = (int)(gridDim.x * (blockDim.x >> 6));
-  const int wv = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const int r = lane * nw + wv;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
   u32 g = 0, n = 0, off = 0;
-  Rect rc = {0, 0, 0, 0};
-  float mx = 0.f, my = 0.f;
-  int rad = 0;
   if (r < P) {
     g = order[r];
-    rad = radii[g];
-    if (rad > 0) {
-      n = tiles_touched[g];
-      off = offsets[r] - n;
+    // offsets is the inclusive scan of tiles_touched in depth order: both neighbours are coalesced reads
+    const u32 incl = offsets[r];
+    const u32 prev = (r > 0) ? offsets[r - 1] : 0u;
+    n = incl - prev;  // == tiles_touched[g]; 0 for culled Gaussians, whose record is stale
+    off = prev;
+    if (n > 0) {
       inst_start[g] = off;
-      mx = means2D[2 * (size_t)g];
-      my = means2D[2 * (size_t)g + 1];
-      rc = get_rect<TILE>(mx, my, rad, gx, gy);
-    }
-  }
-  if (!ellipse) {
-    if (n > 0 && n <= EMIT_BIG) {
-      u32 o = off;
-      for (int y = rc.y0; y < rc.y1; y++)
-        for (int x = rc.x0; x < rc.x1; x++) {
-          keys[o] = (u32)(y * gx + x);
-          inst_gid[o] = g;
-          o++;
+      if (n <= EMIT_BIG) {
+        const float4 r0 = emit_rec[2 * (size_t)g], r1 = emit_rec[2 * (size_t)g + 1];
+        const int rad = __float_as_int(r1.z);
+        const Rect rc = get_rect<TILE>(r0.x, r0.y, rad, gx, gy);
+        u32 o = off;
+        if (!ellipse) {
+          for (int y = rc.y0; y < rc.y1; y++)
+            for (int x = rc.x0; x < rc.x1; x++) {
+              keys[o] = (u32)(y * gx + x);
+              inst_gid[o] = g;
+              o++;
+            }
+        } else {
+          // exact binning: the same row spans preprocess counted (same function, same inputs)
+          const CullEllipse e = cull_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rad);
+          int ya, yb;
+          cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
+          for (int y = ya; y < yb; y++) {
+            int xa, xb;
+            cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
+            for (int x = xa; x < xb; x++) {
+              keys[o] = (u32)(y * gx + x);
+              inst_gid[o] = g;
+              o++;
+            }
+          }
         }
+      }
     }
-    // near splats cover hundreds of tiles: the wave writes those runs together, coalesced
-    u64 big = ballot(n > EMIT_BIG);
-    while (big) {
-      const int sl = __builtin_ctzll(big);
-      big &= big - 1;
-      const u32 bn = __shfl(n, sl), boff = __shfl(off, sl), bg = __shfl(g, sl);
-      const int x0 = __shfl(rc.x0, sl), y0 = __shfl(rc.y0, sl), x1 = __shfl(rc.x1, sl);
-      const u32 wrect = (u32)(x1 - x0);
-      for (u32 t = (u32)lane; t < bn; t += 64) {
+  }
+  const bool is_big = n > EMIT_BIG;
+  const u32 slot = block_list_slot(is_big, &counters[5]);
+  if (is_big) big_list[slot] = make_uint4(g, off, n, 0u);
+}
+
+template <int TILE>
+__global__ __launch_bounds__(256) void emit_big_kernel(const uint4* __restrict__ big_list,
+                                                       const float4* __restrict__ emit_rec, int ellipse, int W, int H,
+                                                       int gx, int gy, const int32_t* __restrict__ counters,
+                                                       u32* __restrict__ keys, u32* __restrict__ inst_gid) {
+  if (counters[2] != 0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+  const int count = counters[5];
+  for (int item = wave; item < count; item += nwaves) {
+    const uint4 it = big_list[item];
+    const u32 g = it.x, off = it.y, n = it.z;
+    const float4 r0 = emit_rec[2 * (size_t)g], r1 = emit_rec[2 * (size_t)g + 1];
+    const int rad = __float_as_int(r1.z);
+    const Rect rc = get_rect<TILE>(r0.x, r0.y, rad, gx, gy);
+    if (!ellipse) {
+      const u32 wrect = (u32)(rc.x1 - rc.x0);
+      for (u32 t = (u32)lane; t < n; t += 64) {
         const u32 yy = t / wrect, xx = t - yy * wrect;
-        keys[boff + t] = (u32)((y0 + (int)yy) * gx + (x0 + (int)xx));
-        inst_gid[boff + t] = bg;
+        keys[off + t] = (u32)((rc.y0 + (int)yy) * gx + (rc.x0 + (int)xx));
+        inst_gid[off + t] = g;
       }
+      continue;
     }
-    return;
-  }
-  // exact binning: the same row spans preprocess counted (same function, same inputs)
-  float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
-  float t2 = -1.f;
-  if (n > 0) {
-    co = reinterpret_cast<const float4*>(conic_opacity)[g];
-    t2 = cull_t2[g];
-  }
-  if (n > 0 && n <= EMIT_BIG) {
-    const CullEllipse e = cull_setup(mx, my, co.x, co.y, co.z, t2, rad);
-    u32 o = off;
-    int ya, yb;
-    cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
-    for (int y = ya; y < yb; y++) {
-      int xa, xb;
-      cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
-      for (int x = xa; x < xb; x++) {
-        keys[o] = (u32)(y * gx + x);
-        inst_gid[o] = g;
-        o++;
-      }
-    }
-  }
-  u64 big = ballot(n > EMIT_BIG);
-  while (big) {
-    const int sl = __builtin_ctzll(big);
-    big &= big - 1;
-    const u32 boff = __shfl(off, sl), bg = __shfl(g, sl);
-    const int x0 = __shfl(rc.x0, sl), x1 = __shfl(rc.x1, sl);
-    int y0 = __shfl(rc.y0, sl), y1 = __shfl(rc.y1, sl);
-    const CullEllipse e = cull_setup(__shfl(mx, sl), __shfl(my, sl), __shfl(co.x, sl), __shfl(co.y, sl),
-                                     __shfl(co.z, sl), __shfl(t2, sl), __shfl(rad, sl));
-    cull_rows<TILE>(e, y0, y1, y0, y1);
+    const CullEllipse e = cull_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rad);
+    int y0, y1;
+    cull_rows<TILE>(e, rc.y0, rc.y1, y0, y1);
     // lane l evaluates rows y0 + l, y0 + l + 64, ...; a wave scan turns the spans into offsets
     u32 run = 0;
     for (int yb = y0; yb < y1; yb += 64) {
       const int y = yb + lane;
       int xa = 0, xb = 0;
-      if (y < y1) cull_row_span<TILE>(e, x0, x1, y, W, H, xa, xb);
+      if (y < y1) cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
       const u32 cnt = (u32)(xb - xa);
       u32 incl = cnt;
 #pragma unroll
@@ -434,8 +433,8 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict_
         const u32 c_r = __shfl(cnt, rr), e_r = __shfl(excl, rr);
         const int xa_r = __shfl(xa, rr);
         for (u32 t = (u32)lane; t < c_r; t += 64) {
-          keys[boff + run + e_r + t] = (u32)((yb + rr) * gx + xa_r + (int)t);
-          inst_gid[boff + run + e_r + t] = bg;
+          keys[off + run + e_r + t] = (u32)((yb + rr) * gx + xa_r + (int)t);
+          inst_gid[off + run + e_r + t] = g;
         }
       }
       run += total;
@@ -445,17 +444,21 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const u32* __restrict_
 
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
                  const BinningState& b, hipStream_t st) {
+  (void)radii;
   if (s.P <= 0) return;
-  const int nb = (s.P + 255) / 256;
+  const int nb = (s.P + EMIT_THREADS - 1) / EMIT_THREADS;
   const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
-  if (d.tile == 15)
-    emit_kernel<15><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii,
-                                        g.conic_opacity, g.cull_t2, ellipse, d.W, d.H, d.gx, d.gy, g.counters, b.key_a,
-                                        b.inst_gid, g.inst_start);
-  else
-    emit_kernel<16><<<nb, 256, 0, st>>>(s.P, g.depth_order, g.offsets, g.tiles_touched, g.means2D, radii,
-                                        g.conic_opacity, g.cull_t2, ellipse, d.W, d.H, d.gx, d.gy, g.counters, b.key_a,
-                                        b.inst_gid, g.inst_start);
+  if (d.tile == 15) {
+    emit_kernel<15><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.offsets, g.emit_rec, ellipse, d.W, d.H, d.gx,
+                                                 d.gy, g.counters, b.key_a, b.inst_gid, g.inst_start, g.big_list);
+    emit_big_kernel<15><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
+                                                         g.counters, b.key_a, b.inst_gid);
+  } else {
+    emit_kernel<16><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.offsets, g.emit_rec, ellipse, d.W, d.H, d.gx,
+                                                 d.gy, g.counters, b.key_a, b.inst_gid, g.inst_start, g.big_list);
+    emit_big_kernel<16><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
+                                                         g.counters, b.key_a, b.inst_gid);
+  }
 }
 
 // ------------------------------------------------------------------------------- row compaction

@@ -75,7 +75,7 @@ __device__ __forceinline__ u32 preprocess_one(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, int W,
     int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int32_t* __restrict__ radii,
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
-    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float* __restrict__ cull_t2,
+    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
     int ellipse) {
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
@@ -142,10 +142,10 @@ __device__ __forceinline__ u32 preprocess_one(
   sort_key[idx] = f2bits(p_view.z);
 
   u32 count = area;
+  float t2 = 0.f;
   if (ellipse) {
     // exact binning: count, per tile row of the rect, the tile columns the alpha-floor ellipse reaches
-    const float t2 = cull_threshold(conic.x, conic.y, conic.z, opacity, irad, TILE);
-    cull_t2[idx] = t2;
+    t2 = cull_threshold(conic.x, conic.y, conic.z, opacity, irad, TILE);
     count = 0;
     if (t2 >= 0.0f) {
       const CullEllipse e = cull_setup(pix_x, pix_y, conic.x, conic.y, conic.z, t2, irad);
@@ -159,6 +159,8 @@ __device__ __forceinline__ u32 preprocess_one(
     }
   }
   tiles_touched[idx] = count;
+  emit_rec[2 * (size_t)idx] = make_float4(pix_x, pix_y, conic.x, conic.y);
+  emit_rec[2 * (size_t)idx + 1] = make_float4(conic.z, t2, __int_as_float(irad), __uint_as_float(count));
   return area;
 }
 
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ cam_pos, int W,
     int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int32_t* __restrict__ radii,
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
-    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float* __restrict__ cull_t2,
+    float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
     int ellipse, u32* __restrict__ rect_partials) {
   __shared__ u32 s_area[4];
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     area = preprocess_one<TILE>(idx, D, M, orig_points, scales, scale_modifier, rotations, opacities, shs, clamped,
                                 cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, W, H, tan_fovx,
                                 tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy,
-                                tiles_touched, cull_t2, sort_key, sort_val, n_touched, prefiltered, ellipse);
+                                tiles_touched, emit_rec, sort_key, sort_val, n_touched, prefiltered, ellipse);
   // instances of the reference's rect binning (its num_rendered): one partial per block, summed by
   // finalize_counts_kernel (7.8 k same-address atomics would cost more than the whole kernel)
 #pragma unroll
@@ -198,7 +200,7 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
   s.P, s.D, s.M, s.means3D, s.scales, s.scale_modifier, s.rotations, s.opacities, s.shs, g.clamped, s.cov3D_precomp,  \
       s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
-      g.cull_t2, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
+      g.emit_rec, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
       reinterpret_cast<u32*>(g.tau_partials)
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);

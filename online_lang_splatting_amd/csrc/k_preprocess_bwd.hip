@@ -55,6 +55,7 @@ __device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
 }
 
 constexpr int RR_THREADS = 256;
+constexpr int RRS_THREADS = 256;     // lane-per-Gaussian pass
 constexpr u32 RR_BIG = 16;           // rows: above this a Gaussian is reduced by a whole wave
 constexpr int RR_BIG_BLOCKS = 2048;  // persistent grid of the wave-per-Gaussian kernel (8 waves/SIMD)
 
@@ -77,25 +78,25 @@ __device__ __forceinline__ void add_row(const float* __restrict__ rows, u32 row,
 // [rowbase[u0], rowbase[u0 + n]) — ascending (tile, slot) order.  Runs of more than RR_BIG rows are
 // appended to big_list (one aggregated atomic per wave; the list order influences no result).
 template <int F>
-__global__ __launch_bounds__(RR_THREADS) void row_reduce_small_kernel(
-    int P, const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ tiles_touched,
-    const int32_t* __restrict__ radii, const u32* __restrict__ rowbase, const float* __restrict__ rows,
-    float* __restrict__ gacc, uint4* __restrict__ big_list, int32_t* __restrict__ counters) {
+__global__ __launch_bounds__(RRS_THREADS) void row_reduce_small_kernel(
+    int P, const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ rowbase,
+    const float* __restrict__ rows, float* __restrict__ gacc, uint4* __restrict__ big_list,
+    int32_t* __restrict__ counters) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   constexpr int NP = next_pow2_(NVAL);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
   u32 idx = 0, first = 0, nrows = 0;
-  bool vis = false;
+  bool vis = false;  // has instances (a visible Gaussian without any is handled by preprocess_bwd_kernel)
   if (r < P && counters[7] == 0) {
-    idx = order[r];
-    if (radii[idx] > 0) {
+    // offsets = inclusive scan of tiles_touched in depth order: the Gaussian's instance run without
+    // gathering radii / tiles_touched by index
+    const u32 u1 = offsets[r], u0 = (r > 0) ? offsets[r - 1] : 0u;
+    if (u1 > u0) {
       vis = true;
-      const u32 n = tiles_touched[idx];
-      const u32 u0 = offsets[r] - n;
+      idx = order[r];
       first = rowbase[u0];
-      nrows = rowbase[u0 + n] - first;
+      nrows = rowbase[u1] - first;
     }
   }
   if (vis && nrows <= RR_BIG) {
@@ -110,15 +111,8 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_small_kernel(
                             4 * v4 + 2 < NVAL ? acc[4 * v4 + 2] : 0.f, 4 * v4 + 3 < NVAL ? acc[4 * v4 + 3] : 0.f);
   }
   const bool is_big = nrows > RR_BIG;
-  const u64 bigm = ballot(is_big);
-  if (bigm) {
-    u32 base = 0;
-    if (lane == 0) base = (u32)atomicAdd(&counters[4], (int)__popcll(bigm));
-    base = __shfl(base, 0);
-    if (is_big)
-      big_list[base + (u32)__popcll(bigm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] =
-          make_uint4(idx, first, nrows, 0u);
-  }
+  const u32 slot = block_list_slot(is_big, &counters[4]);
+  if (is_big) big_list[slot] = make_uint4(idx, first, nrows, 0u);
 }
 
 // Pass 2: one wave per long run: 64 lanes stride over the rows, then one multi-value butterfly.
@@ -306,7 +300,7 @@ __device__ __forceinline__ void cov3d_backward(const float* scale, float mod, co
 
 template <int F>
 __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
-    int P, int D, int M, const float* __restrict__ gacc,
+    int P, int D, int M, const float* __restrict__ gacc, const u32* __restrict__ tiles_touched,
     const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
     const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
     float scale_modifier, const float* __restrict__ cov3Ds, const float* __restrict__ view,
@@ -326,7 +320,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float acc[NVAL];
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) acc[v] = 0.f;
-    if (vis) {
+    if (vis && tiles_touched[idx] > 0) {  // (a Gaussian listed in no tile has no row sum: all zeros)
       const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
       for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
@@ -577,11 +571,11 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
   const int nb = tau_partial_blocks(s.P);
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
   (void)hipMemsetAsync(&g.counters[4], 0, sizeof(int32_t), st);
-  row_reduce_small_kernel<F><<<(s.P + RR_THREADS - 1) / RR_THREADS, RR_THREADS, 0, st>>>(
-      s.P, g.depth_order, g.offsets, g.tiles_touched, radii, b.rowbase, rows, g.gacc, g.big_list, g.counters);
+  row_reduce_small_kernel<F><<<(s.P + RRS_THREADS - 1) / RRS_THREADS, RRS_THREADS, 0, st>>>(
+      s.P, g.depth_order, g.offsets, b.rowbase, rows, g.gacc, g.big_list, g.counters);
   row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, g.counters);
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, 0, st>>>(
-      s.P, s.D, s.M, g.gacc, s.means3D, radii, s.shs, g.clamped,
+      s.P, s.D, s.M, g.gacc, g.tiles_touched, s.means3D, radii, s.shs, g.clamped,
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,

@@ -24,6 +24,29 @@ __device__ __forceinline__ bool wave_all(bool p) { return ballot(!p) == 0ull; }
 __device__ __forceinline__ float bits2f(u32 u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ u32 f2bits(float f) { return __builtin_bit_cast(u32, f); }
 
+// Append-to-list slot for the lanes with `flag` set: ONE global atomic per workgroup (<= 16 waves).
+// Same-address atomics serialise at the memory side (~5 ns each on MI355X: one per wave of a P = 500 k
+// launch is ~40 us); per-wave counts are combined in LDS first.  Must be called by every thread of the block.
+__device__ __forceinline__ u32 block_list_slot(bool flag, int32_t* counter) {
+  __shared__ u32 s_cnt[16];
+  __shared__ u32 s_base;
+  const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6), nw = (int)((blockDim.x + 63) >> 6);
+  const u64 m = ballot(flag);
+  if (lane == 0) s_cnt[w] = (u32)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tot = 0;
+    for (int i = 0; i < nw; ++i) {
+      const u32 c = s_cnt[i];
+      s_cnt[i] = tot;
+      tot += c;
+    }
+    s_base = tot ? (u32)atomicAdd(counter, (int)tot) : 0u;
+  }
+  __syncthreads();
+  return s_base + s_cnt[w] + (u32)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+}
+
 // ---- gfx950 wave reduction of four values at once -----------------------------------------------
 // v_permlane32_swap / v_permlane16_swap (new in gfx950) exchange the upper half of one VGPR with the
 // lower half of another (halves of 32 lanes, resp. rows of 16 inside each half).  One swap + one add

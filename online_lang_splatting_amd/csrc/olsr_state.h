@@ -52,7 +52,8 @@ struct GeometryState {
   float* rgb;             // [P][3]
   uint8_t* clamped;       // [P][3]
   uint32_t* tiles_touched;  // [P] instances the Gaussian emits (rect area, or the exact tile count)
-  float* cull_t2;         // [P] 2 * inflated alpha-floor threshold of the exact binning (cull_threshold)
+  float4* emit_rec;       // [P][2] everything the emission needs about a Gaussian in ONE 32-byte gather (it runs in
+                          //     depth order): {mean x, mean y, conic a, conic b}, {conic c, cull t2, radius, #instances}
   uint32_t* key_a;        // [P] depth keys (ping)
   uint32_t* key_b;        // [P] (pong)
   uint32_t* val_a;        // [P] Gaussian ids (ping)
@@ -64,10 +65,12 @@ struct GeometryState {
   uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
   int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag,
                           //      3 = instances of the reference's rect binning (== R unless OLSR_BINNING_ELLIPSE),
-                          //      4 = #large-footprint Gaussians, 6 = live rows L, 7 = row-capacity overflow
+                          //      4 = #large-footprint Gaussians (backward), 5 = same for the emission (forward),
+                          //      6 = live rows L, 7 = row-capacity overflow
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
-  uint4* big_list;        // [P] backward scratch: {id, #instances, first instance} of large-footprint Gaussians (count: counters[4])
+  uint4* big_list;        // [P] work list of large-footprint Gaussians: emission {id, first instance, #instances, radius}
+                          //     (count: counters[5]); reused by the backward {id, first row, #rows} (count: counters[4])
   static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
     Carver c(buf);
     GeometryState g;
@@ -78,7 +81,7 @@ struct GeometryState {
     g.rgb = c.take<float>(3 * P);
     g.clamped = c.take<uint8_t>(3 * P);
     g.tiles_touched = c.take<uint32_t>(P);
-    g.cull_t2 = c.take<float>(P);
+    g.emit_rec = c.take<float4>(2 * P);
     g.key_a = c.take<uint32_t>(P);
     g.key_b = c.take<uint32_t>(P);
     g.val_a = c.take<uint32_t>(P);
