@@ -103,10 +103,11 @@ __device__ __forceinline__ float lane_read(float v, int lane) {
 
 // ---- pinned exp --------------------------------------------------------------------------
 // Cephes-style expf: n = rne(x*log2e); r = x - n*ln2 (two-term); degree-5 polynomial;
-// scale by 2^n.  Clamped to [-87, 88] so 2^n is a normal number.
+// scale by 2^n.  The oracle clamps to [-87, 88] so 2^n is a normal number; here only the lower clamp is
+// kept (one v_max_f32): both composites discard the result whenever power > 0 (CR/forward.cu:457-458), so
+// arguments above 88 are never consumed, and for every consumed argument the bits equal the oracle's.
 __device__ __forceinline__ float pinned_expf(float x) {
-  x = (x < -87.0f) ? -87.0f : x;
-  x = (x > 88.0f) ? 88.0f : x;
+  x = __builtin_fmaxf(x, -87.0f);
   float n = __builtin_rintf(x * 1.44269504088896341f);
   float r = __builtin_fmaf(n, -0.693359375f, x);
   r = __builtin_fmaf(n, 2.12194440e-4f, r);
