@@ -288,14 +288,25 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 }
 
 // ------------------------------------------------------------------------------- offsets
-__global__ void finalize_counts_kernel(const u32* offsets, int P, long long capacity, int32_t* counters,
-                                       int32_t* num_rendered_dev, const u32* rect_partials, int nparts) {
+// One small block that also does the frame's housekeeping, so that no separate memset launches are
+// needed: tile ranges zeroed (identifyTileRanges only writes tiles that own instances), the
+// work-list and row counters of this frame reset.
+__global__ __launch_bounds__(256) void finalize_counts_kernel(const u32* offsets, int P, long long capacity,
+                                                              int32_t* counters, int32_t* num_rendered_dev,
+                                                              const u32* rect_partials, int nparts, u32* ranges,
+                                                              int nranges) {
+  __shared__ u32 s_rect[4];
+  for (int i = threadIdx.x; i < nranges; i += 256) ranges[i] = 0u;
+  if (threadIdx.x >= 4 && threadIdx.x < 8) counters[threadIdx.x] = 0;
   // the reference's num_rendered (rect binning): sum of preprocess' per-block partials
   u32 rect = 0;
-  for (int i = threadIdx.x; i < nparts; i += 64) rect += rect_partials[i];
+  for (int i = threadIdx.x; i < nparts; i += 256) rect += rect_partials[i];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) rect += __shfl_xor(rect, m);
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+  if ((threadIdx.x & 63) == 0) s_rect[threadIdx.x >> 6] = rect;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rect = s_rect[0] + s_rect[1] + s_rect[2] + s_rect[3];
     counters[3] = (int32_t)rect;
     const u32 R = (P > 0) ? offsets[P - 1] : 0u;
     const bool ok = (long long)R <= capacity && R <= 0x7FFFFFFFu;
@@ -311,10 +322,11 @@ __global__ void finalize_counts_kernel(const u32* offsets, int P, long long capa
 
 // cub::DeviceScan::InclusiveSum over tiles_touched (CR/rasterizer_impl.cu:451), taken in depth order
 void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, int32_t* num_rendered_dev,
-                             hipStream_t st) {
+                             uint32_t* ranges, int ntiles, hipStream_t st) {
   device_scan<LoadGather, true>(LoadGather{g.tiles_touched, g.depth_order}, (int64_t)P, g.offsets, g.scan_partials, st);
-  finalize_counts_kernel<<<1, 64, 0, st>>>(g.offsets, P, (long long)capacity, g.counters, num_rendered_dev,
-                                           reinterpret_cast<const u32*>(g.tau_partials), (P + 255) / 256);
+  finalize_counts_kernel<<<1, 256, 0, st>>>(g.offsets, P, (long long)capacity, g.counters, num_rendered_dev,
+                                            reinterpret_cast<const u32*>(g.tau_partials), (P + 255) / 256, ranges,
+                                            2 * ntiles);
 }
 
 // ------------------------------------------------------------------------------- emission
@@ -480,9 +492,11 @@ __device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, i
   for (int k = 0; k < 16; ++k) v[k] = (u32)__popc((w4[k >> 2] >> (8 * (k & 3))) & 0xFu);
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void popc_reduce_kernel(const uint8_t* __restrict__ flags, int64_t n,
+__global__ __launch_bounds__(SCAN_THREADS) void popc_reduce_kernel(const uint8_t* __restrict__ flags, int64_t n_host,
+                                                                  const int32_t* __restrict__ n_dev,
                                                                   u32* __restrict__ partials) {
   static_assert(SCAN_ITEMS == 16, "one 16-byte load per thread");
+  const int64_t n = bounded_n(n_host, n_dev);  // flags beyond the instances of this frame are stale
   const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
   u32 v[16];
   load_popc16(flags, base, n, v);
@@ -494,9 +508,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void popc_reduce_kernel(const uint8_t
   if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t* __restrict__ flags, int64_t n,
+__global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t* __restrict__ flags, int64_t n_host,
+                                                                 const int32_t* __restrict__ n_dev,
                                                                  const u32* __restrict__ partials,
                                                                  u32* __restrict__ out) {
+  const int64_t n = bounded_n(n_host, n_dev);
   const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
   u32 v[16];
   load_popc16(flags, base, n, v);
@@ -522,13 +538,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t*
   }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* partials, int nb, int64_t n,
-                                                                    u32* rowbase, long long row_capacity,
-                                                                    int32_t* counters, int32_t* status_dev) {
+__global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* partials, int nb, int64_t n_host,
+                                                                    const int32_t* n_dev, u32* rowbase,
+                                                                    long long row_capacity, int32_t* counters,
+                                                                    int32_t* status_dev) {
+  const int64_t n = bounded_n(n_host, n_dev);
   const u32 L = block_prefix_of_partials(partials, nb);
   if (threadIdx.x == 0) {
     const int32_t ov = ((long long)L > row_capacity) ? 1 : 0;
     rowbase[n] = L;
+    counters[4] = 0;  // the backward's work list starts empty
     counters[6] = (int32_t)L;
     counters[7] = ov;
     if (status_dev) {
@@ -538,28 +557,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* 
   }
 }
 
-void launch_row_compaction(const uint8_t* flags, int64_t n_host, uint32_t* rowbase, uint32_t* partials,
-                           int64_t row_capacity, int32_t* counters, int32_t* status_dev, hipStream_t st) {
+void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, uint32_t* rowbase,
+                           uint32_t* partials, int64_t row_capacity, int32_t* counters, int32_t* status_dev,
+                           hipStream_t st) {
   if (n_host <= 0) {
     (void)hipMemsetAsync(rowbase, 0, sizeof(u32), st);
-    (void)hipMemsetAsync(counters + 6, 0, 2 * sizeof(int32_t), st);
+    (void)hipMemsetAsync(counters + 4, 0, 4 * sizeof(int32_t), st);
     if (status_dev) (void)hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), st);
     return;
   }
   const int nb = scan_blocks(n_host);
-  popc_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, partials);
-  popc_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, partials, rowbase);
-  rows_finalize_kernel<<<1, SCAN_THREADS, 0, st>>>(partials, nb, n_host, rowbase, (long long)row_capacity, counters,
-                                                   status_dev);
+  popc_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, partials);
+  popc_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, partials, rowbase);
+  rows_finalize_kernel<<<1, SCAN_THREADS, 0, st>>>(partials, nb, n_host, n_dev, rowbase, (long long)row_capacity,
+                                                   counters, status_dev);
 }
 
 // ------------------------------------------------------------------------------- ranges
-// identifyTileRanges (CR/rasterizer_impl.cu:116-138); ranges must be zeroed beforehand.
+// identifyTileRanges (CR/rasterizer_impl.cu:116-138); ranges were zeroed by finalize_counts_kernel.
+// Also clears the liveness flag of every instance of this frame (the forward composite only writes
+// the flags of instances that blend something).
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict__ keys, int64_t n_host,
-                                                          const int32_t* __restrict__ n_dev, u32* __restrict__ ranges) {
+                                                          const int32_t* __restrict__ n_dev, u32* __restrict__ ranges,
+                                                          uint8_t* __restrict__ flags) {
   const int64_t n = bounded_n(n_host, n_dev);
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
+  flags[idx] = 0;
   const u32 cur = keys[idx];
   if (idx == 0)
     ranges[2 * cur] = 0;
@@ -574,11 +598,10 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const u32* __restrict_
 }
 
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
-                        int ntiles, hipStream_t st) {
-  (void)hipMemsetAsync(ranges, 0, sizeof(u32) * 2 * (size_t)ntiles, st);
+                        uint8_t* flags, hipStream_t st) {
   if (n_host <= 0) return;
   const int nb = (int)((n_host + 255) / 256);
-  tile_ranges_kernel<<<nb, 256, 0, st>>>(sorted_keys, n_host, n_dev, ranges);
+  tile_ranges_kernel<<<nb, 256, 0, st>>>(sorted_keys, n_host, n_dev, ranges, flags);
 }
 
 // ------------------------------------------------------------------------------- tile order

@@ -570,7 +570,6 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
                         hipStream_t st) {
   const int nb = tau_partial_blocks(s.P);
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
-  (void)hipMemsetAsync(&g.counters[4], 0, sizeof(int32_t), st);
   row_reduce_small_kernel<F><<<(s.P + RRS_THREADS - 1) / RRS_THREADS, RRS_THREADS, 0, st>>>(
       s.P, g.depth_order, g.offsets, b.rowbase, rows, g.gacc, g.big_list, g.counters);
   row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, g.counters);

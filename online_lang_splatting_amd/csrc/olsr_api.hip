@@ -139,7 +139,10 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     return fail(OLSR_ERR_ARG, "output image pointers must not be NULL");
   if (s.P > 0 && (!radii || !n_touched)) return fail(OLSR_ERR_ARG, "radii and n_touched must not be NULL");
 
-  HIP_TRY(hipMemsetAsync(g.counters, 0, sizeof(int32_t) * 8, st));
+  if (s.P <= 0) {  // nothing below runs: leave a consistent empty state behind
+    HIP_TRY(hipMemsetAsync(g.counters, 0, sizeof(int32_t) * 8, st));
+    HIP_TRY(hipMemsetAsync(im.ranges, 0, sizeof(uint32_t) * 2 * (size_t)d.ntiles, st));
+  }
 
   int64_t n_host = 0;
   BinningState b{};
@@ -149,7 +152,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
     launch_radix_sort(sb, s.P, nullptr, 32, false, st);
     STAGE("depth_sort");
-    launch_instance_offsets(g, s.P, bp.capacity >= 0 ? bp.capacity : 0x7FFFFFFFLL, num_rendered_dev, st);
+    launch_instance_offsets(g, s.P, bp.capacity >= 0 ? bp.capacity : 0x7FFFFFFFLL, num_rendered_dev, im.ranges,
+                            d.ntiles, st);
     STAGE("instance_offsets");
   }
 
@@ -176,7 +180,6 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   const uint32_t* sorted_keys = b.key_a;
   if (s.P > 0 && n_host > 0) {
     launch_emit(s, d, g, radii, b, st);
-    HIP_TRY(hipMemsetAsync(b.flags, 0, (size_t)n_host, st));
     STAGE("emit");
     // arrange the value ping-pong so that the last pass always lands in b.src
     const bool odd = tile_sort_where(d.ntiles) != 0;
@@ -185,7 +188,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     if (where) sorted_keys = b.key_b;
     STAGE("tile_sort");
   }
-  launch_tile_ranges(sorted_keys, (s.P > 0) ? n_host : 0, n_dev, im.ranges, d.ntiles, st);
+  launch_tile_ranges(sorted_keys, (s.P > 0) ? n_host : 0, n_dev, im.ranges, b.flags, st);
   STAGE("tile_ranges");
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, st);
   STAGE("render_forward");
@@ -294,7 +297,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, bb);
 
   // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended
-  launch_row_compaction(b.flags, num_rendered, b.rowbase, b.scan_partials,
+  launch_row_compaction(b.flags, num_rendered, &g.counters[1], b.rowbase, b.scan_partials,
                         scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, status_dev, st);
   STAGE("row_compaction");
   if (scratch_alloc) {

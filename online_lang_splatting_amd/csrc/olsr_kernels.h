@@ -27,18 +27,22 @@ struct SortBuffers {
 // Returns 0 if the result ends in (key_a,val_a), 1 if in (key_b,val_b).
 int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
                       hipStream_t st);
+// scan of tiles_touched in depth order + the frame's counters; also zeroes `ranges` (2 * ntiles) and the
+// work-list / row counters
 void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, int32_t* num_rendered_dev,
-                             hipStream_t st);
+                             uint32_t* ranges, int ntiles, hipStream_t st);
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
                  const BinningState& b, hipStream_t st);
 // exclusive scan of popcount(flags & 15) over [0, n] -> rowbase[0..n]; counters[6] = total live rows,
 // counters[7] = (total > row_capacity)
-void launch_row_compaction(const uint8_t* flags, int64_t n_host, uint32_t* rowbase, uint32_t* partials,
-                           int64_t row_capacity, int32_t* counters, int32_t* status_dev, hipStream_t st);
+void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, uint32_t* rowbase,
+                           uint32_t* partials, int64_t row_capacity, int32_t* counters, int32_t* status_dev,
+                           hipStream_t st);
 // backward launch order: inside each XCD's contiguous chunk of tiles, heaviest (most live pairs) first
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st);
+// ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
-                        int ntiles, hipStream_t st);
+                        uint8_t* flags, hipStream_t st);
 
 // k_render_fwd.hip
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
