@@ -7,8 +7,8 @@ A "step" is one pass of the hot path over one frame: forward (preprocess, depth 
 tile sort, composite) + backward (composite backward, per-Gaussian backward) of BASELINE.json's
 config 3 — 500 k Gaussians, 1200x680, RGB + depth + 15 language channels — through the
 sync-free C-ABI entry points (olsr_forward_async / olsr_backward) with every input already
-resident in HBM, plus the accumulation of the view's gradients into the flat per-Gaussian
-gradient buffer.  With N > 1 (one process per GPU, torch.distributed over RCCL) every rank
+resident in HBM; the backward writes the view's gradients into the flat per-Gaussian gradient
+buffer (olsr_grad_bucket) that a mapping step all-reduces.  With N > 1 (one process per GPU, torch.distributed over RCCL) every rank
 renders its own viewpoint of the same Gaussians per step and the step ends with the one
 all-reduce of the shared-Gaussian gradient buffer (frame sharding, weak scaling).
 
@@ -168,8 +168,9 @@ def main():
         with torch.cuda.stream(stream):
             ws.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
             out = ws.forward()
-            g = ws.backward(dc, dl, dd)
-            bucket.accumulate(g, out["radii"], first=True)
+            # gradients go straight into the flat bucket (what a mapping step consumes): dL_dmeans3D, dL_dsh,
+            # dL_dopacity, dL_dscales, dL_drotations, dL_dlanguage + densification statistics + dL_dtau_sum
+            ws.backward(dc, dl, dd, bucket=bucket, first=True, bucket_only=True)
             bucket.all_reduce()
 
     def timed(nsteps, warmup, pick):

@@ -156,7 +156,20 @@ int olsr_forward_async(const olsr_scene *scene,
  * (DGR/rasterize_points.cu:390-391); they may be NULL.  The geometry and binning buffers carry
  * scratch regions the backward writes (the reference passes them as char* too).
  * dL_dtau_sum[6] (may be NULL) receives the sum over P that the Python layer computes at
- * DGR/diff_gaussian_rasterization/__init__.py:383-385. */
+ * DGR/diff_gaussian_rasterization/__init__.py:383-385.
+ *
+ * bucket (may be NULL): additionally write (assign != 0) or add (assign == 0) this view's gradients
+ * straight into the flat all-reduce buffer and the densification statistics described at
+ * olsr_accumulate_gradients — the same result as calling that function afterwards, without the
+ * round trip through the separate arrays.  With a bucket, every per-Gaussian output above may be
+ * NULL and is then not written (a mapping step only consumes the bucket and dL_dtau_sum). */
+typedef struct olsr_grad_bucket {
+  float *flat;        /* [P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language] */
+  float *densify;     /* [P][2]  {sum of ||dL_dmeans2D.xy|| over views, number of views that saw it} */
+  int32_t *max_radii; /* [P] */
+  int32_t assign;     /* 1: first view of a step (overwrite), 0: add */
+  int32_t _pad0;
+} olsr_grad_bucket;
 size_t olsr_backward_scratch_bytes(int64_t rows, int32_t F);
 int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   void *geometry_buffer, int32_t num_rendered,
@@ -169,7 +182,8 @@ int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   float *dL_dcolors, float *dL_dlanguage, float *dL_ddepths,
                   float *dL_dmeans3D, float *dL_dcov3D, float *dL_dsh,
                   float *dL_dscales, float *dL_drotations, float *dL_dtau,
-                  float *dL_dtau_sum, int32_t *status_dev, void *hip_stream);
+                  float *dL_dtau_sum, const olsr_grad_bucket *bucket,
+                  int32_t *status_dev, void *hip_stream);
 
 /* Adds one view's per-Gaussian gradients into the flat fp32 buffer
  *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]

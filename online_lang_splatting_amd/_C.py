@@ -159,7 +159,7 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
             dl.data_ptr() if dl is not None else None, dd.data_ptr() if dd is not None else None,
             p("dL_dmeans2D"), p("dL_dconic"), p("dL_dopacity"), p("dL_dcolors"), p("dL_dlanguage"), p("dL_ddepths"),
             p("dL_dmeans3D"), p("dL_dcov3D"), p("dL_dsh"), p("dL_dscales"), p("dL_drotations"), p("dL_dtau"),
-            p("dL_dtau_sum"), None, _stream(dev)))
+            p("dL_dtau_sum"), None, None, _stream(dev)))
         # the scratch tensor may be released now: later work on this stream is ordered after the kernels
         # that read it, and the caching allocator reuses blocks stream-ordered
     return g

@@ -58,6 +58,12 @@ class OlsrScene(C.Structure):
     ]
 
 
+class OlsrGradBucket(C.Structure):
+    """struct olsr_grad_bucket, include/olsr.h."""
+
+    _fields_ = [("flat", _fp), ("densify", _fp), ("max_radii", _fp), ("assign", C.c_int32), ("_pad0", C.c_int32)]
+
+
 def _ptr(t):
     """data_ptr of a tensor, or None for an absent (None / empty) one — the reference maps
     empty tensors to nullptr the same way (contiguous().data<float>() of a 0-element tensor,

@@ -50,7 +50,7 @@ def lib():
     L.olsr_forward_async.restype = C.c_int
     L.olsr_backward_scratch_bytes.argtypes, L.olsr_backward_scratch_bytes.restype = [i64, i32], sz
     L.olsr_backward.argtypes = ([scene_p, vp, vp, i32, vp, vp, _abi.ALLOC_FN, vp, vp, i64] + [vp] * 3 + [vp] * 13
-                                + [vp, vp])
+                                + [C.POINTER(_abi.OlsrGradBucket), vp, vp])
     L.olsr_backward.restype = C.c_int
     L.olsr_accumulate_gradients.argtypes = [i32, i32, i32, i32] + [vp] * 12
     L.olsr_accumulate_gradients.restype = C.c_int

@@ -170,9 +170,11 @@ __device__ __forceinline__ f3 dnormvdv(f3 v, f3 dv) {
 
 // computeColorFromSH backward, CR/backward.cu:21-145.  Writes dL_dsh rows (all M coefficients,
 // zeros above the active degree), returns dL_dmean contribution.
+// `dL_dsh` is the Gaussian's own row of 3M floats; with `add` the values are added to it (fused
+// accumulation into the gradient bucket).
 __device__ __forceinline__ f3 sh_backward(int idx, int deg, int M, const f3& pos, const float* campos,
                                           const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
-                                          const float* dL_dcolor3, float* __restrict__ dL_dshs) {
+                                          const float* dL_dcolor3, float* __restrict__ dL_dsh, bool add) {
   const f3 dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
   const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
   const f3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
@@ -182,11 +184,13 @@ __device__ __forceinline__ f3 sh_backward(int idx, int deg, int M, const f3& pos
   for (int ch = 0; ch < 3; ++ch) dL_dRGB[ch] = dL_dcolor3[ch] * (clamped[3 * (size_t)idx + ch] ? 0 : 1);
   float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
   const float x = dir.x, y = dir.y, z = dir.z;
-  float* dL_dsh = dL_dshs + (size_t)idx * M * 3;
   auto S = [&](int k, int ch) { return sh[3 * k + ch]; };
   auto setsh = [&](int k, float w) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) dL_dsh[3 * k + ch] = w * dL_dRGB[ch];
+    for (int ch = 0; ch < 3; ++ch) {
+      const float v = w * dL_dRGB[ch];
+      dL_dsh[3 * k + ch] = add ? dL_dsh[3 * k + ch] + v : v;
+    }
   };
   setsh(0, SH_C0);
   int written = 1;
@@ -244,11 +248,12 @@ __device__ __forceinline__ f3 sh_backward(int idx, int deg, int M, const f3& pos
       }
     }
   }
-  for (int k = written; k < M; ++k) {
-    dL_dsh[3 * k + 0] = 0.f;
-    dL_dsh[3 * k + 1] = 0.f;
-    dL_dsh[3 * k + 2] = 0.f;
-  }
+  if (!add)
+    for (int k = written; k < M; ++k) {
+      dL_dsh[3 * k + 0] = 0.f;
+      dL_dsh[3 * k + 1] = 0.f;
+      dL_dsh[3 * k + 2] = 0.f;
+    }
   const f3 dL_ddir = {dRGBdx[0] * dL_dRGB[0] + dRGBdx[1] * dL_dRGB[1] + dRGBdx[2] * dL_dRGB[2],
                       dRGBdy[0] * dL_dRGB[0] + dRGBdy[1] * dL_dRGB[1] + dRGBdy[2] * dL_dRGB[2],
                       dRGBdz[0] * dL_dRGB[0] + dRGBdz[1] * dL_dRGB[1] + dRGBdz[2] * dL_dRGB[2]};
@@ -309,9 +314,12 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors, float* __restrict__ dL_dlanguage,
     float* __restrict__ dL_ddepths, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
-    float* __restrict__ dL_dtau, float* __restrict__ tau_partials) {
+    float* __restrict__ dL_dtau, float* __restrict__ tau_partials, float* __restrict__ bucket_flat,
+    float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
+  extern __shared__ float s_bucket[];  // [PB_THREADS][width] when a gradient bucket is given
+  const int width = 11 + 3 * M + F;    // floats per Gaussian in the gradient bucket
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (r < P) {
@@ -331,24 +339,57 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
         if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
       }
     }
+    // bucket row of this Gaussian, staged in LDS: a lane's 116-byte row would be 29 scattered 4-byte stores,
+    // the block's rows together are one contiguous span that is written (or added) coalesced at the end
+    float* brow = bucket_flat ? s_bucket + (size_t)threadIdx.x * width : nullptr;
+    constexpr bool badd = false;  // LDS rows are assigned; assign / add is applied by the block's copy-out
     // what the composite's atomics produced in the reference
-    dL_dmeans2D[3 * (size_t)idx + 0] = acc[0];
-    dL_dmeans2D[3 * (size_t)idx + 1] = acc[1];
-    dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+    if (dL_dmeans2D) {
+      dL_dmeans2D[3 * (size_t)idx + 0] = acc[0];
+      dL_dmeans2D[3 * (size_t)idx + 1] = acc[1];
+      dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+    }
+    if (brow) {
+      // densification statistics (gaussian_model.py:965-969): per-view norm of the screen-space gradient
+      const int rad = radii[idx];
+      const float nrm = vis ? sqrtf(acc[0] * acc[0] + acc[1] * acc[1]) : 0.f;
+      const float cnt = vis ? 1.f : 0.f;
+      float2* dz = reinterpret_cast<float2*>(bucket_densify) + idx;
+      if (bucket_assign) {
+        *dz = make_float2(nrm, cnt);
+        bucket_max_radii[idx] = rad;
+      } else {
+        const float2 o = *dz;
+        *dz = make_float2(o.x + nrm, o.y + cnt);
+        bucket_max_radii[idx] = max(bucket_max_radii[idx], rad);
+      }
+    }
     if (dL_dconic) {
       dL_dconic[4 * (size_t)idx + 0] = acc[2];
       dL_dconic[4 * (size_t)idx + 1] = acc[3];
       dL_dconic[4 * (size_t)idx + 2] = 0.f;
       dL_dconic[4 * (size_t)idx + 3] = acc[4];
     }
-    dL_dopacity[idx] = acc[5];
-    dL_dcolors[3 * (size_t)idx + 0] = acc[6];
-    dL_dcolors[3 * (size_t)idx + 1] = acc[7];
-    dL_dcolors[3 * (size_t)idx + 2] = acc[8];
+    if (dL_dopacity) dL_dopacity[idx] = acc[5];
+    if (dL_dcolors) {
+      dL_dcolors[3 * (size_t)idx + 0] = acc[6];
+      dL_dcolors[3 * (size_t)idx + 1] = acc[7];
+      dL_dcolors[3 * (size_t)idx + 2] = acc[8];
+    }
     if (dL_ddepths) dL_ddepths[idx] = acc[9];
     if constexpr (F > 0) {
+      if (dL_dlanguage) {
 #pragma unroll
-      for (int ch = 0; ch < F; ++ch) dL_dlanguage[(size_t)idx * F + ch] = acc[10 + ch];
+        for (int ch = 0; ch < F; ++ch) dL_dlanguage[(size_t)idx * F + ch] = acc[10 + ch];
+      }
+    }
+    if (brow) {
+      float* o = brow + 3 + 3 * M;  // [opacity | scale 3 | rotation 4 | language F]
+      o[0] = badd ? o[0] + acc[5] : acc[5];
+      if constexpr (F > 0) {
+#pragma unroll
+        for (int ch = 0; ch < F; ++ch) o[8 + ch] = badd ? o[8 + ch] + acc[10 + ch] : acc[10 + ch];
+      }
     }
 
     float dmean[3] = {0.f, 0.f, 0.f};
@@ -501,7 +542,10 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
         }
         if (shs) {
           const float dcol[3] = {acc[6], acc[7], acc[8]};
-          const f3 dm_sh = sh_backward((int)idx, D, M, mean, campos, shs, clamped, dcol, dL_dsh);
+          // one evaluation: into the caller's dL_dsh row if there is one (copied to the bucket below),
+          // else straight into the bucket row
+          float* sh_row = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : brow + 3;
+          const f3 dm_sh = sh_backward((int)idx, D, M, mean, campos, shs, clamped, dcol, sh_row, !dL_dsh && badd);
           sh_written = true;
           dmean[0] += dm_sh.x;
           dmean[1] += dm_sh.y;
@@ -515,19 +559,56 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
       }
     }
     if (M > 0 && !sh_written) {
-      float* o = dL_dsh + (size_t)idx * M * 3;
-      for (int k = 0; k < 3 * M; ++k) o[k] = 0.f;
+      if (dL_dsh) {
+        float* o = dL_dsh + (size_t)idx * M * 3;
+        for (int k = 0; k < 3 * M; ++k) o[k] = 0.f;
+      }
+      if (brow && !badd)
+        for (int k = 0; k < 3 * M; ++k) brow[3 + k] = 0.f;
+    } else if (M > 0 && brow && dL_dsh) {
+      const float* o = dL_dsh + (size_t)idx * M * 3;  // just written by this thread
+      for (int k = 0; k < 3 * M; ++k) brow[3 + k] = badd ? brow[3 + k] + o[k] : o[k];
     }
+    if (dL_dmeans3D) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dL_dmeans3D[3 * (size_t)idx + i] = dmean[i];
+      for (int i = 0; i < 3; ++i) dL_dmeans3D[3 * (size_t)idx + i] = dmean[i];
+    }
+    if (dL_dcov3D) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+      for (int i = 0; i < 6; ++i) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    }
+    if (dL_dscales) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dL_dscales[3 * (size_t)idx + i] = dscale[i];
+      for (int i = 0; i < 3; ++i) dL_dscales[3 * (size_t)idx + i] = dscale[i];
+    }
+    if (dL_drotations) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dL_drotations[4 * (size_t)idx + i] = drot[i];
+      for (int i = 0; i < 4; ++i) dL_drotations[4 * (size_t)idx + i] = drot[i];
+    }
+    if (dL_dtau) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dL_dtau[6 * (size_t)idx + i] = tau[i];
+      for (int i = 0; i < 6; ++i) dL_dtau[6 * (size_t)idx + i] = tau[i];
+    }
+    if (brow) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) brow[i] = badd ? brow[i] + dmean[i] : dmean[i];
+      float* o = brow + 4 + 3 * M;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[i] = badd ? o[i] + dscale[i] : dscale[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[3 + i] = badd ? o[3 + i] + drot[i] : drot[i];
+    }
+  }
+
+  if (bucket_flat) {
+    __syncthreads();
+    const int g0 = blockIdx.x * PB_THREADS;
+    const int count = min(PB_THREADS, P - g0) * width;
+    float* out = bucket_flat + (size_t)g0 * width;
+    if (bucket_assign)
+      for (int e = threadIdx.x; e < count; e += PB_THREADS) out[e] = s_bucket[e];
+    else
+      for (int e = threadIdx.x; e < count; e += PB_THREADS) out[e] += s_bucket[e];
   }
 
   // deterministic block partial of tau (fixed butterfly order, then waves in order)
@@ -573,12 +654,13 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
   row_reduce_small_kernel<F><<<(s.P + RRS_THREADS - 1) / RRS_THREADS, RRS_THREADS, 0, st>>>(
       s.P, g.depth_order, g.offsets, b.rowbase, rows, g.gacc, g.big_list, g.counters);
   row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, g.counters);
-  preprocess_bwd_kernel<F><<<nb, PB_THREADS, 0, st>>>(
+  const size_t bucket_lds = o.bucket_flat ? sizeof(float) * PB_THREADS * (size_t)(11 + 3 * s.M + s.F) : 0;
+  preprocess_bwd_kernel<F><<<nb, PB_THREADS, bucket_lds, st>>>(
       s.P, s.D, s.M, g.gacc, g.tiles_touched, s.means3D, radii, s.shs, g.clamped,
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
-      o.dL_dtau_sum ? tau_partials : nullptr);
+      o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign);
   if (o.dL_dtau_sum) tau_final_kernel<<<6, 256, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
 }
 

@@ -268,7 +268,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
                   const float* dL_dout_depth, float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity,
                   float* dL_dcolors, float* dL_dlanguage, float* dL_ddepths, float* dL_dmeans3D, float* dL_dcov3D,
                   float* dL_dsh, float* dL_dscales, float* dL_drotations, float* dL_dtau, float* dL_dtau_sum,
-                  int32_t* status_dev, void* hip_stream) {
+                  const olsr_grad_bucket* bucket, int32_t* status_dev, void* hip_stream) {
   int rc = check_scene(scene, true);
   if (rc != OLSR_OK) return rc;
   const olsr_scene& s = *scene;
@@ -287,9 +287,13 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
     return fail(OLSR_ERR_ARG, "either a scratch allocation callback or a scratch buffer with its row capacity is required");
   if (!dL_dout_color || !dL_dout_depth || (s.F > 0 && !dL_dout_language))
     return fail(OLSR_ERR_ARG, "upstream gradients must not be NULL");
-  if (!dL_dmeans2D || !dL_dopacity || !dL_dcolors || (s.F > 0 && !dL_dlanguage) || !dL_dmeans3D || !dL_dcov3D ||
-      (s.M > 0 && !dL_dsh) || !dL_dscales || !dL_drotations || !dL_dtau)
-    return fail(OLSR_ERR_ARG, "gradient outputs must not be NULL");
+  if (bucket) {
+    if (!bucket->flat || !bucket->densify || !bucket->max_radii)
+      return fail(OLSR_ERR_ARG, "bucket.flat, bucket.densify and bucket.max_radii must not be NULL");
+  } else if (!dL_dmeans2D || !dL_dopacity || !dL_dcolors || (s.F > 0 && !dL_dlanguage) || !dL_dmeans3D ||
+             !dL_dcov3D || (s.M > 0 && !dL_dsh) || !dL_dscales || !dL_drotations || !dL_dtau) {
+    return fail(OLSR_ERR_ARG, "gradient outputs must not be NULL (unless a gradient bucket is given)");
+  }
   const FrameDims d = frame_dims(s);
   size_t gb, ib, bb;
   const GeometryState g = GeometryState::carve(geometry_buffer, (size_t)s.P, grad_row(s.F), gb);
@@ -317,6 +321,12 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   STAGE("render_backward");
   GradOut o{dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dlanguage, dL_ddepths, dL_dmeans3D,
             dL_dcov3D,   dL_dsh,    dL_dscales,  dL_drotations, dL_dtau,    dL_dtau_sum};
+  if (bucket) {
+    o.bucket_flat = bucket->flat;
+    o.bucket_densify = bucket->densify;
+    o.bucket_max_radii = bucket->max_radii;
+    o.bucket_assign = bucket->assign;
+  }
   launch_preprocess_backward(s, d, g, b, rows, radii, o, g.tau_partials, st);
   STAGE("preprocess_backward");
   (void)gb;

@@ -62,6 +62,11 @@ void launch_render_backward_exact(const olsr_scene& s, const FrameDims& d, const
 struct GradOut {
   float *dL_dmeans2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_dlanguage, *dL_ddepths, *dL_dmeans3D, *dL_dcov3D,
       *dL_dsh, *dL_dscales, *dL_drotations, *dL_dtau, *dL_dtau_sum;
+  // optional fused accumulation (olsr_grad_bucket); every pointer above may then be NULL
+  float* bucket_flat = nullptr;
+  float* bucket_densify = nullptr;
+  int32_t* bucket_max_radii = nullptr;
+  int bucket_assign = 0;
 };
 void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
                                 const BinningState& b, const float* rows, const int32_t* radii, const GradOut& o,

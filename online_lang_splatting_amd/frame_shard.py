@@ -185,18 +185,29 @@ class RasterWorkspace:
             self._stream()))
         return o
 
-    def backward(self, dL_dcolor, dL_dlanguage, dL_ddepth):
+    def backward(self, dL_dcolor, dL_dlanguage, dL_ddepth, bucket=None, first=False, bucket_only=False):
+        """Backward of the last forward.  With `bucket` (a GradientBucket) the per-Gaussian backward kernel also
+        writes (first=True) or adds this view's gradients into the bucket — the fused form of
+        bucket.accumulate(); `bucket_only` additionally skips the separate per-Gaussian gradient arrays
+        (a mapping step only consumes the bucket and dL_dtau_sum)."""
         g = self.grads
 
         def p(t):
             return t.data_ptr() if t is not None and t.numel() > 0 else None
+        bk = None
+        if bucket is not None:
+            bk = _abi.OlsrGradBucket(flat=bucket.flat.data_ptr(), densify=bucket.densify.data_ptr(),
+                                     max_radii=bucket.max_radii.data_ptr(), assign=1 if first else 0)
+            if bucket_only:
+                g = {k: (v if k == "dL_dtau_sum" else None) for k, v in g.items()}
         check(lib().olsr_backward(
             C.byref(self._scene), self.out["radii"].data_ptr(), self.geom.data_ptr(), self.capacity,
             self.binning.data_ptr(), self.img.data_ptr(), _abi.ALLOC_FN(0), None, self.scratch.data_ptr(),
             self.row_capacity, p(dL_dcolor), p(dL_dlanguage), p(dL_ddepth),
             p(g["dL_dmeans2D"]), p(g["dL_dconic"]), p(g["dL_dopacity"]), p(g["dL_dcolors"]), p(g["dL_dlanguage"]),
             p(g["dL_ddepths"]), p(g["dL_dmeans3D"]), p(g["dL_dcov3D"]), p(g["dL_dsh"]), p(g["dL_dscales"]),
-            p(g["dL_drotations"]), p(g["dL_dtau"]), p(g["dL_dtau_sum"]), self.bwd_status.data_ptr(), self._stream()))
+            p(g["dL_drotations"]), p(g["dL_dtau"]), p(g["dL_dtau_sum"]), C.byref(bk) if bk is not None else None,
+            self.bwd_status.data_ptr(), self._stream()))
         return g
 
     def backward_status(self):
@@ -265,8 +276,8 @@ class FrameShardedStep:
                          tanfovy=cam["tanfovy"], **gaussians)
             out = ws.forward()
             dc, dl, dd = cotangents(v, out)
-            g = ws.backward(dc, dl, dd)
-            self.bucket.accumulate(g, out["radii"], first=(n_done == 0))
+            # the per-Gaussian backward kernel writes / adds straight into the bucket (fused accumulate)
+            g = ws.backward(dc, dl, dd, bucket=self.bucket, first=(n_done == 0), bucket_only=True)
             self.pose_grads[v] = g["dL_dtau_sum"].clone()  # [rho | theta], stays on the owning rank
         self.bucket.all_reduce(self.group)
         return self.bucket

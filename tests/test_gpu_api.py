@@ -121,6 +121,48 @@ def test_workspace_async_equals_dropin_path(hip):
     assert torch.equal(g3["dL_dmeans3D"], gg["dL_dmeans3D"])
 
 
+def test_fused_bucket_equals_separate_accumulate(hip):
+    """olsr_backward with an olsr_grad_bucket == olsr_backward + olsr_accumulate_gradients, for the first
+    view (assign) and a second view (add), with and without the separate per-Gaussian arrays; SH degree 3
+    so the 48-float SH slice of the bucket row is exercised."""
+    from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket, RasterWorkspace
+    from online_lang_splatting_amd.scene import arc_cameras
+    dev = torch.device(DEV)
+    sc = make_scene(6000, 200, 150, 15, seed=13, max_sh_degree=3, sh_degree=3)
+    M = sc.shs.shape[1]
+    cams = arc_cameras(200, 150, 2)
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(4))
+    gk = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+              rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev), sh_degree=3)
+    ws = RasterWorkspace(sc.P, 200, 150, 15, M, 300000, dev)
+    ref = GradientBucket(sc.P, GradLayout(M, 15), dev)
+    fused = GradientBucket(sc.P, GradLayout(M, 15), dev)
+    only = GradientBucket(sc.P, GradLayout(M, 15), dev)
+    for b in (ref, fused, only):  # stale contents must be overwritten by the first view
+        b.flat.fill_(7.0)
+        b.densify.fill_(7.0)
+        b.max_radii.fill_(7)
+    for i, c in enumerate(cams):
+        ws.set_scene(viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev),
+                     projmatrix_raw=c.projection_matrix.to(dev), campos=c.camera_center.to(dev), tanfovx=c.tanfovx,
+                     tanfovy=c.tanfovy, **gk)
+        out = ws.forward()
+        g = ws.backward(dc, dl, dd)
+        sep = {k: v.clone() for k, v in g.items()}
+        ref.accumulate(sep, out["radii"], first=(i == 0))
+        g2 = ws.backward(dc, dl, dd, bucket=fused, first=(i == 0))
+        for k in sep:  # the separate arrays are still written, identically
+            assert torch.equal(g2[k], sep[k]), k
+        g3 = ws.backward(dc, dl, dd, bucket=only, first=(i == 0), bucket_only=True)
+        assert torch.equal(g3["dL_dtau_sum"], sep["dL_dtau_sum"])
+        assert not ws.rendered()[1]
+    for b in (fused, only):
+        assert torch.equal(b.flat, ref.flat)
+        assert torch.equal(b.densify, ref.densify)
+        assert torch.equal(b.max_radii, ref.max_radii)
+    assert float(ref.flat.abs().max()) > 0 and int((ref.densify[:, 1] == 2).sum()) > 0
+
+
 def test_frames_in_flight_are_independent(hip):
     """FrameLanes: three views rendered concurrently on three HIP streams == the same views rendered
     one after the other (bit for bit: no shared scratch, no cross-stream race)."""
