@@ -185,6 +185,42 @@ int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   float *dL_dtau_sum, const olsr_grad_bucket *bucket,
                   int32_t *status_dev, void *hip_stream);
 
+/* ---- caller side of the path -----------------------------------------
+ * Mapping loss of one view and its gradient with respect to the rendered images, in one pass over the
+ * pixels.  Replaces, with their autograd backward,
+ *   get_loss_mapping / get_loss_mapping_rgbd                        utils/slam_utils.py:124-165
+ *   F.interpolate(gt_lang_feat, size=(H, W), mode='bilinear', align_corners=False)
+ *   l1_loss(language_feat, gt_lang_feat_resize), lamda_lang weighting   utils/slam_backend.py:579-597
+ *                                                        gaussian_splatting/utils/loss_utils.py:21-22
+ *   loss = alpha * mean|m_rgb * (exp(a) * image + b) - m_rgb * gt_image|
+ *        + (1 - alpha) * mean|m_d * depth - m_d * gt_depth|
+ *        + lamda_lang * mean|language - resize(gt_language)|
+ * with m_rgb = (sum_c gt_image > rgb_boundary_threshold), m_d = (gt_depth > 0.01), means over all
+ * elements of the respective tensor.  The outputs dL_dimage[3,H,W], dL_ddepth[1,H,W] and
+ * dL_dlanguage[F,H,W] are exactly the cotangents olsr_backward consumes, so the rendered images
+ * make one round trip instead of the ~20 elementwise kernels of the PyTorch formulation.
+ *   exposure      device float[2] {exposure_a, exposure_b}, or NULL / initialization != 0 for a = b = 0
+ *   gt_language   [F, lang_height, lang_width] or NULL (no language term; dL_dlanguage zero-filled)
+ *   loss          device float[4]: {total, rgb term, depth term, language term} (each already weighted)
+ *   dL_dexposure  device float[2] {dL/da, dL/db} or NULL
+ *   scratch       olsr_mapping_loss_scratch_bytes(width, height) bytes */
+typedef struct olsr_loss_params {
+  int32_t width, height;
+  int32_t F;                       /* language channels (0: none) */
+  int32_t lang_width, lang_height; /* size of gt_language (192 x 192 in the reference) */
+  int32_t initialization;          /* != 0: skip the exposure transform (get_loss_mapping, :125-126) */
+  float alpha;                     /* config["Training"]["alpha"], default 0.95 */
+  float rgb_boundary_threshold;    /* config["Training"]["rgb_boundary_threshold"] */
+  float lamda_lang;                /* BackEnd.lamda_lang (1.0), utils/slam_backend.py:80 */
+  int32_t _pad0;
+} olsr_loss_params;
+size_t olsr_mapping_loss_scratch_bytes(int32_t width, int32_t height);
+int olsr_mapping_loss(const olsr_loss_params *params, const float *image, const float *depth,
+                      const float *language, const float *gt_image, const float *gt_depth,
+                      const float *gt_language, const float *exposure,
+                      float *dL_dimage, float *dL_ddepth, float *dL_dlanguage,
+                      float *loss, float *dL_dexposure, void *scratch, void *hip_stream);
+
 /* Adds one view's per-Gaussian gradients into the flat fp32 buffer
  *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]
  * that a frame-sharded trainer all-reduces once per optimisation step, and updates the

@@ -64,6 +64,14 @@ class OlsrGradBucket(C.Structure):
     _fields_ = [("flat", _fp), ("densify", _fp), ("max_radii", _fp), ("assign", C.c_int32), ("_pad0", C.c_int32)]
 
 
+class OlsrLossParams(C.Structure):
+    """struct olsr_loss_params, include/olsr.h."""
+
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("F", C.c_int32), ("lang_width", C.c_int32),
+                ("lang_height", C.c_int32), ("initialization", C.c_int32), ("alpha", C.c_float),
+                ("rgb_boundary_threshold", C.c_float), ("lamda_lang", C.c_float), ("_pad0", C.c_int32)]
+
+
 def _ptr(t):
     """data_ptr of a tensor, or None for an absent (None / empty) one — the reference maps
     empty tensors to nullptr the same way (contiguous().data<float>() of a 0-element tensor,

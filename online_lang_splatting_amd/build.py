@@ -29,6 +29,7 @@ UNITS = [
     ("k_render_bwd.hip", "k_render_bwd_exact.o", ["-DOLSR_BWD_TU_MODE=1"]),
     ("k_preprocess_bwd.hip", "k_preprocess_bwd.o", []),
     ("k_accumulate.hip", "k_accumulate.o", []),
+    ("k_loss.hip", "k_loss.o", []),
 ]
 HEADERS = ["olsr_device.h", "olsr_state.h", "olsr_kernels.h", os.path.join("..", "..", "include", "olsr.h")]
 

@@ -347,6 +347,33 @@ int olsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
   return OLSR_OK;
 }
 
+size_t olsr_mapping_loss_scratch_bytes(int32_t width, int32_t height) {
+  if (width <= 0 || height <= 0) return ALIGN;
+  return (size_t)loss_blocks(width, height) * 5 * sizeof(float) + ALIGN;
+}
+
+int olsr_mapping_loss(const olsr_loss_params* params, const float* image, const float* depth, const float* language,
+                      const float* gt_image, const float* gt_depth, const float* gt_language, const float* exposure,
+                      float* dL_dimage, float* dL_ddepth, float* dL_dlanguage, float* loss, float* dL_dexposure,
+                      void* scratch, void* hip_stream) {
+  if (!params) return fail(OLSR_ERR_ARG, "loss params are NULL");
+  const olsr_loss_params& p = *params;
+  if (p.width <= 0 || p.height <= 0) return fail(OLSR_ERR_ARG, "image size must be positive");
+  if (!supported_F(p.F)) return fail(OLSR_ERR_ARG, "F (language channels) must be one of 0, 3, 15, 16, 32");
+  if (!image || !depth || !gt_image || !gt_depth || !dL_dimage || !dL_ddepth || !loss || !scratch)
+    return fail(OLSR_ERR_ARG, "image, depth, their targets, their gradient outputs, loss and scratch are required");
+  if (p.F > 0 && (!language || !dL_dlanguage)) return fail(OLSR_ERR_ARG, "language and dL_dlanguage are required when F > 0");
+  if (p.F > 0 && gt_language && (p.lang_width <= 0 || p.lang_height <= 0))
+    return fail(OLSR_ERR_ARG, "the language target size must be positive");
+  hipStream_t st = (hipStream_t)hip_stream;
+  float* partials = (float*)(((uintptr_t)scratch + ALIGN - 1) / ALIGN * ALIGN);
+  launch_mapping_loss(p, image, depth, language, gt_image, gt_depth, p.F > 0 ? gt_language : nullptr, exposure, dL_dimage,
+                      dL_ddepth, dL_dlanguage, loss, dL_dexposure, partials, st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("mapping_loss launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
 int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, int32_t assign, const float* dL_dmeans3D,
                               const float* dL_dsh,
                               const float* dL_dopacity, const float* dL_dscales, const float* dL_drotations,

@@ -79,4 +79,11 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
                        const float* dmeans2D, const int32_t* radii, float* flat, float* densify, int32_t* max_radii,
                        hipStream_t st);
 
+// k_loss.hip
+int loss_blocks(int W, int H);
+void launch_mapping_loss(const olsr_loss_params& p, const float* image, const float* depth, const float* language,
+                         const float* gt_image, const float* gt_depth, const float* gt_language, const float* exposure,
+                         float* dL_dimage, float* dL_ddepth, float* dL_dlanguage, float* loss, float* dL_dexposure,
+                         float* partials, hipStream_t st);
+
 }  // namespace olsr

@@ -1,0 +1,130 @@
+"""olsr_mapping_loss (HIP, through the C-ABI) against the CPU oracle and the reference-generated golden
+vectors.  Tolerance: the per-pixel gradients are products of exact signs / masks and constants (a few ulp);
+the scalar sums are accumulated in a different order than torch's (block trees, final add in double):
+1e-5 relative is asserted, ~1e-7 is observed."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import loss_oracle  # noqa: E402
+from test_loss_oracle_golden import golden_cases, run_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL = 1e-5
+
+
+def _close(a, b, name, atol_scale=1.0):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max())
+    assert err <= RTOL * scale * atol_scale, f"{name}: abs {err:.3e} vs scale {scale:.3e}"
+
+
+def _run_hip(c, hip_losses, **kw):
+    dev = torch.device(DEV)
+    mv = lambda t: None if t is None else t.to(dev)
+    exposure = None if c.get("a") is None else torch.cat([c["a"].reshape(1), c["b"].reshape(1)]).float().to(dev)
+    return hip_losses.mapping_loss(mv(c["image"]), mv(c["depth"]), mv(c.get("lang")), mv(c["gt_image"]), mv(c["gt_depth"]),
+                                   mv(c.get("gt_lang")), exposure, **kw)
+
+
+def test_golden_vectors_from_the_reference(hip):
+    from online_lang_splatting_amd import losses
+    for c in golden_cases():
+        o = _run_hip(c, losses, alpha=float(c["alpha"]), rgb_boundary_threshold=float(c["thr"]), lamda_lang=1.0,
+                     initialization=bool(int(c["init"])))
+        _close(o["loss"][0], c["loss"], "loss")
+        _close(o["loss"][1] + o["loss"][2], c["loss_map"], "loss_map")
+        _close(o["loss"][3], c["loss_lang"], "loss_lang")
+        _close(o["dL_dimage"], c["d_image"], "dL_dimage")
+        _close(o["dL_ddepth"], c["d_depth"], "dL_ddepth")
+        _close(o["dL_dlanguage"], c["d_lang"], "dL_dlanguage")
+        # exposure gradients are sums of +-1 over ~1e3 pixels with heavy cancellation: compare on the scale of
+        # the sum of magnitudes (alpha / 3 here), not of the cancelled result
+        assert abs(float(o["dL_dexposure"][0]) - float(c["d_a"])) <= 1e-6
+        assert abs(float(o["dL_dexposure"][1]) - float(c["d_b"])) <= 1e-6
+        # decisions are exact: the zero pattern (masks, ties) is identical
+        assert torch.equal(o["dL_dimage"].cpu() == 0, c["d_image"] == 0)
+        assert torch.equal(o["dL_ddepth"].cpu() == 0, c["d_depth"] == 0)
+        assert torch.equal(o["dL_dlanguage"].cpu() == 0, c["d_lang"] == 0)
+
+
+@pytest.mark.parametrize("F,H,W,lh,lw", [(15, 680, 1200, 192, 192), (32, 135, 241, 192, 192), (0, 97, 33, 0, 0),
+                                         (16, 64, 64, 64, 64), (3, 50, 70, 200, 300)])
+def test_against_the_oracle(hip, F, H, W, lh, lw):
+    """Full-size config 3 frame (1200x680, 15 channels, 192x192 target as in the reference), ragged sizes,
+    every supported F, identity-size and down-sampled targets."""
+    from online_lang_splatting_amd import losses
+    g = torch.Generator().manual_seed(F + H)
+    c = dict(image=torch.rand(3, H, W, generator=g), depth=torch.rand(1, H, W, generator=g) * 5,
+             lang=torch.randn(F, H, W, generator=g) * 0.3 if F else None, gt_image=torch.rand(3, H, W, generator=g),
+             gt_depth=torch.rand(H, W, generator=g) * 5, gt_lang=torch.randn(F, lh, lw, generator=g) * 0.3 if F else None,
+             a=torch.tensor([0.11]), b=torch.tensor([-0.03]))
+    c["gt_image"][:, : H // 3] *= 0.001
+    c["gt_depth"][:, : W // 4] = 0.0
+    kw = dict(alpha=0.95, rgb_boundary_threshold=0.01, lamda_lang=1.0)
+    ref = loss_oracle.mapping_loss_and_grads(c["image"], c["depth"], c["lang"], c["gt_image"], c["gt_depth"], c["gt_lang"],
+                                             c["a"], c["b"], **kw)
+    o = _run_hip(c, losses, **kw)
+    _close(o["loss"][0], ref["loss"], "loss")
+    _close(o["loss"][1], ref["rgb"], "rgb")
+    _close(o["loss"][2], ref["depth"], "depth")
+    _close(o["dL_dimage"], ref["dL_dimage"], "dL_dimage")
+    _close(o["dL_ddepth"], ref["dL_ddepth"], "dL_ddepth")
+    if F:
+        _close(o["loss"][3], ref["lang"], "lang")
+        # a bilinear sample that lands within rounding of the rendered value flips a sign: allow a handful
+        d = (o["dL_dlanguage"].cpu() - ref["dL_dlanguage"]).abs()
+        bad = int((d > RTOL * float(ref["dL_dlanguage"].abs().max())).sum())
+        assert bad <= 3, bad
+    assert abs(float(o["dL_dexposure"][0]) - float(ref["dL_da"])) <= 2e-6
+    assert abs(float(o["dL_dexposure"][1]) - float(ref["dL_db"])) <= 2e-6
+    # without a language target the language cotangent is zero-filled; initialization skips the exposure
+    c2 = dict(c, gt_lang=None)
+    o2 = _run_hip(c2, losses, initialization=True, **kw)
+    ref2 = loss_oracle.mapping_loss_and_grads(c["image"], c["depth"], c["lang"], c["gt_image"], c["gt_depth"], None,
+                                              c["a"], c["b"], initialization=True, **kw)
+    _close(o2["loss"][0], ref2["loss"], "loss (init)")
+    _close(o2["dL_dimage"], ref2["dL_dimage"], "dL_dimage (init)")
+    assert float(o2["dL_dlanguage"].abs().max()) == 0 if F else True
+    assert float(o2["dL_dexposure"].abs().max()) == 0
+
+
+def test_loss_feeds_the_rasterizer_backward(hip):
+    """End to end on the GPU: render -> olsr_mapping_loss -> olsr_backward; the cotangents are consumed as they
+    are, and a finite-difference step along the gradient of the opacities decreases the loss."""
+    from online_lang_splatting_amd import losses
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    from online_lang_splatting_amd.scene import make_scene
+    dev = torch.device(DEV)
+    sc = make_scene(5000, 160, 120, 15, seed=17)
+    cam = sc.camera
+    ws = RasterWorkspace(sc.P, 160, 120, 15, sc.shs.shape[1], 300000, dev)
+    g = torch.Generator().manual_seed(3)
+    gt_image, gt_depth = torch.rand(3, 120, 160, generator=g).to(dev), (torch.rand(120, 160, generator=g) * 4).to(dev)
+    gt_lang = (torch.randn(15, 48, 48, generator=g) * 0.3).to(dev)
+    kw = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), scales=sc.scales.to(dev), rotations=sc.rotations.to(dev),
+              shs=sc.shs.to(dev), language=sc.language.to(dev), viewmatrix=cam.world_view_transform.to(dev),
+              projmatrix=cam.full_proj_transform.to(dev), projmatrix_raw=cam.projection_matrix.to(dev),
+              campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+
+    def loss_at(op):
+        ws.set_scene(opacities=op, **kw)
+        out = ws.forward()
+        lo = losses.mapping_loss(out["color"], out["depth"], out["language"], gt_image, gt_depth, gt_lang)
+        return out, lo
+
+    op0 = sc.opacities.to(dev)
+    out, lo = loss_at(op0)
+    grads = ws.backward(lo["dL_dimage"], lo["dL_dlanguage"], lo["dL_ddepth"])
+    gop = grads["dL_dopacity"].reshape(op0.shape).clone()
+    assert bool(torch.isfinite(gop).all()) and float(gop.abs().max()) > 0
+    l0 = float(lo["loss"][0])
+    step = 0.02 / float(gop.abs().max())
+    _, lo1 = loss_at((op0 - step * gop).clamp(1e-4, 1 - 1e-4))
+    assert float(lo1["loss"][0]) < l0
