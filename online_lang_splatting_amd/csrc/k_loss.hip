@@ -30,7 +30,32 @@ __device__ __forceinline__ void bilinear_index(int dst, float scale, int in_size
   l0 = 1.f - l1;
 }
 
-template <int F>
+// VEC consecutive pixels of one row per thread (VEC = 4 when W % 4 == 0: 16-byte loads and stores on
+// every plane; VEC = 1 otherwise).
+template <int VEC>
+struct PixVec {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ PixVec<VEC> load_px(const float* __restrict__ plane, size_t p) {
+  PixVec<VEC> r;
+  if constexpr (VEC == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(plane + p);
+    r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+  } else {
+    r.v[0] = plane[p];
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void store_px(float* __restrict__ plane, size_t p, const PixVec<VEC>& r) {
+  if constexpr (VEC == 4)
+    *reinterpret_cast<float4*>(plane + p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  else
+    plane[p] = r.v[0];
+}
+
+template <int F, int VEC>
 __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
     int W, int H, int lw, int lh, int use_exposure, float alpha, float thr, float lamda,
     const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ lang,
@@ -38,57 +63,80 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
     const float* __restrict__ exposure, float* __restrict__ d_image, float* __restrict__ d_depth,
     float* __restrict__ d_lang, float* __restrict__ partials) {
   const size_t HW = (size_t)H * W;
-  const size_t p = (size_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
+  const size_t p = ((size_t)blockIdx.x * LOSS_THREADS + threadIdx.x) * VEC;  // first pixel of this thread
   float s[LOSS_SUMS] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (p < HW) {
     const float ea = use_exposure ? expf(exposure[0]) : 1.f;
     const float eb = use_exposure ? exposure[1] : 0.f;
     // ---- RGB: |m * (e^a image + b) - m * gt|, utils/slam_utils.py:125-127,143-146
-    const float g0 = gt_image[p], g1 = gt_image[HW + p], g2 = gt_image[2 * HW + p];
-    const float m = ((g0 + g1) + g2 > thr) ? 1.f : 0.f;
+    PixVec<VEC> gt[3], m;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gt[c] = load_px<VEC>(gt_image + c * HW, p);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) m.v[i] = ((gt[0].v[i] + gt[1].v[i]) + gt[2].v[i] > thr) ? 1.f : 0.f;
     const float wrgb = alpha / (3.0f * (float)HW);
-    const float gts[3] = {g0, g1, g2};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float x = image[c * HW + p];
-      const float ab = use_exposure ? ea * x + eb : x;
-      const float v = ab * m - gts[c] * m;
-      s[0] += fabsf(v);
-      const float dab = sgn(v) * m;  // d|v| / d(image_ab)
-      d_image[c * HW + p] = wrgb * dab * ea;
-      s[3] += dab * (ea * x);        // d(image_ab)/da = e^a image
-      s[4] += dab;
+      const PixVec<VEC> x = load_px<VEC>(image + c * HW, p);
+      PixVec<VEC> d;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float ab = use_exposure ? ea * x.v[i] + eb : x.v[i];
+        const float v = ab * m.v[i] - gt[c].v[i] * m.v[i];
+        s[0] += fabsf(v);
+        const float dab = sgn(v) * m.v[i];  // d|v| / d(image_ab)
+        d.v[i] = wrgb * dab * ea;
+        s[3] += dab * (ea * x.v[i]);        // d(image_ab)/da = e^a image
+        s[4] += dab;
+      }
+      store_px<VEC>(d_image + c * HW, p, d);
     }
     // ---- depth: |m_d * depth - m_d * gt_depth|, :144,147
     {
-      const float gd = gt_depth[p];
-      const float md = (gd > 0.01f) ? 1.f : 0.f;
-      const float v = depth[p] * md - gd * md;
-      s[1] += fabsf(v);
-      d_depth[p] = (1.f - alpha) / (float)HW * sgn(v) * md;
+      const PixVec<VEC> gd = load_px<VEC>(gt_depth, p), x = load_px<VEC>(depth, p);
+      PixVec<VEC> d;
+      const float wd = (1.f - alpha) / (float)HW;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float md = (gd.v[i] > 0.01f) ? 1.f : 0.f;
+        const float v = x.v[i] * md - gd.v[i] * md;
+        s[1] += fabsf(v);
+        d.v[i] = wd * sgn(v) * md;
+      }
+      store_px<VEC>(d_depth, p, d);
     }
     // ---- language: |language - bilinear(gt_language)|, utils/slam_backend.py:579-590
     if constexpr (F > 0) {
       const int x = (int)(p % (size_t)W), y = (int)(p / (size_t)W);
       if (gt_lang != nullptr) {
-        int x0, x1, y0, y1;
-        float lx0, lx1, ly0, ly1;
-        bilinear_index(x, (float)lw / (float)W, lw, x0, x1, lx0, lx1);
+        int x0[VEC], x1[VEC], y0, y1;
+        float lx0[VEC], lx1[VEC], ly0, ly1;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) bilinear_index(x + i, (float)lw / (float)W, lw, x0[i], x1[i], lx0[i], lx1[i]);
         bilinear_index(y, (float)lh / (float)H, lh, y0, y1, ly0, ly1);
         const float wl = lamda / ((float)F * (float)HW);
         const size_t plane = (size_t)lh * lw;
-#pragma unroll 5
+#pragma unroll 3
         for (int c = 0; c < F; ++c) {
-          const float* g = gt_lang + c * plane;
-          const float t = ly0 * (lx0 * g[(size_t)y0 * lw + x0] + lx1 * g[(size_t)y0 * lw + x1]) +
-                          ly1 * (lx0 * g[(size_t)y1 * lw + x0] + lx1 * g[(size_t)y1 * lw + x1]);
-          const float v = lang[c * HW + p] - t;
-          s[2] += fabsf(v);
-          d_lang[c * HW + p] = wl * sgn(v);
+          const float* g0 = gt_lang + c * plane + (size_t)y0 * lw;
+          const float* g1 = gt_lang + c * plane + (size_t)y1 * lw;
+          const PixVec<VEC> l = load_px<VEC>(lang + c * HW, p);
+          PixVec<VEC> d;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float t = ly0 * (lx0[i] * g0[x0[i]] + lx1[i] * g0[x1[i]]) + ly1 * (lx0[i] * g1[x0[i]] + lx1[i] * g1[x1[i]]);
+            const float v = l.v[i] - t;
+            s[2] += fabsf(v);
+            d.v[i] = wl * sgn(v);
+          }
+          store_px<VEC>(d_lang + c * HW, p, d);
         }
       } else {
-#pragma unroll 5
-        for (int c = 0; c < F; ++c) d_lang[c * HW + p] = 0.f;
+        PixVec<VEC> z;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) z.v[i] = 0.f;
+#pragma unroll 3
+        for (int c = 0; c < F; ++c) store_px<VEC>(d_lang + c * HW, p, z);
       }
     }
   }
@@ -152,20 +200,30 @@ void launch_mapping_loss(const olsr_loss_params& p, const float* image, const fl
                          const float* gt_image, const float* gt_depth, const float* gt_language, const float* exposure,
                          float* dL_dimage, float* dL_ddepth, float* dL_dlanguage, float* loss, float* dL_dexposure,
                          float* partials, hipStream_t st) {
-  const int nb = loss_blocks(p.width, p.height);
+  // 16-byte path: planes are [C][H][W], so with W % 4 == 0 every plane and row stays 16-byte aligned if the
+  // base pointers are
+  auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15u) == 0; };
+  const bool vec4 = (p.width % 4) == 0 && al16(image) && al16(depth) && al16(language) && al16(gt_image) &&
+                    al16(gt_depth) && al16(dL_dimage) && al16(dL_ddepth) && al16(dL_dlanguage);
+  const size_t threads = ((size_t)p.width * p.height + (vec4 ? 3 : 0)) / (vec4 ? 4 : 1);
+  const int nb = (int)((threads + LOSS_THREADS - 1) / LOSS_THREADS);  // <= loss_blocks(): the scratch is sized for VEC = 1
   const int use_exposure = (exposure != nullptr && !p.initialization) ? 1 : 0;
-#define OLSR_LOSS(FV)                                                                                                  \
-  case FV:                                                                                                             \
-    mapping_loss_kernel<FV><<<nb, LOSS_THREADS, 0, st>>>(p.width, p.height, p.lang_width, p.lang_height, use_exposure, \
-                                                         p.alpha, p.rgb_boundary_threshold, p.lamda_lang, image, depth, \
-                                                         language, gt_image, gt_depth, gt_language, exposure, dL_dimage, \
-                                                         dL_ddepth, dL_dlanguage, partials);                           \
+#define OLSR_LOSS_ARGS                                                                                           \
+  p.width, p.height, p.lang_width, p.lang_height, use_exposure, p.alpha, p.rgb_boundary_threshold, p.lamda_lang, \
+      image, depth, language, gt_image, gt_depth, gt_language, exposure, dL_dimage, dL_ddepth, dL_dlanguage, partials
+#define OLSR_LOSS(FV)                                                                   \
+  case FV:                                                                              \
+    if (vec4)                                                                           \
+      mapping_loss_kernel<FV, 4><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);          \
+    else                                                                                \
+      mapping_loss_kernel<FV, 1><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);          \
     break;
   switch (p.F) {
     OLSR_LOSS(0) OLSR_LOSS(3) OLSR_LOSS(15) OLSR_LOSS(16) OLSR_LOSS(32)
     default: break;
   }
 #undef OLSR_LOSS
+#undef OLSR_LOSS_ARGS
   mapping_loss_final_kernel<<<1, 256, 0, st>>>(partials, nb, p.width, p.height, p.F, gt_language != nullptr ? 1 : 0,
                                                p.alpha, p.lamda_lang, loss, use_exposure ? dL_dexposure : nullptr);
   if (!use_exposure && dL_dexposure) (void)hipMemsetAsync(dL_dexposure, 0, 2 * sizeof(float), st);
