@@ -477,7 +477,10 @@ void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g
 // Exclusive scan of popcount(flags[u] & 15) — how many slot rows each instance owns.  Same
 // three-kernel scan as above, specialised so that a thread fetches its 16 flag bytes with ONE
 // 16-byte load (the flag array is 256-byte aligned and padded to a multiple of 16).
-__device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, int64_t base, int64_t n, u32 (&v)[16]) {
+// rows per instance = popcount((flag >> shift) & mask): shift 0 / mask 15 = one row per forward slot,
+// shift 4 / mask 3 = one row per packed survivor wave (reference mode, 15x15 tiles)
+__device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, int64_t base, int64_t n, int shift,
+                                            u32 mask, u32 (&v)[16]) {
   uint4 q = make_uint4(0u, 0u, 0u, 0u);
   if (base + 16 <= n) {
     q = *reinterpret_cast<const uint4*>(flags + base);
@@ -489,17 +492,17 @@ __device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, i
   }
   const u32 w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = (u32)__popc((w4[k >> 2] >> (8 * (k & 3))) & 0xFu);
+  for (int k = 0; k < 16; ++k) v[k] = (u32)__popc((w4[k >> 2] >> (8 * (k & 3) + shift)) & mask);
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void popc_reduce_kernel(const uint8_t* __restrict__ flags, int64_t n_host,
-                                                                  const int32_t* __restrict__ n_dev,
-                                                                  u32* __restrict__ partials) {
+                                                                  const int32_t* __restrict__ n_dev, int shift,
+                                                                  u32 mask, u32* __restrict__ partials) {
   static_assert(SCAN_ITEMS == 16, "one 16-byte load per thread");
   const int64_t n = bounded_n(n_host, n_dev);  // flags beyond the instances of this frame are stale
   const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
   u32 v[16];
-  load_popc16(flags, base, n, v);
+  load_popc16(flags, base, n, shift, mask, v);
   u32 s = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s += v[k];
@@ -509,13 +512,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void popc_reduce_kernel(const uint8_t
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t* __restrict__ flags, int64_t n_host,
-                                                                 const int32_t* __restrict__ n_dev,
-                                                                 const u32* __restrict__ partials,
+                                                                 const int32_t* __restrict__ n_dev, int shift,
+                                                                 u32 mask, const u32* __restrict__ partials,
                                                                  u32* __restrict__ out) {
   const int64_t n = bounded_n(n_host, n_dev);
   const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
   u32 v[16];
-  load_popc16(flags, base, n, v);
+  load_popc16(flags, base, n, shift, mask, v);
   u32 s = 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s += v[k];
@@ -557,9 +560,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* 
   }
 }
 
-void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, uint32_t* rowbase,
-                           uint32_t* partials, int64_t row_capacity, int32_t* counters, int32_t* status_dev,
-                           hipStream_t st) {
+void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, bool packed_ref15,
+                           uint32_t* rowbase, uint32_t* partials, int64_t row_capacity, int32_t* counters,
+                           int32_t* status_dev, hipStream_t st) {
+  const int shift = packed_ref15 ? 4 : 0;
+  const u32 mask = packed_ref15 ? 3u : 15u;
   if (n_host <= 0) {
     (void)hipMemsetAsync(rowbase, 0, sizeof(u32), st);
     (void)hipMemsetAsync(counters + 4, 0, 4 * sizeof(int32_t), st);
@@ -567,8 +572,8 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
     return;
   }
   const int nb = scan_blocks(n_host);
-  popc_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, partials);
-  popc_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, partials, rowbase);
+  popc_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, partials);
+  popc_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, partials, rowbase);
   rows_finalize_kernel<<<1, SCAN_THREADS, 0, st>>>(partials, nb, n_host, n_dev, rowbase, (long long)row_capacity,
                                                    counters, status_dev);
 }

@@ -54,8 +54,11 @@ __device__ __forceinline__ bool ref_survives(int rank) {
 
 constexpr int BWD_BATCH = 128;
 
-template <int TILE, int F, int MODE>
-__global__ __launch_bounds__(256) void render_bwd_kernel(
+// PACKED (reference mode, 15x15 tiles): the workgroup is the 128 survivors of the reference's reduction
+// tree in two full waves (ref15_rank_of_packed); the 97 other pixels of the tile are not evaluated at all —
+// nothing they compute reaches an output of the reference's backward.
+template <int TILE, int F, int MODE, bool PACKED>
+__global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
     const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src,
     const uint8_t* __restrict__ flags, const u32* __restrict__ rowbase, const int32_t* __restrict__ counters,
     const u32* __restrict__ tile_order, int W, int H, int gx, int ntiles, const float* __restrict__ bg,
@@ -76,14 +79,17 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   constexpr int F2 = (F + 1) / 2;        // packed pairs of language channels
   constexpr int F2X = (F2 > 0) ? F2 : 1;
   constexpr int B = BWD_BATCH;
+  constexpr int NT = PACKED ? 128 : 256;  // threads
+  constexpr int NWV = NT / 64;            // waves
   static_assert(ROW <= 64, "one lane per row element");
+  static_assert(!PACKED || (REF && TILE == 15), "survivor packing is the reference mode of 15x15 tiles");
 
   __shared__ float2 s_xy[B];
   __shared__ float4 s_co[B];
   __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
   __shared__ u32 s_row[B];   // first compact row of the instance
   __shared__ u32 s_flag[B];
-  __shared__ int s_kmax[4];
+  __shared__ int s_kmax[NWV];
 
   // workgroup b runs on XCD b % 8 and takes the (b / 8)-th heaviest tile of that XCD's chunk
   const int tile_id = (int)tile_order[xcd_remap((int)blockIdx.x, ntiles)];
@@ -107,10 +113,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   //   accum_rec_F <- last_alpha * last_F + (1 - last_alpha) * accum_rec_F     (CR/backward.cu:1132)
   // becomes A <- last_alpha * D_last + (1 - last_alpha) * A and the contribution is D - A.
   // Algebraically identical, 2 registers per pixel instead of 2F.
-  const int rank = tid;
+  const int rank = PACKED ? ref15_rank_of_packed(tid) : tid;
   const int px = bx * TILE + rank % TILE, py = by * TILE + rank / TILE;
   const bool inside = (rank < BS) && (px < W) && (py < H);
-  const bool surv = REF ? ref_survives<TILE>(rank) : true;
+  const bool surv = (REF && !PACKED) ? ref_survives<TILE>(rank) : true;
   const float pixfx = (float)px, pixfy = (float)py;
   const size_t pix = (size_t)W * py + px;
   const float T_final = inside ? final_Ts[pix] : 0.f;
@@ -169,7 +175,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
   for (int m = 32; m >= 1; m >>= 1) kmax = max(kmax, __shfl_xor(kmax, m));
   if (lane == 0) s_kmax[w] = kmax;
   __syncthreads();
-  kmax = max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
+  kmax = s_kmax[0];
+#pragma unroll
+  for (int k = 1; k < NWV; ++k) kmax = max(kmax, s_kmax[k]);
 
   for (int kstart = kmax - 1; kstart >= 0; kstart -= B) {
     const int cnt = min(B, kstart + 1);
@@ -180,12 +188,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
         const u32 sp = r0 + (u32)(kstart - e);
         const u32 u = src[sp];        // emission index of the instance
         const u32 gid = inst_gid[u];  // its Gaussian
-        if (tid < B) {
+        if (PACKED || tid < B) {
           s_row[e] = rowbase[u];
           s_flag[e] = flags[u];
           s_xy[e] = reinterpret_cast<const float2*>(means2D)[gid];
           s_co[e] = reinterpret_cast<const float4*>(conic_opacity)[gid];
-        } else {
+        }
+        if (PACKED || tid >= B) {
           float* fr = &s_feat[e * FR];
           fr[0] = colors[3 * (size_t)gid + 0];
           fr[1] = colors[3 * (size_t)gid + 1];
@@ -203,8 +212,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     // From here to the next batch the four waves run independently: no barrier per splat.
     for (int i = 0; i < cnt; ++i) {
       const u32 fl = s_flag[i];
-      if (fl == 0) continue;  // whole tile skips this splat: no state changes (CR/backward.cu:1091-1093)
-      const bool mine = (fl >> w) & 1u;  // did any pixel of THIS wave's slot blend it in the forward?
+      if ((fl & 15u) == 0) continue;  // whole tile skips this splat: no state changes (CR/backward.cu:1091-1093)
+      // did any pixel of THIS wave blend it in the forward?  (bits 0-3: the forward's slots; bits 4-5: the
+      // packed survivor waves)
+      const bool mine = (fl >> (PACKED ? 4 + w : w)) & 1u;
       if (!REF && !mine) continue;
       const float* fr = &s_feat[i * FR];
       float D_cur = 0.f;
@@ -333,7 +344,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
         rowval = lang_lane ? dcd0 * dLf0_lane : rowval;
       }
       // compact row index: rows of an instance are consecutive, one per set slot bit
-      if (role >= 0) rows[((size_t)s_row[i] + (u32)__popc(fl & ((1u << w) - 1u))) * ROW + role] = rowval;
+      const u32 before = PACKED ? ((fl >> 4) & (u32)w) : (u32)__popc(fl & ((1u << w) - 1u));  // rows of earlier waves
+      if (role >= 0) rows[((size_t)s_row[i] + before) * ROW + role] = rowval;
     }
   }
 }
@@ -343,7 +355,8 @@ static void launch_bwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                          const ImageState& im, const float* dc, const float* dl, const float* dd, float* rows,
                          hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
-  render_bwd_kernel<TILE, F, MODE><<<d.ntiles, 256, 0, st>>>(
+  constexpr bool PACKED = (MODE == OLSR_BWD_REFERENCE && TILE == 15);
+  render_bwd_kernel<TILE, F, MODE, PACKED><<<d.ntiles, PACKED ? 128 : 256, 0, st>>>(
       im.ranges, b.inst_gid, b.src, b.flags, b.rowbase, g.counters, im.tile_order, d.W, d.H, d.gx, d.ntiles,
       s.background,
       g.means2D, g.conic_opacity, colors, s.language_precomp, g.depths, im.final_T, im.n_contrib, dc, dl, dd, rows);

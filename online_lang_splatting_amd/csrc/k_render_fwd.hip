@@ -15,7 +15,8 @@
 //   * n_touched is counted with per-wave popcounts (each wave owns one byte of the splat's LDS
 //     record: no LDS atomics) and ONE global integer atomic per (splat, batch);
 //   * the kernel records, per (tile, splat) instance, WHICH 64-pixel slots blended it
-//     (flags[] bit w, indexed by emission position).  The backward composite visits only those
+//     (flags[] bits 0-3, indexed by emission position; bits 4-5 say the same for the two packed waves of
+//     the reference-mode backward, see ref15_survives in olsr_device.h).  The backward composite visits only those
 //     (instance, slot) pairs, and "flags != 0" is exactly the tile-wide
 //     skip_counter != BLOCK_SIZE predicate of CR/backward.cu:1087-1093.
 // Per-pixel arithmetic keeps the reference's operation order (see olsr_device.h), so the
@@ -49,6 +50,9 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   // per staged splat, one byte per wave: bit 7 = the wave's slot blended it, bits 0-6 = how many of its
   // pixels counted it as touched (<= 64); each wave writes only its own byte
   __shared__ u32 s_hit[B];
+  // same layout, for the reference-mode backward (15x15 tiles): bit b of wave w's byte = a pixel of this wave
+  // that SURVIVES the reference's reduction tree and belongs to backward wave b blended the splat
+  __shared__ u32 s_cls[B];
   __shared__ u32 s_work;
 
   const int tile_id = xcd_remap((int)blockIdx.x, ntiles);
@@ -63,6 +67,11 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   const bool inside = (rank < BS) && (px < W) && (py < H);
   const float pixfx = (float)px, pixfy = (float)py;
   bool done = !inside;
+  // backward wave (0 / 1) of this pixel among the survivors of the reference's tree, 2 = not a survivor
+  int cls = 2;
+  if constexpr (TILE == 15) {
+    if (rank < BS && ref15_survives(rank)) cls = ref15_packed_of_rank(rank) >> 6;
+  }
   if (tid == 0) s_work = 0;
   u32 my_work = 0;  // live (instance, slot) pairs flushed by this thread
   float T = 1.0f;
@@ -87,6 +96,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
           s_id[e] = gid;
           s_src[e] = u;
           s_hit[e] = 0;
+          s_cls[e] = 0;
           const float2 m = reinterpret_cast<const float2*>(means2D)[gid];
           const float4 c = reinterpret_cast<const float4*>(conic_opacity)[gid];
           // alpha = o * exp(power) can only reach 1/255 if power >= -ln(255 o).  Keep a margin far
@@ -144,6 +154,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
         if (cb != 0ull) {
           const u32 tc = (u32)__popcll(ballot(contrib && test_T > 0.5f));
           if ((tid & 63) == 0) reinterpret_cast<uint8_t*>(s_hit)[4 * j + w] = (uint8_t)(0x80u | tc);
+          if constexpr (TILE == 15) {
+            const u32 cb01 = (ballot(contrib && cls == 0) ? 1u : 0u) | (ballot(contrib && cls == 1) ? 2u : 0u);
+            if ((tid & 63) == 0 && cb01) reinterpret_cast<uint8_t*>(s_cls)[4 * j + w] = (uint8_t)cb01;
+          }
         }
         if (wave_all(done)) break;
       }
@@ -152,7 +166,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
     if (tid < cnt) {
       const u32 hit = s_hit[tid];
       const u32 fl = ((hit >> 7) & 1u) | ((hit >> 14) & 2u) | ((hit >> 21) & 4u) | ((hit >> 28) & 8u);
-      if (fl) flags[s_src[tid]] = (uint8_t)fl;
+      // bits 0-3: forward slots that blended it; bits 4-5: backward waves of the reference-mode survivors
+      const u32 cl = s_cls[tid];
+      const u32 cl2 = (cl | (cl >> 8) | (cl >> 16) | (cl >> 24)) & 3u;
+      if (fl) flags[s_src[tid]] = (uint8_t)(fl | (cl2 << 4));
       my_work += (u32)__popc(fl);
       // tc of a wave is <= 64 = 0x40: with bit 7 set a full wave reads 0xC0, so mask 0x7F keeps all 7 bits
       const u32 tc = (hit & 0x7Fu) + ((hit >> 8) & 0x7Fu) + ((hit >> 16) & 0x7Fu) + ((hit >> 24) & 0x7Fu);

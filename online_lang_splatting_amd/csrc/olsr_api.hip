@@ -301,7 +301,8 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, bb);
 
   // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended
-  launch_row_compaction(b.flags, num_rendered, &g.counters[1], b.rowbase, b.scan_partials,
+  const bool packed_ref15 = (s.bwd_mode == OLSR_BWD_REFERENCE && s.tile == 15);
+  launch_row_compaction(b.flags, num_rendered, &g.counters[1], packed_ref15, b.rowbase, b.scan_partials,
                         scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, status_dev, st);
   STAGE("row_compaction");
   if (scratch_alloc) {

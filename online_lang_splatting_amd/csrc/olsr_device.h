@@ -355,6 +355,26 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return start + k;
 }
 
+// ---- the ranks that survive the reference's 225-lane reduction tree ---------------------------
+// render_cuda_reduce_sum halves g.size() = 225 with integer division (CR/backward.cu:691-702): the steps
+// 112, 56, 28, 14, 7, 3, 1 drop rank 224 and every rank whose residue mod 7 is 2, 5 or 6.  Exactly
+// 128 ranks reach element 0; everything the other 97 pixels compute in the reference's backward is
+// discarded (and its language gradient only ever comes from rank 0, a survivor).  So in reference
+// mode the backward composite runs on the survivors alone, packed into two full waves:
+//   packed index s in [0, 128)  <->  rank = 7 * (s / 4) + {0, 1, 3, 4}[s % 4].
+__device__ __forceinline__ bool ref15_survives(int rank) {
+  const int m = rank % 7;
+  return rank < 224 && (m == 0 || m == 1 || m == 3 || m == 4);
+}
+__device__ __forceinline__ int ref15_rank_of_packed(int s) {
+  const int k = s & 3;
+  return 7 * (s >> 2) + k + (k >> 1);  // 0, 1, 3, 4
+}
+__device__ __forceinline__ int ref15_packed_of_rank(int rank) {  // survivors only
+  const int m = rank % 7;
+  return 4 * (rank / 7) + m - (m >= 3 ? 1 : 0);  // 0->0, 1->1, 3->2, 4->3
+}
+
 constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // staged per-Gaussian feature row: [r, g, b, depth, lang[F]] padded to a multiple of 4 floats
 constexpr int feat_row(int F) { return round_up(4 + F, 4); }

@@ -35,9 +35,10 @@ void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g
                  const BinningState& b, hipStream_t st);
 // exclusive scan of popcount(flags & 15) over [0, n] -> rowbase[0..n]; counters[6] = total live rows,
 // counters[7] = (total > row_capacity)
-void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, uint32_t* rowbase,
-                           uint32_t* partials, int64_t row_capacity, int32_t* counters, int32_t* status_dev,
-                           hipStream_t st);
+// packed_ref15: rows per instance = packed survivor waves (flag bits 4-5) instead of forward slots (bits 0-3)
+void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, bool packed_ref15,
+                           uint32_t* rowbase, uint32_t* partials, int64_t row_capacity, int32_t* counters,
+                           int32_t* status_dev, hipStream_t st);
 // backward launch order: inside each XCD's contiguous chunk of tiles, heaviest (most live pairs) first
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st);
 // ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)
