@@ -29,7 +29,7 @@ namespace olsr {
 constexpr int FWD_BATCH = 128;
 
 template <int TILE, int F>
-__global__ __launch_bounds__(256) void render_fwd_kernel(
+__global__ __launch_bounds__(256, (F <= 16 ? 6 : 4)) void render_fwd_kernel(
     const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
@@ -47,12 +47,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
   __shared__ u32 s_id[B];
   __shared__ u32 s_src[B];
-  // per staged splat, one byte per wave: bit 7 = the wave's slot blended it, bits 0-6 = how many of its
-  // pixels counted it as touched (<= 64); each wave writes only its own byte
-  __shared__ u32 s_hit[B];
-  // same layout, for the reference-mode backward (15x15 tiles): bit b of wave w's byte = a pixel of this wave
-  // that SURVIVES the reference's reduction tree and belongs to backward wave b blended the splat
-  __shared__ u32 s_cls[B];
+  // per staged splat, 16 bits per wave: bit 15 = the wave's slot blended it, bits 0-6 = how many of its pixels
+  // counted it as touched (<= 64), bits 8-9 = which packed survivor wave of the reference-mode backward a
+  // blending pixel belongs to (15x15 tiles); each wave writes only its own 16 bits
+  __shared__ uint2 s_hit[B];
   __shared__ u32 s_work;
 
   const int tile_id = xcd_remap((int)blockIdx.x, ntiles);
@@ -72,6 +70,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
   if constexpr (TILE == 15) {
     if (rank < BS && ref15_survives(rank)) cls = ref15_packed_of_rank(rank) >> 6;
   }
+  const u64 cls_m0 = ballot(cls == 0), cls_m1 = ballot(cls == 1);  // wave-uniform lane masks (scalar registers)
   if (tid == 0) s_work = 0;
   u32 my_work = 0;  // live (instance, slot) pairs flushed by this thread
   float T = 1.0f;
@@ -95,8 +94,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
         if (tid < B) {
           s_id[e] = gid;
           s_src[e] = u;
-          s_hit[e] = 0;
-          s_cls[e] = 0;
+          s_hit[e] = make_uint2(0u, 0u);
           const float2 m = reinterpret_cast<const float2*>(means2D)[gid];
           const float4 c = reinterpret_cast<const float4*>(conic_opacity)[gid];
           // alpha = o * exp(power) can only reach 1/255 if power >= -ln(255 o).  Keep a margin far
@@ -153,26 +151,22 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(
         const u64 cb = ballot(contrib);
         if (cb != 0ull) {
           const u32 tc = (u32)__popcll(ballot(contrib && test_T > 0.5f));
-          if ((tid & 63) == 0) reinterpret_cast<uint8_t*>(s_hit)[4 * j + w] = (uint8_t)(0x80u | tc);
-          if constexpr (TILE == 15) {
-            const u32 cb01 = (ballot(contrib && cls == 0) ? 1u : 0u) | (ballot(contrib && cls == 1) ? 2u : 0u);
-            if ((tid & 63) == 0 && cb01) reinterpret_cast<uint8_t*>(s_cls)[4 * j + w] = (uint8_t)cb01;
-          }
+          u32 cb01 = 0;
+          if constexpr (TILE == 15) cb01 = ((cb & cls_m0) ? 1u : 0u) | ((cb & cls_m1) ? 2u : 0u);  // scalar ALU only
+          if ((tid & 63) == 0) reinterpret_cast<uint16_t*>(s_hit)[4 * j + w] = (uint16_t)(0x8000u | (cb01 << 8) | tc);
         }
         if (wave_all(done)) break;
       }
     }
     __syncthreads();
     if (tid < cnt) {
-      const u32 hit = s_hit[tid];
-      const u32 fl = ((hit >> 7) & 1u) | ((hit >> 14) & 2u) | ((hit >> 21) & 4u) | ((hit >> 28) & 8u);
+      const uint2 hit = s_hit[tid];
       // bits 0-3: forward slots that blended it; bits 4-5: backward waves of the reference-mode survivors
-      const u32 cl = s_cls[tid];
-      const u32 cl2 = (cl | (cl >> 8) | (cl >> 16) | (cl >> 24)) & 3u;
+      const u32 fl = ((hit.x >> 15) & 1u) | ((hit.x >> 30) & 2u) | ((hit.y >> 13) & 4u) | ((hit.y >> 28) & 8u);
+      const u32 cl2 = ((hit.x >> 8) | (hit.x >> 24) | (hit.y >> 8) | (hit.y >> 24)) & 3u;
       if (fl) flags[s_src[tid]] = (uint8_t)(fl | (cl2 << 4));
       my_work += (u32)__popc(fl);
-      // tc of a wave is <= 64 = 0x40: with bit 7 set a full wave reads 0xC0, so mask 0x7F keeps all 7 bits
-      const u32 tc = (hit & 0x7Fu) + ((hit >> 8) & 0x7Fu) + ((hit >> 16) & 0x7Fu) + ((hit >> 24) & 0x7Fu);
+      const u32 tc = (hit.x & 0x7Fu) + ((hit.x >> 16) & 0x7Fu) + (hit.y & 0x7Fu) + ((hit.y >> 16) & 0x7Fu);
       if (tc) atomicAdd(&n_touched[s_id[tid]], (int)tc);
     }
   }
