@@ -185,6 +185,16 @@ int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   float *dL_dtau_sum, const olsr_grad_bucket *bucket,
                   int32_t *status_dev, void *hip_stream);
 
+/* ---- the reference's other native dependency ----------------------------
+ * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest neighbours (FLT_MAX counts
+ * for a missing neighbour when P < 4).  Replaces simple_knn._C.distCUDA2 -> SimpleKNN::knn
+ * (submodules/simple-knn/spatial.cu:15-26, simple_knn.cu:185-221), used to initialise Gaussian scales
+ * (gaussian_splatting/scene/gaussian_model.py:256-263).  points[P,3], mean_dist2[P], scratch of
+ * olsr_knn_scratch_bytes(P) bytes; everything stays on the device (the reference copies the bounding box
+ * to the host twice). */
+size_t olsr_knn_scratch_bytes(int32_t P);
+int olsr_knn_mean_dist2(int32_t P, const float *points, float *mean_dist2, void *scratch, void *hip_stream);
+
 /* ---- caller side of the path -----------------------------------------
  * Mapping loss of one view and its gradient with respect to the rendered images, in one pass over the
  * pixels.  Replaces, with their autograd backward,

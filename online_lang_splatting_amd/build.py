@@ -30,6 +30,7 @@ UNITS = [
     ("k_preprocess_bwd.hip", "k_preprocess_bwd.o", []),
     ("k_accumulate.hip", "k_accumulate.o", []),
     ("k_loss.hip", "k_loss.o", []),
+    ("k_knn.hip", "k_knn.o", []),
 ]
 HEADERS = ["olsr_device.h", "olsr_state.h", "olsr_kernels.h", os.path.join("..", "..", "include", "olsr.h")]
 

@@ -348,6 +348,18 @@ int olsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
   return OLSR_OK;
 }
 
+size_t olsr_knn_scratch_bytes(int32_t P) { return knn_scratch_bytes(P); }
+
+int olsr_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* scratch, void* hip_stream) {
+  if (P < 0) return fail(OLSR_ERR_ARG, "P must be >= 0");
+  if (P == 0) return OLSR_OK;
+  if (!points || !mean_dist2 || !scratch) return fail(OLSR_ERR_ARG, "points, mean_dist2 and scratch are required");
+  launch_knn(P, points, mean_dist2, scratch, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("knn launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
 size_t olsr_mapping_loss_scratch_bytes(int32_t width, int32_t height) {
   if (width <= 0 || height <= 0) return ALIGN;
   return (size_t)loss_blocks(width, height) * 5 * sizeof(float) + ALIGN;

@@ -80,6 +80,10 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
                        const float* dmeans2D, const int32_t* radii, float* flat, float* densify, int32_t* max_radii,
                        hipStream_t st);
 
+// k_knn.hip
+size_t knn_scratch_bytes(int P);
+void launch_knn(int P, const float* points, float* mean_dist2, void* scratch, hipStream_t st);
+
 // k_loss.hip
 int loss_blocks(int W, int H);
 void launch_mapping_loss(const olsr_loss_params& p, const float* image, const float* depth, const float* language,

@@ -1052,4 +1052,35 @@ int64_t oracle_get_field(void* h, const char* name, void* dst) {
 
 float oracle_expf_probe(float x) { return oracle_expf(x); }
 
+// distCUDA2 / SimpleKNN::knn (/root/reference/submodules/simple-knn/spatial.cu:15-26,
+// simple_knn.cu:131-145,185-221): mean of the squared distances to the 3 nearest neighbours.  The
+// reference searches Morton-sorted boxes with conservative pruning, i.e. it returns the EXACT three
+// smallest distances; restated here as the brute-force definition (O(P^2), OpenMP over points) with
+// the same update rule (updateKBest<3>) and the distance expression as nvcc contracts it
+// (d.x*d.x + d.y*d.y + d.z*d.z -> fma(d.z, d.z, fma(d.y, d.y, d.x*d.x))).  Missing neighbours (P < 4) stay
+// FLT_MAX as in the reference.  Parity unpinned by the reference (no tests, CUDA only).
+int oracle_knn_mean_dist2(int32_t P, const float* points, float* out) {
+  if (P < 0 || (P > 0 && (!points || !out))) return OLSR_ERR_ARG;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < P; ++i) {
+    const float qx = points[3 * (size_t)i], qy = points[3 * (size_t)i + 1], qz = points[3 * (size_t)i + 2];
+    float best[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    for (int j = 0; j < P; ++j) {
+      if (j == i) continue;
+      const float dx = points[3 * (size_t)j] - qx, dy = points[3 * (size_t)j + 1] - qy,
+                  dz = points[3 * (size_t)j + 2] - qz;
+      float dist = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      for (int k = 0; k < 3; ++k) {
+        if (best[k] > dist) {
+          const float t = best[k];
+          best[k] = dist;
+          dist = t;
+        }
+      }
+    }
+    out[i] = ((best[0] + best[1]) + best[2]) / 3.0f;
+  }
+  return OLSR_OK;
+}
+
 }  // extern "C"

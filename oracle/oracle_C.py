@@ -54,6 +54,8 @@ def lib():
         L.oracle_mark_visible.restype = C.c_int
         L.oracle_get_field.argtypes = [vp, C.c_char_p, vp]
         L.oracle_get_field.restype = C.c_int64
+        L.oracle_knn_mean_dist2.argtypes = [C.c_int32, vp, vp]
+        L.oracle_knn_mean_dist2.restype = C.c_int
         L.oracle_expf_probe.argtypes = [C.c_float]
         L.oracle_expf_probe.restype = C.c_float
         _lib = L
@@ -235,6 +237,15 @@ def mark_visible(means3D, viewmatrix, projmatrix):
         _check(lib().oracle_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), present.data_ptr()),
                "mark_visible")
     return present
+
+
+def distCUDA2(points):
+    """simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26): brute-force exact 3-NN on the CPU."""
+    pts = points.contiguous().float()
+    out = torch.zeros(pts.shape[0], dtype=torch.float32)
+    if pts.shape[0]:
+        _check(lib().oracle_knn_mean_dist2(pts.shape[0], pts.data_ptr(), out.data_ptr()), "knn")
+    return out
 
 
 def expf(x):

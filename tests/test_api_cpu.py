@@ -22,7 +22,7 @@ def L():
 def _declared_functions():
     src = open(os.path.join(ROOT, "include", "olsr.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(olsr_[a-z_]+)\s*\(", src)) - {"olsr_alloc_fn"})
+    return sorted(set(re.findall(r"\b(olsr_[a-z0-9_]+)\s*\(", src)) - {"olsr_alloc_fn"})
 
 
 def test_library_exports_every_declared_symbol(L):
