@@ -115,7 +115,9 @@ static void device_scan(Load ld, int64_t n, u32* out, u32* partials, hipStream_t
 // The digit width is chosen per sort (<= 8 bits): a 12-bit tile id is sorted in two 6-bit passes.
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ROUNDS = SORT_CHUNK / SORT_THREADS;  // 16 rounds of 64 per wave
-constexpr int SELF_SCAN_MAX_BLOCKS = 48;                // <= 196 k keys: scatter blocks scan the table themselves
+// The self-scanning scatter reads the whole [block][digit] table in every block (nblk^2 * NB loads in total): it
+// wins while that table is small — measured: 123 blocks x 256 digits -24 us per sort, 489 x 256 +17 us.
+constexpr int SELF_SCAN_MAX_TABLE = 40960;              // blocks * digits
 
 __device__ __forceinline__ int64_t bounded_n(int64_t n_host, const int32_t* n_dev) {
   if (n_dev) {
@@ -125,10 +127,11 @@ __device__ __forceinline__ int64_t bounded_n(int64_t n_host, const int32_t* n_de
   return n_host;
 }
 
-// table[d * nblk + b] = number of keys of block b whose digit is d
+// number of keys of block b whose digit is d: table[d * nblk + b] (the layout the device-wide scan walks), or,
+// transposed, table[b * (dmask + 1) + d] (the layout the self-scanning scatter reads coalesced)
 __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
                                                                    const int32_t* __restrict__ n_dev, int shift,
-                                                                   u32 dmask, u32* __restrict__ table) {
+                                                                   u32 dmask, int transposed, u32* __restrict__ table) {
   __shared__ u32 hist[256];
   const int64_t n = bounded_n(n_host, n_dev);
   hist[threadIdx.x] = 0;
@@ -140,7 +143,9 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const u32* __r
     if (i < n) atomicAdd(&hist[(keys[i] >> shift) & dmask], 1u);
   }
   __syncthreads();
-  if (threadIdx.x <= dmask) table[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x <= dmask)
+    table[transposed ? (size_t)blockIdx.x * (dmask + 1) + threadIdx.x : (size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+        hist[threadIdx.x];
 }
 
 // Stable scatter.  Wave w of block b owns the contiguous run [b*CHUNK + w*1024, +1024) and walks
@@ -149,9 +154,10 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_kernel(const u32* __r
 // bits).  The block first orders its 4096 pairs by digit in LDS, then writes every digit's run
 // with consecutive lanes -> coalesced stores instead of 4-byte scatters.
 //
-// SELF_SCAN: for short inputs (few blocks) the table arrives RAW from the histogram kernel and each
-// block derives its own bases — digit totals (row sums), their exclusive prefix, and the prefix of
-// its row up to its own column — saving the three launches of the device-wide scan per pass.
+// SELF_SCAN (tables of up to SELF_SCAN_MAX_TABLE entries): the table arrives RAW and transposed ([block][digit]) from
+// the histogram kernel and each block derives its own bases — digit totals (column sums), their exclusive
+// prefix, and the sum of its column over the earlier blocks — with coalesced, independent loads (all 256
+// threads; 256 / NB threads share a digit).  Saves the two launches of the device-wide scan per pass.
 template <int DB, bool SELF_SCAN>
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const u32* __restrict__ keys_in, const u32* __restrict__ vals_in, int64_t n_host,
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
   __shared__ u32 dstart[NB + 1]; // local start of digit d inside the block
   __shared__ u32 ex_key[SORT_CHUNK];
   __shared__ u32 ex_val[SORT_CHUNK];
+  __shared__ u32 s_part[2][SORT_THREADS];  // SELF_SCAN partial column sums
   const int64_t n = bounded_n(n_host, n_dev);
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const int64_t bbase = (int64_t)blockIdx.x * SORT_CHUNK;
@@ -188,13 +195,28 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_kernel(
     const u32 start = block_excl_scan_256(tot, nullptr);
     u32 gb = 0;
     if constexpr (SELF_SCAN) {
-      u32 row_total = 0, row_before = 0;
-      if (d < NB) {
-        const u32* row = table + (size_t)d * gridDim.x;
-        for (u32 bb = 0; bb < gridDim.x; ++bb) {
-          const u32 c = row[bb];
-          row_before += (bb < blockIdx.x) ? c : 0u;
-          row_total += c;
+      constexpr u32 PARTS = SORT_THREADS / NB;  // threads per digit
+      const u32 dd = threadIdx.x & DMASK, part = threadIdx.x >> DB;
+      u32 tot_p = 0, bef_p = 0;
+#pragma unroll 8
+      for (u32 bb = part; bb < gridDim.x; bb += PARTS) {
+        const u32 c = table[(size_t)bb * NB + dd];
+        bef_p += (bb < blockIdx.x) ? c : 0u;
+        tot_p += c;
+      }
+      u32 row_total = tot_p, row_before = bef_p;
+      if constexpr (PARTS > 1) {
+        s_part[0][threadIdx.x] = tot_p;
+        s_part[1][threadIdx.x] = bef_p;
+        __syncthreads();
+        row_total = 0;
+        row_before = 0;
+        if (d < NB) {
+#pragma unroll
+          for (u32 q = 0; q < PARTS; ++q) {
+            row_total += s_part[0][q * NB + d];
+            row_before += s_part[1][q * NB + d];
+          }
         }
       }
       gb = block_excl_scan_256(row_total, nullptr) + row_before;
@@ -260,8 +282,9 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
   int where = 0;
   for (int p = 0; p < passes; ++p) {
     const int shift = db * p;
-    radix_hist_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, n_host, n_dev, shift, (1u << db) - 1u, b.table);
-    const bool self_scan = nblk <= SELF_SCAN_MAX_BLOCKS;
+    const bool self_scan = (int64_t)nblk * (1 << db) <= SELF_SCAN_MAX_TABLE;
+    radix_hist_kernel<<<nblk, SORT_THREADS, 0, st>>>(kin, n_host, n_dev, shift, (1u << db) - 1u, self_scan ? 1 : 0,
+                                                     b.table);
     if (!self_scan)
       device_scan<LoadPlain, false>(LoadPlain{b.table}, (int64_t)(1 << db) * nblk, b.table, b.partials, st);
     const u32* vsrc = (p == 0 && vals_in_identity) ? nullptr : vin;
