@@ -60,9 +60,13 @@ class GradientBucket:
 
     def __init__(self, P, layout: GradLayout, device):
         self.layout = layout
-        self.flat = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
+        # one storage for everything that is SUM-reduced, so the step's exchange is a single large all-reduce
+        # (+ one small MAX all-reduce): [P x width gradients | P x 2 densification statistics]
+        off = (P * layout.width + 3) // 4 * 4  # keep the statistics 16-byte aligned
+        self.sum_storage = torch.zeros(off + 2 * P, dtype=torch.float32, device=device)
+        self.flat = self.sum_storage[: P * layout.width].view(P, layout.width)
         # xyz_gradient_accum, denom (gaussian_model.py:965-969): sum-reducible once the norm is taken per view
-        self.densify = torch.zeros(P, 2, dtype=torch.float32, device=device)
+        self.densify = self.sum_storage[off:off + 2 * P].view(P, 2)
         self.max_radii = torch.zeros(P, dtype=torch.int32, device=device)  # max-reducible
         self._sl = layout.slices()
 
@@ -110,8 +114,7 @@ class GradientBucket:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(self.densify, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(self.sum_storage, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
 
 
