@@ -38,17 +38,15 @@
 
 namespace olsr {
 
-// Which thread ranks reach element 0 of render_cuda_reduce_sum's tree when g.size() == TILE*TILE
-// (steps size/2, /2, ... with integer division).  256 lanes: all of them.  225 lanes: the tree
-// 112,56,28,14,7,3,1 drops rank 224 and every rank whose residue mod 7 is 2, 5 or 6.
+// Which thread ranks reach element 0 of render_cuda_reduce_sum's tree when g.size() == TILE*TILE:
+// all 256 for 16x16 tiles, the 128 of ref15_survives (olsr_device.h) for 15x15 tiles.
 template <int TILE>
 __device__ __forceinline__ bool ref_survives(int rank) {
   if constexpr (TILE == 16) {
     return true;
   } else {
     static_assert(TILE == 15, "closed form derived for 15x15 and 16x16 tiles only");
-    const int m = rank % 7;
-    return rank < 224 && (m == 0 || m == 1 || m == 3 || m == 4);
+    return ref15_survives(rank);
   }
 }
 

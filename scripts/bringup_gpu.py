@@ -13,7 +13,7 @@ print(torch.cuda.get_device_name(0))
 def compare(P, W, H, F, deg=0, seed=1, tile=15, mode=0, bg=None, max_sh=None):
     sc = make_scene(P, W, H, F, seed=seed, max_sh_degree=deg if max_sh is None else max_sh, sh_degree=deg, bg=bg)
     t0 = time.time(); fo, go = run_backend(O, sc, None, seed, tile, mode); t1 = time.time()
-    fg, gg = run_backend(G, sc, dev, seed, tile, mode); torch.cuda.synchronize(); t2 = time.time()
+    fg, gg = run_backend(G, sc, dev, seed, tile, mode, binning=0); torch.cuda.synchronize(); t2 = time.time()  # reference binning: lists comparable 1:1
     print(f"--- P={P} {W}x{H} F={F} deg={deg} tile={tile} mode={mode}: R oracle={fo['R']} hip={fg['R']}  (oracle {t1-t0:.2f}s, hip {t2-t1:.2f}s)")
     # geometry stage
     for name, cnt, dt in (("depths", P, torch.float32), ("means2D", 2*P, torch.float32), ("conic_opacity", 4*P, torch.float32),
