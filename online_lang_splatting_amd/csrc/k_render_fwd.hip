@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? 6 : 4)) void render_fwd_kernel(
     if (rank < BS && ref15_survives(rank)) cls = ref15_packed_of_rank(rank) >> 6;
   }
   const u64 cls_m0 = ballot(cls == 0), cls_m1 = ballot(cls == 1);  // wave-uniform lane masks (scalar registers)
+  u64 done_m = ballot(done);  // lanes that are outside the image or saturated
+  const bool lane0 = (tid & 63) == 0;
   if (tid == 0) s_work = 0;
   u32 my_work = 0;  // live (instance, slot) pairs flushed by this thread
   float T = 1.0f;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? 6 : 4)) void render_fwd_kernel(
 
   for (int base = 0; base < n; base += B) {
     // also the barrier that separates the previous batch's flush from this batch's staging
-    if (__syncthreads_and(done)) break;
+    if (__syncthreads_and(done_m == ~0ull)) break;
     const int cnt = min(B, n - base);
     {
       const int e = tid & (B - 1);
@@ -118,44 +120,41 @@ __global__ __launch_bounds__(256, (F <= 16 ? 6 : 4)) void render_fwd_kernel(
     }
     __syncthreads();
 
-    if (!wave_all(done)) {
-      // software pipeline: splat j+1's geometry is fetched from LDS while splat j is evaluated
-      float4 ngeo = s_geo[0];
-      float4 nco = s_co[0];
+    if (done_m != ~0ull) {
+      // The lane predicates of CR/forward.cu:449-476 live in scalar registers as 64-bit wave masks: every test
+      // is one v_cmp whose result is combined with s_and / s_andn2, "any lane" is an s_cmp, and only the
+      // accumulation runs under a lane mask (inverse_ballot -> exec).  Same tests, same order of arithmetic.
       for (int j = 0; j < cnt; ++j) {
-        const float4 geo = ngeo;
-        const float4 co = nco;
-        ngeo = s_geo[j + 1];  // arrays hold B + 1 entries: the look-ahead never leaves them
-        nco = s_co[j + 1];
-        // Branch-free restatement of CR/forward.cu:449-476: same tests, same order of arithmetic.
+        const float4 geo = s_geo[j];
+        const float4 co = s_co[j];
         const float dx = geo.x - pixfx, dy = geo.y - pixfy;
         const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+        const u64 live = ~done_m;
         // wave-level early-out: no live pixel of this slot can reach the alpha floor
-        if (!wave_any(!done && !(power < geo.z))) continue;
+        if ((ballot(!(power < geo.z)) & live) == 0ull) continue;
         const float alpha = fminf_ref(0.99f, co.w * pinned_expf(power));
         const float test_T = T * (1 - alpha);
-        const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        const bool term = ok && (test_T < 0.0001f);
-        const bool contrib = ok && !term;
-        done = done || term;
-        if (contrib) {
-          // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
-          // reference's expression (CR/forward.cu:479-484), and what the oracle restates
-          const v2f* fr2 = reinterpret_cast<const v2f*>(&s_feat[j * FR]);
-          const v2f a2 = {alpha, alpha}, T2 = {T, T};
+        const u64 ok_m = ballot(!(power > 0.0f)) & ballot(!(alpha < 1.0f / 255.0f)) & live;
+        const u64 term_m = ok_m & ballot(test_T < 0.0001f);
+        const u64 contrib_m = ok_m & ~term_m;
+        done_m |= term_m;
+        if (contrib_m != 0ull) {
+          if (__builtin_amdgcn_inverse_ballot_w64(contrib_m)) {
+            // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
+            // reference's expression (CR/forward.cu:479-484), and what the oracle restates
+            const v2f* fr2 = reinterpret_cast<const v2f*>(&s_feat[j * FR]);
+            const v2f a2 = {alpha, alpha}, T2 = {T, T};
 #pragma unroll
-          for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
-          T = test_T;
-          last_contributor = (u32)(base + j + 1);
+            for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
+            T = test_T;
+            last_contributor = (u32)(base + j + 1);
+          }
+          const u32 tc = (u32)__popcll(contrib_m & ballot(test_T > 0.5f));
+          u32 rec = 0x8000u | tc;
+          if constexpr (TILE == 15) rec |= ((contrib_m & cls_m0) ? 0x100u : 0u) | ((contrib_m & cls_m1) ? 0x200u : 0u);
+          if (lane0) reinterpret_cast<uint16_t*>(s_hit)[4 * j + w] = (uint16_t)rec;
         }
-        const u64 cb = ballot(contrib);
-        if (cb != 0ull) {
-          const u32 tc = (u32)__popcll(ballot(contrib && test_T > 0.5f));
-          u32 cb01 = 0;
-          if constexpr (TILE == 15) cb01 = ((cb & cls_m0) ? 1u : 0u) | ((cb & cls_m1) ? 2u : 0u);  // scalar ALU only
-          if ((tid & 63) == 0) reinterpret_cast<uint16_t*>(s_hit)[4 * j + w] = (uint16_t)(0x8000u | (cb01 << 8) | tc);
-        }
-        if (wave_all(done)) break;
+        if (done_m == ~0ull) break;
       }
     }
     __syncthreads();
