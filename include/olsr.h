@@ -162,7 +162,9 @@ int olsr_forward_async(const olsr_scene *scene,
  * straight into the flat all-reduce buffer and the densification statistics described at
  * olsr_accumulate_gradients — the same result as calling that function afterwards, without the
  * round trip through the separate arrays.  With a bucket, every per-Gaussian output above may be
- * NULL and is then not written (a mapping step only consumes the bucket and dL_dtau_sum). */
+ * NULL and is then not written (a mapping step only consumes the bucket and dL_dtau_sum).  Likewise with
+ * dL_dtau_sum alone: tracking (utils/slam_frontend.py) optimises only the camera pose, so a pose-only backward
+ * passes NULL for every per-Gaussian array. */
 typedef struct olsr_grad_bucket {
   float *flat;        /* [P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language] */
   float *densify;     /* [P][2]  {sum of ||dL_dmeans2D.xy|| over views, number of views that saw it} */

@@ -186,6 +186,7 @@ __device__ __forceinline__ f3 sh_backward(int idx, int deg, int M, const f3& pos
   const float x = dir.x, y = dir.y, z = dir.z;
   auto S = [&](int k, int ch) { return sh[3 * k + ch]; };
   auto setsh = [&](int k, float w) {
+    if (dL_dsh == nullptr) return;  // pose-only backward: only the dL_dmean contribution below is wanted
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float v = w * dL_dRGB[ch];
@@ -248,7 +249,7 @@ __device__ __forceinline__ f3 sh_backward(int idx, int deg, int M, const f3& pos
       }
     }
   }
-  if (!add)
+  if (!add && dL_dsh != nullptr)
     for (int k = written; k < M; ++k) {
       dL_dsh[3 * k + 0] = 0.f;
       dL_dsh[3 * k + 1] = 0.f;
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
           const float dcol[3] = {acc[6], acc[7], acc[8]};
           // one evaluation: into the caller's dL_dsh row if there is one (copied to the bucket below),
           // else straight into the bucket row
-          float* sh_row = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : brow + 3;
+          float* sh_row = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : (brow ? brow + 3 : nullptr);
           const f3 dm_sh = sh_backward((int)idx, D, M, mean, campos, shs, clamped, dcol, sh_row, !dL_dsh && badd);
           sh_written = true;
           dmean[0] += dm_sh.x;

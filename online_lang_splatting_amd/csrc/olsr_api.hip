@@ -290,9 +290,10 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   if (bucket) {
     if (!bucket->flat || !bucket->densify || !bucket->max_radii)
       return fail(OLSR_ERR_ARG, "bucket.flat, bucket.densify and bucket.max_radii must not be NULL");
-  } else if (!dL_dmeans2D || !dL_dopacity || !dL_dcolors || (s.F > 0 && !dL_dlanguage) || !dL_dmeans3D ||
-             !dL_dcov3D || (s.M > 0 && !dL_dsh) || !dL_dscales || !dL_drotations || !dL_dtau) {
-    return fail(OLSR_ERR_ARG, "gradient outputs must not be NULL (unless a gradient bucket is given)");
+  } else if (!dL_dtau_sum && (!dL_dmeans2D || !dL_dopacity || !dL_dcolors || (s.F > 0 && !dL_dlanguage) ||
+                              !dL_dmeans3D || !dL_dcov3D || (s.M > 0 && !dL_dsh) || !dL_dscales || !dL_drotations ||
+                              !dL_dtau)) {
+    return fail(OLSR_ERR_ARG, "gradient outputs must not be NULL (unless a gradient bucket or dL_dtau_sum is given)");
   }
   const FrameDims d = frame_dims(s);
   size_t gb, ib, bb;

@@ -188,11 +188,13 @@ class RasterWorkspace:
             self._stream()))
         return o
 
-    def backward(self, dL_dcolor, dL_dlanguage, dL_ddepth, bucket=None, first=False, bucket_only=False):
+    def backward(self, dL_dcolor, dL_dlanguage, dL_ddepth, bucket=None, first=False, bucket_only=False,
+                 pose_only=False):
         """Backward of the last forward.  With `bucket` (a GradientBucket) the per-Gaussian backward kernel also
         writes (first=True) or adds this view's gradients into the bucket — the fused form of
         bucket.accumulate(); `bucket_only` additionally skips the separate per-Gaussian gradient arrays
-        (a mapping step only consumes the bucket and dL_dtau_sum)."""
+        (a mapping step only consumes the bucket and dL_dtau_sum).  `pose_only`: tracking — only dL_dtau_sum
+        ([rho | theta] of the camera) is produced, no per-Gaussian array is written."""
         g = self.grads
 
         def p(t):
@@ -203,6 +205,8 @@ class RasterWorkspace:
                                      max_radii=bucket.max_radii.data_ptr(), assign=1 if first else 0)
             if bucket_only:
                 g = {k: (v if k == "dL_dtau_sum" else None) for k, v in g.items()}
+        if pose_only:
+            g = {k: (v if k == "dL_dtau_sum" else None) for k, v in g.items()}
         check(lib().olsr_backward(
             C.byref(self._scene), self.out["radii"].data_ptr(), self.geom.data_ptr(), self.capacity,
             self.binning.data_ptr(), self.img.data_ptr(), _abi.ALLOC_FN(0), None, self.scratch.data_ptr(),

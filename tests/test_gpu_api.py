@@ -155,6 +155,8 @@ def test_fused_bucket_equals_separate_accumulate(hip):
             assert torch.equal(g2[k], sep[k]), k
         g3 = ws.backward(dc, dl, dd, bucket=only, first=(i == 0), bucket_only=True)
         assert torch.equal(g3["dL_dtau_sum"], sep["dL_dtau_sum"])
+        g4 = ws.backward(dc, dl, dd, pose_only=True)  # tracking: the pose gradient alone
+        assert torch.equal(g4["dL_dtau_sum"], sep["dL_dtau_sum"]) and g4["dL_dmeans3D"] is None
         assert not ws.rendered()[1]
     for b in (fused, only):
         assert torch.equal(b.flat, ref.flat)
