@@ -92,7 +92,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   // workgroup b runs on XCD b % 8 and takes the (b / 8)-th heaviest tile of that XCD's chunk
   const int tile_id = (int)tile_order[xcd_remap((int)blockIdx.x, ntiles)];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bx = tile_id % gx, by = tile_id / gx;
   const u32 r0 = ranges[2 * tile_id], r1 = ranges[2 * tile_id + 1];
   if (r1 <= r0) return;
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
 
     // From here to the next batch the four waves run independently: no barrier per splat.
     for (int i = 0; i < cnt; ++i) {
-      const u32 fl = s_flag[i];
+      // (wave-uniform values are moved to scalar registers: the tests below become s_cmp / s_cbranch)
+      const u32 fl = (u32)__builtin_amdgcn_readfirstlane((int)s_flag[i]);
       if ((fl & 15u) == 0) continue;  // whole tile skips this splat: no state changes (CR/backward.cu:1091-1093)
       // did any pixel of THIS wave blend it in the forward?  (bits 0-3: the forward's slots; bits 4-5: the
       // packed survivor waves)
@@ -343,7 +344,8 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
       }
       // compact row index: rows of an instance are consecutive, one per set slot bit
       const u32 before = PACKED ? ((fl >> 4) & (u32)w) : (u32)__popc(fl & ((1u << w) - 1u));  // rows of earlier waves
-      if (role >= 0) rows[((size_t)s_row[i] + before) * ROW + role] = rowval;
+      float* rowp = rows + ((size_t)(u32)__builtin_amdgcn_readfirstlane((int)s_row[i]) + before) * ROW;  // scalar
+      if (role >= 0) rowp[role] = rowval;
     }
   }
 }
