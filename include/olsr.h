@@ -233,6 +233,22 @@ int olsr_mapping_loss(const olsr_loss_params *params, const float *image, const 
                       float *dL_dimage, float *dL_ddepth, float *dL_dlanguage,
                       float *loss, float *dL_dexposure, void *scratch, void *hip_stream);
 
+/* Tracking loss of one view (front end: the pose is optimised, the Gaussians are fixed) and its image cotangents.
+ * Replaces get_loss_tracking / get_loss_tracking_rgb / get_loss_tracking_rgbd (utils/slam_utils.py:92-121):
+ *   loss = alpha * mean(opacity * |m * (exp(a) * image + b) - m * gt_image|)
+ *        + (1 - alpha) * mean|dm * depth - dm * gt_depth|
+ * m = (sum_c gt_image > rgb_boundary_threshold) * grad_mask (grad_mask[H,W] float, NULL = all ones),
+ * dm = (gt_depth > 0.01) * (opacity > 0.95).  params->F, lang_* and lamda_lang are ignored.
+ * loss = device float[4] {total, rgb term, depth term, 0}.  No gradient is produced for `opacity`: the
+ * rasterizer's autograd function discards the cotangent of its opacity output
+ * (DGR/diff_gaussian_rasterization/__init__.py:333-343), so the reference's backward drops it as well.
+ * Same scratch as olsr_mapping_loss.  Follow with olsr_backward in pose-only mode (dL_dtau_sum alone). */
+int olsr_tracking_loss(const olsr_loss_params *params, const float *image, const float *depth,
+                       const float *opacity, const float *gt_image, const float *gt_depth,
+                       const float *grad_mask, const float *exposure,
+                       float *dL_dimage, float *dL_ddepth, float *loss, float *dL_dexposure,
+                       void *scratch, void *hip_stream);
+
 /* Adds one view's per-Gaussian gradients into the flat fp32 buffer
  *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]
  * that a frame-sharded trainer all-reduces once per optimisation step, and updates the

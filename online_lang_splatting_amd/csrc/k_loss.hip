@@ -55,13 +55,18 @@ __device__ __forceinline__ void store_px(float* __restrict__ plane, size_t p, co
     plane[p] = r.v[0];
 }
 
-template <int F, int VEC>
+// TRACK: the tracking loss (get_loss_tracking / _rgb / _rgbd, utils/slam_utils.py:92-121): the RGB term is weighted
+// by the rendered opacity and masked by the keyframe's image-gradient mask, the depth term is masked by
+// opacity > 0.95; no language term.  (The gradient THROUGH the opacity is not produced: the rasterizer's autograd
+// function ignores the cotangent of its opacity output, DGR/diff_gaussian_rasterization/__init__.py:333-343.)
+template <int F, int VEC, bool TRACK>
 __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
     int W, int H, int lw, int lh, int use_exposure, float alpha, float thr, float lamda,
     const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ lang,
     const float* __restrict__ gt_image, const float* __restrict__ gt_depth, const float* __restrict__ gt_lang,
-    const float* __restrict__ exposure, float* __restrict__ d_image, float* __restrict__ d_depth,
-    float* __restrict__ d_lang, float* __restrict__ partials) {
+    const float* __restrict__ exposure, const float* __restrict__ opacity, const float* __restrict__ grad_mask,
+    float* __restrict__ d_image, float* __restrict__ d_depth, float* __restrict__ d_lang,
+    float* __restrict__ partials) {
   const size_t HW = (size_t)H * W;
   const size_t p = ((size_t)blockIdx.x * LOSS_THREADS + threadIdx.x) * VEC;  // first pixel of this thread
   float s[LOSS_SUMS] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -74,6 +79,17 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
     for (int c = 0; c < 3; ++c) gt[c] = load_px<VEC>(gt_image + c * HW, p);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) m.v[i] = ((gt[0].v[i] + gt[1].v[i]) + gt[2].v[i] > thr) ? 1.f : 0.f;
+    PixVec<VEC> op;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) op.v[i] = 1.f;
+    if constexpr (TRACK) {
+      op = load_px<VEC>(opacity, p);
+      if (grad_mask != nullptr) {
+        const PixVec<VEC> gm = load_px<VEC>(grad_mask, p);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m.v[i] *= gm.v[i];  // rgb_pixel_mask * viewpoint.grad_mask, :102
+      }
+    }
     const float wrgb = alpha / (3.0f * (float)HW);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -83,8 +99,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
       for (int i = 0; i < VEC; ++i) {
         const float ab = use_exposure ? ea * x.v[i] + eb : x.v[i];
         const float v = ab * m.v[i] - gt[c].v[i] * m.v[i];
-        s[0] += fabsf(v);
-        const float dab = sgn(v) * m.v[i];  // d|v| / d(image_ab)
+        s[0] += TRACK ? op.v[i] * fabsf(v) : fabsf(v);  // l1 = opacity * |.|, :103
+        const float dab = TRACK ? op.v[i] * (sgn(v) * m.v[i]) : sgn(v) * m.v[i];  // d loss term / d(image_ab)
         d.v[i] = wrgb * dab * ea;
         s[3] += dab * (ea * x.v[i]);        // d(image_ab)/da = e^a image
         s[4] += dab;
@@ -98,7 +114,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
       const float wd = (1.f - alpha) / (float)HW;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const float md = (gd.v[i] > 0.01f) ? 1.f : 0.f;
+        float md = (gd.v[i] > 0.01f) ? 1.f : 0.f;
+        if constexpr (TRACK) md *= (op.v[i] > 0.95f) ? 1.f : 0.f;  // depth_pixel_mask * opacity_mask, :113-117
         const float v = x.v[i] * md - gd.v[i] * md;
         s[1] += fabsf(v);
         d.v[i] = wd * sgn(v) * md;
@@ -198,33 +215,44 @@ int loss_blocks(int W, int H) { return (int)(((size_t)W * H + LOSS_THREADS - 1) 
 
 void launch_mapping_loss(const olsr_loss_params& p, const float* image, const float* depth, const float* language,
                          const float* gt_image, const float* gt_depth, const float* gt_language, const float* exposure,
-                         float* dL_dimage, float* dL_ddepth, float* dL_dlanguage, float* loss, float* dL_dexposure,
-                         float* partials, hipStream_t st) {
+                         const float* opacity, const float* grad_mask, bool tracking, float* dL_dimage,
+                         float* dL_ddepth, float* dL_dlanguage, float* loss, float* dL_dexposure, float* partials,
+                         hipStream_t st) {
   // 16-byte path: planes are [C][H][W], so with W % 4 == 0 every plane and row stays 16-byte aligned if the
   // base pointers are
   auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q & 15u) == 0; };
   const bool vec4 = (p.width % 4) == 0 && al16(image) && al16(depth) && al16(language) && al16(gt_image) &&
-                    al16(gt_depth) && al16(dL_dimage) && al16(dL_ddepth) && al16(dL_dlanguage);
+                    al16(gt_depth) && al16(dL_dimage) && al16(dL_ddepth) && al16(dL_dlanguage) && al16(opacity) &&
+                    al16(grad_mask);
   const size_t threads = ((size_t)p.width * p.height + (vec4 ? 3 : 0)) / (vec4 ? 4 : 1);
   const int nb = (int)((threads + LOSS_THREADS - 1) / LOSS_THREADS);  // <= loss_blocks(): the scratch is sized for VEC = 1
   const int use_exposure = (exposure != nullptr && !p.initialization) ? 1 : 0;
 #define OLSR_LOSS_ARGS                                                                                           \
   p.width, p.height, p.lang_width, p.lang_height, use_exposure, p.alpha, p.rgb_boundary_threshold, p.lamda_lang, \
-      image, depth, language, gt_image, gt_depth, gt_language, exposure, dL_dimage, dL_ddepth, dL_dlanguage, partials
-#define OLSR_LOSS(FV)                                                                   \
-  case FV:                                                                              \
-    if (vec4)                                                                           \
-      mapping_loss_kernel<FV, 4><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);          \
-    else                                                                                \
-      mapping_loss_kernel<FV, 1><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);          \
+      image, depth, language, gt_image, gt_depth, gt_language, exposure, opacity, grad_mask, dL_dimage, dL_ddepth, \
+      dL_dlanguage, partials
+#define OLSR_LOSS(FV)                                                                       \
+  case FV:                                                                                  \
+    if (vec4)                                                                               \
+      mapping_loss_kernel<FV, 4, false><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);       \
+    else                                                                                    \
+      mapping_loss_kernel<FV, 1, false><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);       \
     break;
-  switch (p.F) {
-    OLSR_LOSS(0) OLSR_LOSS(3) OLSR_LOSS(15) OLSR_LOSS(16) OLSR_LOSS(32)
-    default: break;
+  if (tracking) {
+    if (vec4)
+      mapping_loss_kernel<0, 4, true><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);
+    else
+      mapping_loss_kernel<0, 1, true><<<nb, LOSS_THREADS, 0, st>>>(OLSR_LOSS_ARGS);
+  } else {
+    switch (p.F) {
+      OLSR_LOSS(0) OLSR_LOSS(3) OLSR_LOSS(15) OLSR_LOSS(16) OLSR_LOSS(32)
+      default: break;
+    }
   }
 #undef OLSR_LOSS
 #undef OLSR_LOSS_ARGS
-  mapping_loss_final_kernel<<<1, 256, 0, st>>>(partials, nb, p.width, p.height, p.F, gt_language != nullptr ? 1 : 0,
+  mapping_loss_final_kernel<<<1, 256, 0, st>>>(partials, nb, p.width, p.height, tracking ? 0 : p.F,
+                                               (!tracking && gt_language != nullptr) ? 1 : 0,
                                                p.alpha, p.lamda_lang, loss, use_exposure ? dL_dexposure : nullptr);
   if (!use_exposure && dL_dexposure) (void)hipMemsetAsync(dL_dexposure, 0, 2 * sizeof(float), st);
 }

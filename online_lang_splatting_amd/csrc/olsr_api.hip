@@ -381,10 +381,28 @@ int olsr_mapping_loss(const olsr_loss_params* params, const float* image, const 
     return fail(OLSR_ERR_ARG, "the language target size must be positive");
   hipStream_t st = (hipStream_t)hip_stream;
   float* partials = (float*)(((uintptr_t)scratch + ALIGN - 1) / ALIGN * ALIGN);
-  launch_mapping_loss(p, image, depth, language, gt_image, gt_depth, p.F > 0 ? gt_language : nullptr, exposure, dL_dimage,
-                      dL_ddepth, dL_dlanguage, loss, dL_dexposure, partials, st);
+  launch_mapping_loss(p, image, depth, language, gt_image, gt_depth, p.F > 0 ? gt_language : nullptr, exposure, nullptr,
+                      nullptr, false, dL_dimage, dL_ddepth, dL_dlanguage, loss, dL_dexposure, partials, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("mapping_loss launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
+int olsr_tracking_loss(const olsr_loss_params* params, const float* image, const float* depth, const float* opacity,
+                       const float* gt_image, const float* gt_depth, const float* grad_mask, const float* exposure,
+                       float* dL_dimage, float* dL_ddepth, float* loss, float* dL_dexposure, void* scratch,
+                       void* hip_stream) {
+  if (!params) return fail(OLSR_ERR_ARG, "loss params are NULL");
+  const olsr_loss_params& p = *params;
+  if (p.width <= 0 || p.height <= 0) return fail(OLSR_ERR_ARG, "image size must be positive");
+  if (!image || !depth || !opacity || !gt_image || !gt_depth || !dL_dimage || !dL_ddepth || !loss || !scratch)
+    return fail(OLSR_ERR_ARG, "image, depth, opacity, their targets, the gradient outputs, loss and scratch are required");
+  hipStream_t st = (hipStream_t)hip_stream;
+  float* partials = (float*)(((uintptr_t)scratch + ALIGN - 1) / ALIGN * ALIGN);
+  launch_mapping_loss(p, image, depth, nullptr, gt_image, gt_depth, nullptr, exposure, opacity, grad_mask, true, dL_dimage,
+                      dL_ddepth, nullptr, loss, dL_dexposure, partials, st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("tracking_loss launch: ") + hipGetErrorString(e));
   return OLSR_OK;
 }
 

@@ -88,7 +88,8 @@ void launch_knn(int P, const float* points, float* mean_dist2, void* scratch, hi
 int loss_blocks(int W, int H);
 void launch_mapping_loss(const olsr_loss_params& p, const float* image, const float* depth, const float* language,
                          const float* gt_image, const float* gt_depth, const float* gt_language, const float* exposure,
-                         float* dL_dimage, float* dL_ddepth, float* dL_dlanguage, float* loss, float* dL_dexposure,
-                         float* partials, hipStream_t st);
+                         const float* opacity, const float* grad_mask, bool tracking, float* dL_dimage,
+                         float* dL_ddepth, float* dL_dlanguage, float* loss, float* dL_dexposure, float* partials,
+                         hipStream_t st);
 
 }  // namespace olsr

@@ -43,3 +43,34 @@ def mapping_loss(image, depth, language, gt_image, gt_depth, gt_language=None, e
                                   ptr(out["dL_dlanguage"]), ptr(out["loss"]), ptr(out["dL_dexposure"]),
                                   scratch.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return out
+
+
+def tracking_loss(image, depth, opacity, gt_image, gt_depth, grad_mask=None, exposure=None, *, alpha=0.95,
+                  rgb_boundary_threshold=0.01):
+    """get_loss_tracking (utils/slam_utils.py:92-121) and its image cotangents in one pass.
+    image [3,H,W], depth [1,H,W], opacity [1,H,W], gt_image [3,H,W], gt_depth [H,W], grad_mask [1,H,W] or [H,W]
+    (bool or float) or None, exposure = device tensor [2] or None.
+    Returns dict(loss[4] = {total, rgb term, depth term, 0}, dL_dimage, dL_ddepth, dL_dexposure[2])."""
+    for name, t in (("image", image), ("depth", depth), ("opacity", opacity), ("gt_image", gt_image),
+                    ("gt_depth", gt_depth)):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError(f"tracking_loss: {name} must be a float32 tensor on the GPU")
+    dev = image.device
+    H, W = image.shape[1], image.shape[2]
+    f32 = dict(dtype=torch.float32, device=dev)
+    c = lambda t: None if t is None else t.contiguous()
+    gm = None if grad_mask is None else grad_mask.to(torch.float32)
+    image, depth, opacity, gt_image, gt_depth, gm, exposure = map(c, (image, depth, opacity, gt_image, gt_depth, gm, exposure))
+    p = _abi.OlsrLossParams(width=W, height=H, F=0, lang_width=0, lang_height=0, initialization=0, alpha=float(alpha),
+                            rgb_boundary_threshold=float(rgb_boundary_threshold), lamda_lang=0.0)
+    out = dict(loss=torch.empty(4, **f32), dL_dimage=torch.empty(3, H, W, **f32), dL_ddepth=torch.empty(1, H, W, **f32),
+               dL_dexposure=torch.empty(2, **f32))
+    L = lib()
+    scratch = torch.empty(L.olsr_mapping_loss_scratch_bytes(W, H), dtype=torch.uint8, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None and t.numel() > 0 else None
+    with torch.cuda.device(dev):
+        check(L.olsr_tracking_loss(C.byref(p), ptr(image), ptr(depth), ptr(opacity), ptr(gt_image), ptr(gt_depth), ptr(gm),
+                                   ptr(exposure), ptr(out["dL_dimage"]), ptr(out["dL_ddepth"]), ptr(out["loss"]),
+                                   ptr(out["dL_dexposure"]), scratch.data_ptr(),
+                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out

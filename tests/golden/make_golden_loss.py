@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, "/root/reference")
-from utils.slam_utils import get_loss_mapping  # noqa: E402
+from utils.slam_utils import get_loss_mapping, get_loss_tracking  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -65,8 +65,42 @@ def case(seed, H, W, Fch, lh, lw, a, b, alpha, thr, init):
                 d_b=vp.exposure_b.grad if vp.exposure_b.grad is not None else z)
 
 
+def tracking_case(seed, H, W, a, b, alpha, thr):
+    """get_loss_tracking (utils/slam_utils.py:92-121) on a stub viewpoint; opacity enters as a constant (the
+    rasterizer's backward discards its cotangent)."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.rand(3, H, W, generator=g, requires_grad=True)
+    depth = (torch.rand(1, H, W, generator=g) * 4).requires_grad_(True)
+    opacity = torch.rand(1, H, W, generator=g)
+    opacity[:, :, W // 2:] = 0.96 + 0.04 * opacity[:, :, W // 2:]   # half of the pixels pass opacity > 0.95
+    gt_image = torch.rand(3, H, W, generator=g)
+    gt_image[:, : H // 4, : W // 3] = 0.0
+    gt_depth = torch.rand(H, W, generator=g) * 4
+    gt_depth[H // 2:, : W // 5] = 0.0
+    grad_mask = torch.rand(1, H, W, generator=g) > 0.4               # Camera.compute_grad_mask yields a bool mask
+    vp = _Viewpoint()
+    vp.original_image = gt_image.as_subclass(_StaysHere)
+    vp.depth = gt_depth.numpy()
+    vp.grad_mask = grad_mask
+    vp.exposure_a = torch.tensor([a], requires_grad=True)
+    vp.exposure_b = torch.tensor([b], requires_grad=True)
+    cfg = {"Training": {"alpha": alpha, "rgb_boundary_threshold": thr}}
+    loss = get_loss_tracking(cfg, image, depth, opacity, vp)                                # the reference
+    loss.backward()
+    return dict(image=image.detach(), depth=depth.detach(), opacity=opacity, gt_image=gt_image, gt_depth=gt_depth,
+                grad_mask=grad_mask.to(torch.float32), a=torch.tensor([a]), b=torch.tensor([b]),
+                alpha=torch.tensor(alpha, dtype=torch.float64), thr=torch.tensor(thr, dtype=torch.float64),
+                loss=loss.detach(), d_image=image.grad, d_depth=depth.grad, d_a=vp.exposure_a.grad,
+                d_b=vp.exposure_b.grad)
+
+
 def main():
     out = {}
+    tcases = [(11, 24, 40, 0.07, -0.02, 0.9, 0.01), (12, 33, 21, -0.2, 0.04, 0.95, 0.5)]
+    for i, c in enumerate(tcases):
+        for k, v in tracking_case(*c).items():
+            out[f"t{i}_{k}"] = v.numpy()
+    out["n_tracking_cases"] = np.array(len(tcases))
     cases = [(1, 24, 40, 15, 12, 12, 0.07, -0.02, 0.95, 0.01, False),
              (2, 33, 21, 15, 48, 40, -0.3, 0.05, 0.9, 0.6, False),       # downsampling target, odd sizes
              (3, 16, 16, 3, 5, 7, 0.0, 0.0, 0.95, 0.01, True)]           # initialization: no exposure transform

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import loss_oracle  # noqa: E402
-from test_loss_oracle_golden import golden_cases, run_oracle  # noqa: E402
+from test_loss_oracle_golden import golden_cases, golden_tracking_cases, run_oracle  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -128,3 +128,35 @@ def test_loss_feeds_the_rasterizer_backward(hip):
     step = 0.02 / float(gop.abs().max())
     _, lo1 = loss_at((op0 - step * gop).clamp(1e-4, 1 - 1e-4))
     assert float(lo1["loss"][0]) < l0
+
+
+def test_tracking_loss_golden_and_oracle(hip):
+    """olsr_tracking_loss against the vectors from the reference's get_loss_tracking and, at full size, the oracle."""
+    from online_lang_splatting_amd import losses
+    dev = torch.device(DEV)
+    for c in golden_tracking_cases():
+        expo = torch.cat([c["a"], c["b"]]).float().to(dev)
+        o = losses.tracking_loss(c["image"].to(dev), c["depth"].to(dev), c["opacity"].to(dev), c["gt_image"].to(dev),
+                                 c["gt_depth"].to(dev), c["grad_mask"].to(dev), expo, alpha=float(c["alpha"]),
+                                 rgb_boundary_threshold=float(c["thr"]))
+        _close(o["loss"][0], c["loss"], "loss")
+        _close(o["dL_dimage"], c["d_image"], "dL_dimage")
+        _close(o["dL_ddepth"], c["d_depth"], "dL_ddepth")
+        assert abs(float(o["dL_dexposure"][0]) - float(c["d_a"])) <= 1e-6
+        assert abs(float(o["dL_dexposure"][1]) - float(c["d_b"])) <= 1e-6
+        assert torch.equal(o["dL_dimage"].cpu() == 0, c["d_image"] == 0)
+        assert torch.equal(o["dL_ddepth"].cpu() == 0, c["d_depth"] == 0)
+    H, W = 680, 1200
+    g = torch.Generator().manual_seed(9)
+    image, depth = torch.rand(3, H, W, generator=g), torch.rand(1, H, W, generator=g) * 5
+    opacity = torch.rand(1, H, W, generator=g) * 0.2 + 0.85
+    gt_image, gt_depth = torch.rand(3, H, W, generator=g), torch.rand(H, W, generator=g) * 5
+    gm = torch.rand(1, H, W, generator=g) > 0.5
+    a, b = torch.tensor([0.05]), torch.tensor([0.01])
+    ref = loss_oracle.tracking_loss_and_grads(image, depth, opacity, gt_image, gt_depth, gm, a, b)
+    o = losses.tracking_loss(image.to(dev), depth.to(dev), opacity.to(dev), gt_image.to(dev), gt_depth.to(dev), gm.to(dev),
+                             torch.cat([a, b]).to(dev))
+    _close(o["loss"][0], ref["loss"], "loss")
+    _close(o["dL_dimage"], ref["dL_dimage"], "dL_dimage")
+    _close(o["dL_ddepth"], ref["dL_ddepth"], "dL_ddepth")
+    assert abs(float(o["dL_dexposure"][0]) - float(ref["dL_da"])) <= 2e-6
