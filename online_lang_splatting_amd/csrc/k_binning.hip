@@ -430,12 +430,21 @@ __global__ __launch_bounds__(256) void emit_big_kernel(const uint4* __restrict__
   const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
   const int count = counters[5];
+  if (wave >= count) return;
+  // the next item's descriptor and record are fetched while the current one is written
+  uint4 it = big_list[wave];
+  float4 r0 = emit_rec[2 * (size_t)it.x], r1 = emit_rec[2 * (size_t)it.x + 1];
   for (int item = wave; item < count; item += nwaves) {
-    const uint4 it = big_list[item];
     const u32 g = it.x, off = it.y, n = it.z;
-    const float4 r0 = emit_rec[2 * (size_t)g], r1 = emit_rec[2 * (size_t)g + 1];
-    const int rad = __float_as_int(r1.z);
-    const Rect rc = get_rect<TILE>(r0.x, r0.y, rad, gx, gy);
+    const float4 c0 = r0, c1 = r1;
+    {
+      const int nxt = item + nwaves;
+      it = big_list[nxt < count ? nxt : item];
+      r0 = emit_rec[2 * (size_t)it.x];
+      r1 = emit_rec[2 * (size_t)it.x + 1];
+    }
+    const int rad = __float_as_int(c1.z);
+    const Rect rc = get_rect<TILE>(c0.x, c0.y, rad, gx, gy);
     if (!ellipse) {
       const u32 wrect = (u32)(rc.x1 - rc.x0);
       for (u32 t = (u32)lane; t < n; t += 64) {
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(256) void emit_big_kernel(const uint4* __restrict__
       }
       continue;
     }
-    const CullEllipse e = cull_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rad);
+    const CullEllipse e = cull_setup(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rad);
     int y0, y1;
     cull_rows<TILE>(e, rc.y0, rc.y1, y0, y1);
     // lane l evaluates rows y0 + l, y0 + l + 64, ...; a wave scan turns the spans into offsets
@@ -639,20 +648,26 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
 // Rank sort (len <= a few thousand): rank = #tiles heavier, ties by index -> a permutation.
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
                                                          int ntiles) {
-  extern __shared__ u32 s_work[];  // the chunk's weights
-  const int x = blockIdx.x;        // XCD
+  extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 4
+  const int x = blockIdx.x;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   const int len = q + (x < r ? 1 : 0);
-  for (int j = threadIdx.x; j < len; j += blockDim.x) s_work[j] = work[start + j];
+  const int len4 = (len + 3) & ~3;
+  for (int j = threadIdx.x; j < len4; j += blockDim.x) s_work[j] = (j < len) ? work[start + j] : 0u;
   __syncthreads();
   const int i = blockIdx.y * blockDim.x + threadIdx.x;  // one tile per thread
   if (i >= len) return;
   const u32 wi = s_work[i];
   int rank = 0;
-  for (int j = 0; j < len; ++j) {  // wave-uniform LDS broadcast reads
-    const u32 wj = s_work[j];
-    rank += (wj > wi) || (wj == wi && j < i);
+  // wave-uniform 16-byte LDS broadcast reads, four comparisons each; the zero padding never outranks anything
+  // (a padded slot j >= len has weight 0 <= wi and j > i)
+  for (int j = 0; j < len4; j += 4) {
+    const uint4 w4 = *reinterpret_cast<const uint4*>(&s_work[j]);
+    rank += (w4.x > wi) || (w4.x == wi && j < i);
+    rank += (w4.y > wi) || (w4.y == wi && j + 1 < i);
+    rank += (w4.z > wi) || (w4.z == wi && j + 2 < i);
+    rank += (w4.w > wi) || (w4.w == wi && j + 3 < i);
   }
   order[start + rank] = (u32)(start + i);
 }
@@ -660,7 +675,8 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
-  tile_order_kernel<<<dim3(8, (len + 255) / 256), 256, sizeof(u32) * (size_t)len, st>>>(tile_work, tile_order, ntiles);
+  tile_order_kernel<<<dim3(8, (len + 255) / 256), 256, sizeof(u32) * (size_t)(len + 4), st>>>(tile_work, tile_order,
+                                                                                            ntiles);
 }
 
 }  // namespace olsr
