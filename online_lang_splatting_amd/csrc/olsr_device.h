@@ -170,7 +170,9 @@ __device__ __forceinline__ float cull_threshold(float a, float b, float c, float
   if (!(o255 > 0.0f)) return -1.0f;
   const float L = __logf(o255);
   const float D = (float)radius + (float)tile + 1.0f;
-  const float thr = L + 2e-3f + 1e-4f * fabsf(L) + 5e-7f * (a + c + fabsf(b)) * D * D;
+  // (|a| + |c|: a conic that came out of a rounded-to-negative determinant is not positive definite; such
+  //  Gaussians keep their whole rect below, but the bound must not turn negative here)
+  const float thr = L + 2e-3f + 1e-4f * fabsf(L) + 5e-7f * (fabsf(a) + fabsf(c) + fabsf(b)) * D * D;
   if (!(thr >= 0.0f)) return -1.0f;
   return 2.0f * thr * (1.0f + 1e-6f);
 }

@@ -7,6 +7,8 @@ expression shares its fp32 operation order and the pinned exp; gradients differ 
 order of the cross-pixel summation.  The tests assert exact equality for the forward and
 integer state, and RTOL = 1e-4 (relative to the tensor's largest magnitude) for gradients.
 """
+import os
+
 import pytest
 import torch
 
@@ -184,6 +186,42 @@ def test_needles_and_faint_splats_exact_binning(hip, oracle):
     sc = make_scene(3000, 240, 165, 15, seed=66, camera=cam, scale_mult=6.0)
     sc.scales[:, 2] *= 0.02
     _check(hip, oracle, sc, seed=12, tile=16, grad_keys=COMPOSITE_GRADS)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OLSR_STRESS_SEEDS", "48"))))
+def test_exact_binning_never_drops_a_blending_instance(hip, seed):
+    """Randomised stress of the conservative interval arithmetic behind the exact tile lists (no oracle needed):
+    random anisotropy up to 3000:1, scale, opacity around the alpha floor, off-screen and near-plane splats,
+    rotated cameras, both tile sizes.  The exact lists must give bit-identical images / n_touched, and every
+    instance that blends a pixel under the reference binning must still be listed."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    W, H = (211, 143) if seed % 2 else (160, 120)
+    tile = 16 if seed % 3 == 0 else 15
+    cam = default_camera(W, H, yaw_deg=float(torch.rand(1, generator=g) * 40 - 20), tx=float(torch.rand(1, generator=g) - 0.5))
+    sc = make_scene(3000, W, H, 15, seed=2000 + seed, camera=cam, scale_mult=float(10 ** (torch.rand(1, generator=g) * 2 - 1)))
+    sc.scales *= torch.exp(torch.randn(sc.P, 3, generator=g) * 2.0)            # anisotropy
+    sc.opacities[:] = torch.sigmoid(torch.randn(sc.P, 1, generator=g) * 3 - 2).reshape(sc.opacities.shape)
+    sc.opacities[::7] = (torch.rand(len(sc.opacities[::7]), generator=g) * 0.012).reshape(sc.opacities[::7].shape)  # ~ 1/255
+    dev = torch.device(DEV)
+    fr, gr = run_backend(hip, sc, dev, seed, tile, _abi.BWD_EXACT, binning=_abi.BINNING_RECT)
+    fe, ge = run_backend(hip, sc, dev, seed, tile, _abi.BWD_EXACT, binning=_abi.BINNING_ELLIPSE)
+    assert fe["R"] <= fr["R"]
+    for k in ("color", "language", "depth", "opacity", "radii", "n_touched"):
+        assert torch.equal(fe[k], fr[k]), k
+    if fr["R"] > 0:
+        kr, flr, _ = _tile_pairs(hip, fr, sc, tile)
+        if fe["R"] > 0:
+            ke, fle, _ = _tile_pairs(hip, fe, sc, tile)
+            keep = torch.isin(kr, ke)
+            assert int(keep.sum()) == ke.numel() and torch.equal(kr[keep], ke)
+            assert torch.equal(flr[keep] & 15, fle & 15)
+        else:
+            keep = torch.zeros_like(kr, dtype=torch.bool)
+        assert int(((flr[~keep] & 15) != 0).sum()) == 0
+    for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dlanguage"):
+        r, _ = rel_err(ge[k], gr[k])
+        assert r <= 1e-5, (k, r)
+    hip.TILE, hip.BWD_MODE, hip.BINNING = 15, 0, 1
 
 
 def test_transparent_scene_walks_whole_lists(hip, oracle):
