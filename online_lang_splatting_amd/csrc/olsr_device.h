@@ -166,6 +166,9 @@ __device__ __forceinline__ Rect get_rect(float px, float py, int max_radius, int
 // and two sums of the composite's `power` at distances up to D = radius + TILE + 1.  Negative:
 // no pixel can pass.
 __device__ __forceinline__ float cull_threshold(float a, float b, float c, float opacity, int radius, int tile) {
+  // not-a-number anywhere: the composite's comparisons then all fail and it blends alpha = 0.99 (fminf_ref): keep
+  // every tile of the rect (3e38 makes cull_setup fall back to the full spans)
+  if (a != a || b != b || c != c || opacity != opacity) return 3e38f;
   const float o255 = 255.0f * opacity;
   if (!(o255 > 0.0f)) return -1.0f;
   const float L = __logf(o255);
@@ -173,8 +176,9 @@ __device__ __forceinline__ float cull_threshold(float a, float b, float c, float
   // (|a| + |c|: a conic that came out of a rounded-to-negative determinant is not positive definite; such
   //  Gaussians keep their whole rect below, but the bound must not turn negative here)
   const float thr = L + 2e-3f + 1e-4f * fabsf(L) + 5e-7f * (fabsf(a) + fabsf(c) + fabsf(b)) * D * D;
+  if (thr != thr) return 3e38f;
   if (!(thr >= 0.0f)) return -1.0f;
-  return 2.0f * thr * (1.0f + 1e-6f);
+  return fminf(2.0f * thr * (1.0f + 1e-6f), 3e38f);
 }
 
 struct CullEllipse {
