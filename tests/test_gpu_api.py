@@ -269,6 +269,46 @@ def test_full_size_config3_properties(hip):
     hip.TILE, hip.BWD_MODE, hip.BINNING = 15, 0, 1
 
 
+def test_full_size_config5_properties(hip):
+    """BASELINE.json configs[4], one of its eight views: 2 M Gaussians, 1920x1080, F = 32 — the large-sort paths
+    (> 1000 radix blocks, device-wide scans), 9 216 tiles, 192-byte gradient rows.  Oracle-free properties:
+    range partition, front-to-back order, opacity identity, finite outputs, run-to-run determinism, and
+    agreement of the two binning modes."""
+    dev = torch.device(DEV)
+    sc = make_config_scene(5)
+    P, W, H, F = sc.P, 1920, 1080, 32
+    fg, g1 = run_backend(hip, sc, dev, 5, 15, 0)
+    R = fg["R"]
+    cnt = hip.state_field("geometry", fg["geom"], "counters", P=P, F=F, dtype=torch.int32, count=8)
+    assert int(cnt[3]) == 14948564 and 6_000_000 < R < 11_000_000
+    gx, gy = math.ceil(W / 15), math.ceil(H / 15)
+    pl = hip.state_field("binning", fg["binning"], "point_list", R=R, F=F, dtype=torch.int32, count=R).long()
+    rg = hip.state_field("image", fg["img"], "ranges", W=W, H=H, dtype=torch.int32, count=2 * gx * gy).view(-1, 2).long()
+    lens = rg[:, 1] - rg[:, 0]
+    assert int(lens.sum()) == R
+    depths = hip.state_field("geometry", fg["geom"], "depths", P=P, F=F, dtype=torch.float32, count=P)
+    d = depths[pl]
+    tile_of = torch.repeat_interleave(torch.arange(gx * gy, device=dev), lens)
+    same_tile = tile_of[1:] == tile_of[:-1]
+    assert bool((d[1:][same_tile] >= d[:-1][same_tile]).all())
+    final_T = hip.state_field("image", fg["img"], "final_T", W=W, H=H, dtype=torch.float32, count=W * H)
+    assert torch.equal(fg["opacity"].reshape(-1), 1 - final_T)
+    assert bool(torch.isfinite(fg["color"]).all()) and bool(torch.isfinite(fg["language"]).all())
+    _, g2 = run_backend(hip, sc, dev, 5, 15, 0)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+        assert bool(torch.isfinite(g1[k]).all()), k
+    del g2
+    fr, gr = run_backend(hip, sc, dev, 5, 15, 0, binning=0)
+    assert fr["R"] == 14948564
+    for k in ("color", "language", "depth", "opacity", "radii", "n_touched"):
+        assert torch.equal(fr[k], fg[k]), k
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dlanguage", "dL_dmeans3D"):
+        r, _ = rel_err(g1[k], gr[k])
+        assert r <= 1e-5, (k, r)
+    hip.TILE, hip.BWD_MODE, hip.BINNING = 15, 0, 1
+
+
 def test_fused_accumulate_matches_torch_formulation(hip):
     """olsr_accumulate_gradients == GradientBucket's torch specification (the gloo tests' path)."""
     from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket
