@@ -48,6 +48,17 @@ extern "C" {
  * resize functionals of CR/rasterizer.h:34-36 and DGR/rasterize_points.cu:27-33. */
 typedef void *(*olsr_alloc_fn)(void *user, size_t nbytes);
 
+/* Caller-side activations folded into the kernels.  The reference applies
+ * sigmoid / exp / normalize in PyTorch before every render (GaussianModel.get_opacity / get_scaling /
+ * get_rotation, gaussian_splatting/scene/gaussian_model.py:95-105) and autograd chains back through them.
+ * With a bit set, the corresponding array holds the RAW parameter, preprocess applies
+ *   opacity = 1 / (1 + exp(-x))      scale = exp(x)      rotation = q / max(|q|, 1e-12)
+ * and the backward returns the gradient with respect to the RAW parameter (dL_dopacity, dL_dscales,
+ * dL_drotations and the bucket rows).  With a raw opacity the backward needs scene->opacities too. */
+#define OLSR_ACT_OPACITY_SIGMOID 1
+#define OLSR_ACT_SCALE_EXP 2
+#define OLSR_ACT_ROTATION_NORMALIZE 4
+
 /* How Gaussians are binned into tiles.
  *   OLSR_BINNING_RECT     every tile of the reference's bounding square (getRect, CR/auxiliary.h:46-56):
  *                         instance lists, num_rendered and n_contrib equal the reference's bit for bit.
@@ -92,6 +103,9 @@ typedef struct olsr_scene {
   const float *projmatrix;       /* [16] */
   const float *projmatrix_raw;   /* [16] (backward only; may be NULL in forward) */
   const float *cam_pos;          /* [3] */
+  int32_t activations; /* OLSR_ACT_* bit mask: which parameter arrays are RAW (pre-activation); 0 = the
+                        * reference's calling convention (already activated) */
+  int32_t _pad1;
 } olsr_scene;
 
 /* Sizes of the three opaque state buffers (bytes).  Replace

@@ -13,6 +13,11 @@ OLSR_ERR_CAPACITY = -4
 BWD_REFERENCE = 0
 BWD_EXACT = 1
 
+ACT_OPACITY_SIGMOID = 1      # OLSR_ACT_*: the array holds the raw parameter, the kernels apply the activation
+ACT_SCALE_EXP = 2
+ACT_ROTATION_NORMALIZE = 4
+ACT_ALL = 7
+
 BINNING_RECT = 0     # every tile of the reference's bounding square (bit-identical instance lists)
 BINNING_ELLIPSE = 1  # only tiles the alpha >= 1/255 ellipse reaches (identical outputs, shorter lists)
 
@@ -55,6 +60,8 @@ class OlsrScene(C.Structure):
         ("projmatrix", _fp),
         ("projmatrix_raw", _fp),
         ("cam_pos", _fp),
+        ("activations", C.c_int32),
+        ("_pad1", C.c_int32),
     ]
 
 
@@ -82,7 +89,7 @@ def _ptr(t):
 
 
 def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode, tan_fovx, tan_fovy,
-               scale_modifier, binning=BINNING_RECT, background, means3D, shs, colors_precomp, language_precomp, opacities,
+               scale_modifier, binning=BINNING_RECT, activations=0, background, means3D, shs, colors_precomp, language_precomp, opacities,
                scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos):
     s = OlsrScene()
     s.P, s.D, s.M, s.F = int(P), int(D), int(M), int(F)
@@ -90,6 +97,7 @@ def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode,
     s.prefiltered, s.debug, s.bwd_mode = int(bool(prefiltered)), int(bool(debug)), int(bwd_mode)
     s.tan_fovx, s.tan_fovy, s.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
     s.binning = int(binning)
+    s.activations = int(activations)
     s.background = _ptr(background)
     s.means3D = _ptr(means3D)
     s.shs = _ptr(shs)

@@ -77,7 +77,7 @@ __device__ __forceinline__ u32 preprocess_one(
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
-    int ellipse) {
+    int ellipse, int act) {
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
   tiles_touched[idx] = 0;
@@ -103,7 +103,19 @@ __device__ __forceinline__ u32 preprocess_one(
 #pragma unroll
     for (int i = 0; i < 6; ++i) cov3D[i] = cov3D_precomp[6 * (size_t)idx + i];
   } else {
-    cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, cov3D);
+    float sc3[3], q4[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float v = scales[3 * (size_t)idx + k];
+      sc3[k] = (act & OLSR_ACT_SCALE_EXP) ? expf(v) : v;
+    }
+    if (act & OLSR_ACT_ROTATION_NORMALIZE) {
+      act_normalize4(rotations + 4 * (size_t)idx, q4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * (size_t)idx + k];
+    }
+    cov3d_from_scale_rot(sc3, scale_modifier, q4, cov3D);
 #pragma unroll
     for (int i = 0; i < 6; ++i) cov3Ds[6 * (size_t)idx + i] = cov3D[i];
   }
@@ -132,7 +144,7 @@ __device__ __forceinline__ u32 preprocess_one(
     rgb[3 * (size_t)idx + 1] = c.y;
     rgb[3 * (size_t)idx + 2] = c.z;
   }
-  const float opacity = opacities[idx];
+  const float opacity = (act & OLSR_ACT_OPACITY_SIGMOID) ? act_sigmoid(opacities[idx]) : opacities[idx];
   depths[idx] = p_view.z;
   radii[idx] = irad;
   means2D[2 * (size_t)idx + 0] = pix_x;
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
-    int ellipse, u32* __restrict__ rect_partials) {
+    int ellipse, int act, u32* __restrict__ rect_partials) {
   __shared__ u32 s_area[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   u32 area = 0;
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     area = preprocess_one<TILE>(idx, D, M, orig_points, scales, scale_modifier, rotations, opacities, shs, clamped,
                                 cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, W, H, tan_fovx,
                                 tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy,
-                                tiles_touched, emit_rec, sort_key, sort_val, n_touched, prefiltered, ellipse);
+                                tiles_touched, emit_rec, sort_key, sort_val, n_touched, prefiltered, ellipse, act);
   // instances of the reference's rect binning (its num_rendered): one partial per block, summed by
   // finalize_counts_kernel (7.8 k same-address atomics would cost more than the whole kernel)
 #pragma unroll
@@ -201,7 +213,7 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
       s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
       g.emit_rec, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
-      reinterpret_cast<u32*>(g.tau_partials)
+      s.activations, reinterpret_cast<u32*>(g.tau_partials)
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

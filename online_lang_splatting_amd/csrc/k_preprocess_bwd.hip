@@ -316,7 +316,8 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float* __restrict__ dL_ddepths, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dtau, float* __restrict__ tau_partials, float* __restrict__ bucket_flat,
-    float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign) {
+    float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign, int act,
+    const float* __restrict__ opacities_raw) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   extern __shared__ float s_bucket[];  // [PB_THREADS][width] when a gradient bucket is given
@@ -342,6 +343,10 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     }
     // bucket row of this Gaussian, staged in LDS: a lane's 116-byte row would be 29 scattered 4-byte stores,
     // the block's rows together are one contiguous span that is written (or added) coalesced at the end
+    if (act & OLSR_ACT_OPACITY_SIGMOID) {  // d sigmoid(x) / dx = o (1 - o)
+      const float o = act_sigmoid(opacities_raw[idx]);
+      acc[5] *= o * (1.0f - o);
+    }
     float* brow = bucket_flat ? s_bucket + (size_t)threadIdx.x * width : nullptr;
     constexpr bool badd = false;  // LDS rows are assigned; assign / add is applied by the block's copy-out
     // what the composite's atomics produced in the reference
@@ -555,8 +560,33 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
           tau[1] += -dm_sh.y;
           tau[2] += -dm_sh.z;
         }
-        if (scales)
-          cov3d_backward(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dcov, dscale, drot);
+        if (scales) {
+          // the activated scale / rotation are recomputed from the raw parameters (OLSR_ACT_*), and the
+          // gradients chained back through exp / normalize
+          float sc3[3], q4[4];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float v = scales[3 * (size_t)idx + k];
+            sc3[k] = (act & OLSR_ACT_SCALE_EXP) ? expf(v) : v;
+          }
+          if (act & OLSR_ACT_ROTATION_NORMALIZE) {
+            act_normalize4(rotations + 4 * (size_t)idx, q4);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * (size_t)idx + k];
+          }
+          cov3d_backward(sc3, scale_modifier, q4, dcov, dscale, drot);
+          if (act & OLSR_ACT_SCALE_EXP) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dscale[k] *= sc3[k];  // d exp(x) / dx = exp(x)
+          }
+          if (act & OLSR_ACT_ROTATION_NORMALIZE) {
+            float graw[4];
+            act_normalize4_backward(rotations + 4 * (size_t)idx, drot, graw);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) drot[k] = graw[k];
+          }
+        }
       }
     }
     if (M > 0 && !sh_written) {
@@ -661,7 +691,8 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
-      o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign);
+      o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign,
+      s.activations, s.opacities);
   if (o.dL_dtau_sum) tau_final_kernel<<<6, 256, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
 }
 

@@ -85,6 +85,12 @@ int check_scene(const olsr_scene* s, bool backward) {
   if (!s->means3D || !s->background || !s->viewmatrix || !s->projmatrix || !s->cam_pos)
     return fail(OLSR_ERR_ARG, "means3D, background, viewmatrix, projmatrix and cam_pos are required");
   if (!backward && !s->opacities) return fail(OLSR_ERR_ARG, "opacities are required");
+  if (s->activations & ~(OLSR_ACT_OPACITY_SIGMOID | OLSR_ACT_SCALE_EXP | OLSR_ACT_ROTATION_NORMALIZE))
+    return fail(OLSR_ERR_ARG, "activations holds unknown OLSR_ACT_* bits");
+  if (backward && (s->activations & OLSR_ACT_OPACITY_SIGMOID) && !s->opacities)
+    return fail(OLSR_ERR_ARG, "a raw (pre-sigmoid) opacity is needed by backward as well");
+  if ((s->activations & (OLSR_ACT_SCALE_EXP | OLSR_ACT_ROTATION_NORMALIZE)) && s->cov3D_precomp)
+    return fail(OLSR_ERR_ARG, "scale / rotation activations make no sense with a precomputed 3D covariance");
   if ((s->shs == nullptr) == (s->colors_precomp == nullptr))
     return fail(OLSR_ERR_ARG, "Please provide excatly one of either SHs or precomputed colors!");
   const bool has_sr = s->scales != nullptr && s->rotations != nullptr;

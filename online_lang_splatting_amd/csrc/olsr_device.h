@@ -361,6 +361,24 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return start + k;
 }
 
+// ---- caller-side activations folded into preprocess (OLSR_ACT_*, include/olsr.h) -----------------------
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ void act_normalize4(const float* q, float* o) {  // F.normalize(q, dim=-1), eps 1e-12
+  const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = q[k] / n;
+}
+// d/dq_raw of normalize: (g - qhat <qhat, g>) / |q|
+__device__ __forceinline__ void act_normalize4_backward(const float* q, const float* g, float* o) {
+  const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+  float h[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h[k] = q[k] / n;
+  const float dot = h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[3] * g[3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (g[k] - h[k] * dot) / n;
+}
+
 // ---- the ranks that survive the reference's 225-lane reduction tree ---------------------------
 // render_cuda_reduce_sum halves g.size() = 225 with integer division (CR/backward.cu:691-702): the steps
 // 112, 56, 28, 14, 7, 3, 1 drop rank 224 and every rank whose residue mod 7 is 2, 5 or 6.  Exactly

@@ -161,9 +161,11 @@ class RasterWorkspace:
 
     def set_scene(self, *, bg, means3D, opacities, scales, rotations, shs, language, viewmatrix, projmatrix,
                   projmatrix_raw, campos, tanfovx, tanfovy, sh_degree, scale_modifier=1.0, colors_precomp=None,
-                  cov3D_precomp=None):
+                  cov3D_precomp=None, activations=0):
         """Bind (borrow) the input tensors of the next forward/backward.  All must be contiguous fp32 on the
-        workspace device."""
+        workspace device.  `activations` (_abi.ACT_* bits): opacities / scales / rotations are the RAW parameters
+        (GaussianModel._opacity, _scaling, _rotation); the kernels apply sigmoid / exp / normalize and the
+        backward returns gradients with respect to the raw parameters."""
         keep = [bg, means3D, shs, colors_precomp, language, opacities, scales, rotations, cov3D_precomp, viewmatrix,
                 projmatrix, projmatrix_raw, campos]
         for t in keep:
@@ -173,7 +175,8 @@ class RasterWorkspace:
         self._scene = _abi.make_scene(
             P=self.P, D=sh_degree, M=self.M if shs is not None else 0, F=self.F, width=self.W, height=self.H,
             tile=self.tile, prefiltered=False, debug=False, bwd_mode=self.bwd_mode, tan_fovx=tanfovx,
-            tan_fovy=tanfovy, scale_modifier=scale_modifier, binning=self.binning_mode, background=bg,
+            tan_fovy=tanfovy, scale_modifier=scale_modifier, binning=self.binning_mode, activations=activations,
+            background=bg,
             means3D=means3D, shs=shs,
             colors_precomp=colors_precomp, language_precomp=language, opacities=opacities, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix,

@@ -165,6 +165,51 @@ def test_fused_bucket_equals_separate_accumulate(hip):
     assert float(ref.flat.abs().max()) > 0 and int((ref.densify[:, 1] == 2).sum()) > 0
 
 
+def test_fused_activations_match_the_pytorch_chain(hip):
+    """OLSR_ACT_*: raw opacity / scale / rotation parameters in, gradients with respect to them out — against
+    PyTorch's sigmoid / exp / normalize around the un-fused path (GaussianModel.get_opacity / get_scaling /
+    get_rotation, gaussian_model.py:95-105, and the autograd chain through them)."""
+    import torch.nn.functional as Fn
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    dev = torch.device(DEV)
+    sc = make_scene(8000, 200, 150, 15, seed=23)
+    cam = sc.camera
+    g = torch.Generator().manual_seed(23)
+    raw_op = torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)).to(dev)
+    raw_sc = torch.log(sc.scales).to(dev)
+    raw_rot = (sc.rotations * (0.3 + 2 * torch.rand(sc.P, 1, generator=g))).to(dev)   # un-normalised quaternions
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(6))
+    base = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev),
+                viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+                projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+                tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+    ws = RasterWorkspace(sc.P, 200, 150, 15, sc.shs.shape[1], 600000, dev)
+    # un-fused: PyTorch activations, gradients chained by autograd
+    ro, rs, rr = (t.clone().requires_grad_(True) for t in (raw_op, raw_sc, raw_rot))
+    act_o, act_s, act_r = torch.sigmoid(ro), torch.exp(rs), Fn.normalize(rr)
+    ws.set_scene(opacities=act_o.detach().contiguous(), scales=act_s.detach().contiguous(),
+                 rotations=act_r.detach().contiguous(), **base)
+    out_ref = {k: v.clone() for k, v in ws.forward().items()}
+    gref = {k: v.clone() for k, v in ws.backward(dc, dl, dd).items()}
+    torch.autograd.backward([act_o, act_s, act_r],
+                            [gref["dL_dopacity"].reshape(act_o.shape), gref["dL_dscales"], gref["dL_drotations"]])
+    # fused
+    ws.set_scene(opacities=raw_op, scales=raw_sc, rotations=raw_rot, activations=_abi.ACT_ALL, **base)
+    out = ws.forward()
+    for k in ("color", "language", "depth", "opacity"):
+        r, e = rel_err(out[k], out_ref[k])
+        assert r <= 2e-5, (k, r)           # expf / sigmoid differ from PyTorch's by an ulp or two
+    assert int((out["radii"] != out_ref["radii"]).sum()) <= 2
+    gf = ws.backward(dc, dl, dd)
+    for name, got, exp in (("opacity", gf["dL_dopacity"].reshape(-1), ro.grad.reshape(-1)), ("scales", gf["dL_dscales"], rs.grad),
+                           ("rotations", gf["dL_drotations"], rr.grad), ("means3D", gf["dL_dmeans3D"], gref["dL_dmeans3D"]),
+                           ("language", gf["dL_dlanguage"], gref["dL_dlanguage"])):
+        r, e = rel_err(got, exp)
+        assert r <= 2e-4, (name, r, e)
+    # a raw opacity must be handed to the backward too, and activations exclude a precomputed covariance
+    assert float(gf["dL_drotations"].abs().max()) > 0 and float(rr.grad.abs().max()) > 0
+
+
 def test_frames_in_flight_are_independent(hip):
     """FrameLanes: three views rendered concurrently on three HIP streams == the same views rendered
     one after the other (bit for bit: no shared scratch, no cross-stream race)."""
