@@ -201,6 +201,25 @@ int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   float *dL_dtau_sum, const olsr_grad_bucket *bucket,
                   int32_t *status_dev, void *hip_stream);
 
+/* ---- optimiser step on the gradient bucket -------------------------------
+ * One fused Adam step over all Gaussian parameters, fed by the flat bucket olsr_backward / the all-reduce
+ * produced: replaces `self.gaussians.optimizer.step()` — torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) over
+ * xyz, f_dc, f_rest, opacity, scaling, rotation, f_language (gaussian_splatting/scene/gaussian_model.py:393-440,
+ * utils/slam_backend.py:747-749) — with the same arithmetic (torch/optim/adam.py, single-tensor path, no
+ * amsgrad / weight decay) and the same DENSE semantics (rows with zero gradient decay their moments and
+ * move).  `step` is the 1-based step count AFTER the increment.  shs is [P,M,3] (k = 0: f_dc, k >= 1:
+ * f_rest); parameter arrays hold whatever the caller optimises (raw parameters with scene.activations).
+ * exp_avg / exp_avg_sq: [P, 11 + 3M + F] in bucket layout, zero before the first step. */
+typedef struct olsr_adam_params {
+  float lr_xyz, lr_sh_dc, lr_sh_rest, lr_opacity, lr_scale, lr_rotation, lr_language;
+  float beta1, beta2, eps; /* 0.9, 0.999, 1e-15 in the reference */
+  int32_t step;
+  int32_t _pad0;
+} olsr_adam_params;
+int olsr_adam_step(int32_t P, int32_t M, int32_t F, const olsr_adam_params *params, const float *flat,
+                   float *means3D, float *shs, float *opacities, float *scales, float *rotations,
+                   float *language, float *exp_avg, float *exp_avg_sq, void *hip_stream);
+
 /* ---- the reference's other native dependency ----------------------------
  * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest neighbours (FLT_MAX counts
  * for a missing neighbour when P < 4).  Replaces simple_knn._C.distCUDA2 -> SimpleKNN::knn

@@ -31,6 +31,7 @@ UNITS = [
     ("k_accumulate.hip", "k_accumulate.o", []),
     ("k_loss.hip", "k_loss.o", []),
     ("k_knn.hip", "k_knn.o", []),
+    ("k_adam.hip", "k_adam.o", []),
 ]
 HEADERS = ["olsr_device.h", "olsr_state.h", "olsr_kernels.h", os.path.join("..", "..", "include", "olsr.h")]
 

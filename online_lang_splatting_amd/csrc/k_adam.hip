@@ -1,0 +1,72 @@
+// k_adam.hip — one fused Adam step over every Gaussian parameter, fed by the flat gradient bucket.
+//
+// Caller side of the path.  The reference steps `torch.optim.Adam(param_groups, lr=0.0,
+// eps=1e-15)` over seven parameter tensors (gaussian_splatting/scene/gaussian_model.py:393-440,
+// utils/slam_backend.py:747-749): per tensor a chain of elementwise PyTorch kernels.  Here the bucket that
+// the frame-sharded step all-reduces IS the gradient of all seven (row = [3 xyz | 3M sh | 1 opacity |
+// 3 scale | 4 rotation | F language]), so one pass reads a row of gradient, parameters and both moments and
+// writes parameters and moments back.  The arithmetic is torch.optim.Adam's single-tensor path, operation for
+// operation (torch/optim/adam.py: lerp, mul/addcmul, sqrt / bias_correction2_sqrt + eps, addcdiv), dense:
+// a Gaussian with zero gradient still decays its moments and moves, exactly as in the reference — a
+// "visible rows only" step would be cheaper but is a different optimiser.
+//
+// HBM-bound: 5 reads + 3 writes of P x width floats, all coalesced (consecutive threads = consecutive floats
+// of the flat arrays; the parameter arrays are [P, k] slices addressed per (row, column)).
+#include "olsr_device.h"
+#include "olsr_kernels.h"
+
+namespace olsr {
+
+constexpr int ADAM_G = 64;  // Gaussians per block, as in k_accumulate.hip
+
+__global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int width, const float* __restrict__ flat,
+                                                        float* __restrict__ means3D, float* __restrict__ shs,
+                                                        float* __restrict__ opacities, float* __restrict__ scales,
+                                                        float* __restrict__ rotations, float* __restrict__ language,
+                                                        float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                        olsr_adam_params hp, float bias_correction1,
+                                                        float bias_correction2_sqrt) {
+  const int g0 = blockIdx.x * ADAM_G;
+  const int ng = min(ADAM_G, P - g0);
+  const int count = ng * width;
+  const int sh_w = 3 * M;
+  const float inv_w = 1.0f / (float)width;
+  const size_t base = (size_t)g0 * width;
+  for (int e = threadIdx.x; e < count; e += 256) {
+    const int gl = (int)(((float)e + 0.5f) * inv_w);
+    const int c = e - gl * width;
+    const size_t g = (size_t)(g0 + gl);
+    float* p;
+    float lr;
+    if (c < 3) { p = means3D + 3 * g + c; lr = hp.lr_xyz; }
+    else if (c < 3 + sh_w) { p = shs + g * sh_w + (c - 3); lr = (c < 6) ? hp.lr_sh_dc : hp.lr_sh_rest; }
+    else if (c < 4 + sh_w) { p = opacities + g; lr = hp.lr_opacity; }
+    else if (c < 7 + sh_w) { p = scales + 3 * g + (c - 4 - sh_w); lr = hp.lr_scale; }
+    else if (c < 11 + sh_w) { p = rotations + 4 * g + (c - 7 - sh_w); lr = hp.lr_rotation; }
+    else { p = language + g * F + (c - 11 - sh_w); lr = hp.lr_language; }
+    const float grad = flat[base + e];
+    float m = exp_avg[base + e], v = exp_avg_sq[base + e];
+    m = m + (grad - m) * (1.0f - hp.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * hp.beta2 + (1.0f - hp.beta2) * grad * grad; // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) / bias_correction2_sqrt + hp.eps;
+    const float step_size = lr / bias_correction1;
+    *p = *p + (-step_size) * (m / denom);               // param.addcdiv_(exp_avg, denom, value=-step_size)
+    exp_avg[base + e] = m;
+    exp_avg_sq[base + e] = v;
+  }
+}
+
+void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* flat, float* means3D, float* shs,
+                      float* opacities, float* scales, float* rotations, float* language, float* exp_avg,
+                      float* exp_avg_sq, hipStream_t st) {
+  if (P <= 0) return;
+  const int width = 11 + 3 * M + F;
+  // the scalar bias corrections are formed in double like torch's Python-float arithmetic
+  const double bc1 = 1.0 - pow((double)hp.beta1, (double)hp.step);
+  const double bc2 = 1.0 - pow((double)hp.beta2, (double)hp.step);
+  adam_step_kernel<<<(P + ADAM_G - 1) / ADAM_G, 256, 0, st>>>(P, M, F, width, flat, means3D, shs, opacities, scales,
+                                                             rotations, language, exp_avg, exp_avg_sq, hp, (float)bc1,
+                                                             (float)sqrt(bc2));
+}
+
+}  // namespace olsr

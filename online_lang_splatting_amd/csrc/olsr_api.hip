@@ -355,6 +355,22 @@ int olsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
   return OLSR_OK;
 }
 
+int olsr_adam_step(int32_t P, int32_t M, int32_t F, const olsr_adam_params* params, const float* flat, float* means3D,
+                   float* shs, float* opacities, float* scales, float* rotations, float* language, float* exp_avg,
+                   float* exp_avg_sq, void* hip_stream) {
+  if (P < 0 || M < 0 || !supported_F(F)) return fail(OLSR_ERR_ARG, "P, M must be >= 0 and F one of 0, 3, 15, 16, 32");
+  if (!params || params->step < 1) return fail(OLSR_ERR_ARG, "adam params are required and step must be >= 1");
+  if (P == 0) return OLSR_OK;
+  if (!flat || !means3D || !opacities || !scales || !rotations || !exp_avg || !exp_avg_sq || (M > 0 && !shs) ||
+      (F > 0 && !language))
+    return fail(OLSR_ERR_ARG, "the bucket, every parameter array and both moment buffers are required");
+  launch_adam_step(P, M, F, *params, flat, means3D, shs, opacities, scales, rotations, language, exp_avg, exp_avg_sq,
+                   (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("adam_step launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
 size_t olsr_knn_scratch_bytes(int32_t P) { return knn_scratch_bytes(P); }
 
 int olsr_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* scratch, void* hip_stream) {

@@ -80,6 +80,11 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
                        const float* dmeans2D, const int32_t* radii, float* flat, float* densify, int32_t* max_radii,
                        hipStream_t st);
 
+// k_adam.hip
+void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* flat, float* means3D, float* shs,
+                      float* opacities, float* scales, float* rotations, float* language, float* exp_avg,
+                      float* exp_avg_sq, hipStream_t st);
+
 // k_knn.hip
 size_t knn_scratch_bytes(int P);
 void launch_knn(int P, const float* points, float* mean_dist2, void* scratch, hipStream_t st);

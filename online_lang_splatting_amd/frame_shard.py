@@ -118,6 +118,38 @@ class GradientBucket:
         dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
 
 
+class FusedAdam:
+    """torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) of the reference's GaussianModel
+    (gaussian_splatting/scene/gaussian_model.py:393-440) as ONE kernel over the gradient bucket
+    (olsr_adam_step, include/olsr.h): same arithmetic, same dense semantics, parameters updated in place."""
+
+    def __init__(self, P, layout: GradLayout, device, betas=(0.9, 0.999), eps=1e-15):
+        self.layout, self.betas, self.eps = layout, betas, eps
+        self.exp_avg = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
+        self.step_count = 0
+
+    def step(self, bucket: GradientBucket, params: Dict[str, torch.Tensor], lrs: Dict[str, float]):
+        """params: means3D [P,3], shs [P,M,3], opacities [P(,1)], scales [P,3], rotations [P,4], language [P,F]
+        (contiguous fp32 on the GPU, updated in place); lrs: xyz, sh_dc, sh_rest, opacity, scale, rotation, language."""
+        self.step_count += 1
+        hp = _abi.OlsrAdamParams(lr_xyz=lrs["xyz"], lr_sh_dc=lrs["sh_dc"], lr_sh_rest=lrs["sh_rest"], lr_opacity=lrs["opacity"],
+                                 lr_scale=lrs["scale"], lr_rotation=lrs["rotation"], lr_language=lrs.get("language", 0.0),
+                                 beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, step=self.step_count)
+        for k, t in params.items():
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                raise RuntimeError(f"FusedAdam: {k} must be a contiguous fp32 tensor on the GPU")
+
+        def p(name):
+            t = params.get(name)
+            return t.data_ptr() if t is not None and t.numel() > 0 else None
+        P = bucket.flat.shape[0]
+        check(lib().olsr_adam_step(P, self.layout.M, self.layout.F, C.byref(hp), bucket.flat.data_ptr(), p("means3D"),
+                                   p("shs"), p("opacities"), p("scales"), p("rotations"), p("language"),
+                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                   C.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)))
+
+
 class RasterWorkspace:
     """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
 

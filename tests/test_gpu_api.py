@@ -210,6 +210,57 @@ def test_fused_activations_match_the_pytorch_chain(hip):
     assert float(gf["dL_drotations"].abs().max()) > 0 and float(rr.grad.abs().max()) > 0
 
 
+def test_fused_adam_equals_torch_optim_adam(hip):
+    """olsr_adam_step over the gradient bucket == torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) over the seven
+    parameter tensors of the reference's GaussianModel (gaussian_model.py:393-440), three steps, dense semantics
+    (a third of the rows get zero gradient in step 2 and must still move)."""
+    from online_lang_splatting_amd.frame_shard import FusedAdam, GradLayout, GradientBucket
+    dev = torch.device(DEV)
+    P, M, F = 5000, 4, 15
+    g = torch.Generator().manual_seed(31)
+    init = dict(means3D=torch.randn(P, 3, generator=g), shs=torch.randn(P, M, 3, generator=g) * 0.3,
+                opacities=torch.randn(P, 1, generator=g), scales=torch.randn(P, 3, generator=g) - 3,
+                rotations=torch.randn(P, 4, generator=g), language=torch.zeros(P, F))
+    lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=2.5e-3 / 20, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
+    # the reference's optimiser (features split into dc / rest as in GaussianModel)
+    ref = {k: v.clone().requires_grad_(True) for k, v in init.items() if k != "shs"}
+    f_dc = init["shs"][:, :1].clone().requires_grad_(True)
+    f_rest = init["shs"][:, 1:].clone().requires_grad_(True)
+    opt = torch.optim.Adam([dict(params=[ref["means3D"]], lr=lrs["xyz"]), dict(params=[f_dc], lr=lrs["sh_dc"]),
+                            dict(params=[f_rest], lr=lrs["sh_rest"]), dict(params=[ref["opacities"]], lr=lrs["opacity"]),
+                            dict(params=[ref["scales"]], lr=lrs["scale"]), dict(params=[ref["rotations"]], lr=lrs["rotation"]),
+                            dict(params=[ref["language"]], lr=lrs["language"])], lr=0.0, eps=1e-15)
+    mine = {k: v.clone().to(dev).contiguous() for k, v in init.items()}
+    bucket = GradientBucket(P, GradLayout(M, F), dev)
+    adam = FusedAdam(P, GradLayout(M, F), dev)
+    for step in range(3):
+        grads = dict(dL_dmeans3D=torch.randn(P, 3, generator=g) * 1e-3, dL_dsh=torch.randn(P, M, 3, generator=g) * 1e-3,
+                     dL_dopacity=torch.randn(P, 1, generator=g) * 1e-2, dL_dscales=torch.randn(P, 3, generator=g) * 1e-3,
+                     dL_drotations=torch.randn(P, 4, generator=g) * 1e-3, dL_dlanguage=torch.randn(P, F, generator=g) * 1e-3,
+                     dL_dmeans2D=torch.randn(P, 3, generator=g))
+        if step == 1:
+            for v in grads.values():
+                v[::3] = 0.0
+        radii = torch.ones(P, dtype=torch.int32)
+        bucket.accumulate({k: v.to(dev) for k, v in grads.items()}, radii.to(dev), first=True)
+        adam.step(bucket, mine, lrs)
+        ref["means3D"].grad, ref["opacities"].grad = grads["dL_dmeans3D"].clone(), grads["dL_dopacity"].clone()
+        ref["scales"].grad, ref["rotations"].grad = grads["dL_dscales"].clone(), grads["dL_drotations"].clone()
+        ref["language"].grad = grads["dL_dlanguage"].clone()
+        f_dc.grad, f_rest.grad = grads["dL_dsh"][:, :1].clone(), grads["dL_dsh"][:, 1:].clone()
+        opt.step()
+    expect = dict(ref, shs=torch.cat([f_dc, f_rest], dim=1))
+    for k in init:
+        torch.testing.assert_close(mine[k].cpu(), expect[k].detach(), rtol=2e-6, atol=2e-7, msg=lambda m, k=k: f"{k}: {m}")  # one ulp of an O(1) parameter
+    m_ref = torch.cat([opt.state[p_]["exp_avg"].reshape(P, -1) for p_ in
+                       (ref["means3D"], f_dc, f_rest, ref["opacities"], ref["scales"], ref["rotations"], ref["language"])], dim=1)
+    v_ref = torch.cat([opt.state[p_]["exp_avg_sq"].reshape(P, -1) for p_ in
+                       (ref["means3D"], f_dc, f_rest, ref["opacities"], ref["scales"], ref["rotations"], ref["language"])], dim=1)
+    # (torch's CPU lerp / addcmul fuse some multiply-adds; a few ulp of the largest entries after three steps)
+    torch.testing.assert_close(adam.exp_avg.cpu(), m_ref, rtol=1e-5, atol=2e-9)
+    torch.testing.assert_close(adam.exp_avg_sq.cpu(), v_ref, rtol=1e-5, atol=1e-11)
+
+
 def test_frames_in_flight_are_independent(hip):
     """FrameLanes: three views rendered concurrently on three HIP streams == the same views rendered
     one after the other (bit for bit: no shared scratch, no cross-stream race)."""
