@@ -183,10 +183,13 @@ def main():
         t0 = time.perf_counter()
         for _ in range(nsteps):
             one_step(pick())
+        issue = time.perf_counter() - t0  # host time to enqueue everything (diagnostic: << el when GPU-bound)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
+        if os.environ.get("OLSR_BENCH_DEBUG"):
+            print(f"[bench] enqueue {1e3 * issue / nsteps:.3f} ms/step, total {1e3 * el / nsteps:.3f} ms/step", file=sys.stderr)
         st = _lib.stage_times() if rank == 0 else []
         _lib.set_profiling(False)
         t = torch.tensor([el], dtype=torch.float64, device=dev)
