@@ -13,11 +13,17 @@
  *   - all float arrays are fp32, row-major, contiguous, resident on the GPU;
  *   - viewmatrix / projmatrix / projmatrix_raw are the 16 floats the Python caller
  *     holds (i.e. the transposes W2C^T, (P*W2C)^T, P^T) — column-major to the kernels;
- *   - opacities are post-sigmoid, scales post-exp, rotations are NOT re-normalised;
+ *   - opacities are post-sigmoid, scales post-exp, rotations are NOT re-normalised (unless
+ *     scene->activations says the arrays are raw, see OLSR_ACT_*);
  *   - outputs are fully overwritten by the library (the caller need not zero them).
  *
  * Error behaviour: every function returns OLSR_OK (0) or a negative code and
  * records a message retrievable with olsr_last_error() (thread-local).
+ *
+ * Contents: the rasterizer itself (olsr_forward, olsr_forward_async, olsr_backward, olsr_mark_visible and
+ * their size / introspection / profiling helpers — SURVEY.md section 8 rows a-e), then the callers and
+ * data either side of it (rows f1-f3): olsr_mapping_loss, olsr_tracking_loss, olsr_accumulate_gradients,
+ * olsr_adam_step, olsr_knn_mean_dist2.
  */
 #ifndef OLSR_H_INCLUDED
 #define OLSR_H_INCLUDED
