@@ -29,7 +29,7 @@ namespace olsr {
 constexpr int FWD_BATCH = 128;
 
 template <int TILE, int F>
-__global__ __launch_bounds__(256, (F <= 16 ? 7 : 4)) void render_fwd_kernel(
+__global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
     const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
