@@ -59,8 +59,9 @@ constexpr int RRS_THREADS = 256;     // lane-per-Gaussian pass
 constexpr u32 RR_BIG = 16;           // rows: above this a Gaussian is reduced by a whole wave
 constexpr int RR_BIG_BLOCKS = 2048;  // persistent grid of the wave-per-Gaussian kernel (8 waves/SIMD)
 
-template <int F>
-__device__ __forceinline__ void add_row(const float* __restrict__ rows, u32 row, float (&acc)[next_pow2_(10 + F)]) {
+template <int F, int N>
+__device__ __forceinline__ void add_row(const float* __restrict__ rows, u32 row, float (&acc)[N]) {
+  static_assert(N >= 10 + F, "accumulator array too small");
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   const float4* p = reinterpret_cast<const float4*>(rows + (size_t)row * ROW);
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(RRS_THREADS) void row_reduce_small_kernel(
     int32_t* __restrict__ counters) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
-  constexpr int NP = next_pow2_(NVAL);
+  constexpr int NP = (NVAL + 3) / 4 * 4;  // (the wave-per-Gaussian kernel needs a power of two, this one does not)
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   u32 idx = 0, first = 0, nrows = 0;
   bool vis = false;  // has instances (a visible Gaussian without any is handled by preprocess_bwd_kernel)
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(RRS_THREADS) void row_reduce_small_kernel(
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = 0; t < nrows; ++t) add_row<F>(rows, first + t, acc);
+    for (u32 t = 0; t < nrows; ++t) add_row<F, NP>(rows, first + t, acc);
     float4* dst = reinterpret_cast<float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
     for (int v4 = 0; v4 < ROW / 4; ++v4)
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float*
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = (u32)lane; t < nrows; t += 64) add_row<F>(rows, first + t, acc);
+    for (u32 t = (u32)lane; t < nrows; t += 64) add_row<F, NP>(rows, first + t, acc);
     wave_reduce_rec<NP / 2, 32, NP>(acc, lane);
     float v = __shfl(acc[0], (lane * G_LANES) & 63);
     if (lane >= NVAL) v = 0.f;
@@ -662,18 +663,29 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
   }
 }
 
-// one block per tau component: 256 threads stride over the block partials, fixed-order reduction
-__global__ __launch_bounds__(256) void tau_final_kernel(const float* __restrict__ partials, int nb,
-                                                        float* __restrict__ out) {
-  __shared__ float red[4];
-  const int comp = blockIdx.x;
-  float acc = 0.f;
-  for (int b = threadIdx.x; b < nb; b += 256) acc += partials[(size_t)b * 6 + comp];
+// one block: 1024 threads stride over the block partials (six consecutive floats each), fixed-order reduction
+__global__ __launch_bounds__(1024) void tau_final_kernel(const float* __restrict__ partials, int nb,
+                                                         float* __restrict__ out) {
+  __shared__ float red[16][6];
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < nb; b += 1024) {
+    const float2* p = reinterpret_cast<const float2*>(partials + (size_t)b * 6);  // 24-byte records: 8-byte aligned
+    const float2 a0 = p[0], a1 = p[1], a2 = p[2];
+    acc[0] += a0.x; acc[1] += a0.y; acc[2] += a1.x; acc[3] += a1.y; acc[4] += a2.x; acc[5] += a2.y;
+  }
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  for (int c = 0; c < 6; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) out[comp] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x < 6) {
+    float v = 0.f;
+    for (int w = 0; w < 16; ++w) v += red[w][threadIdx.x];
+    out[threadIdx.x] = v;
+  }
 }
 
 template <int F>
@@ -693,7 +705,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
       o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign,
       s.activations, s.opacities);
-  if (o.dL_dtau_sum) tau_final_kernel<<<6, 256, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
+  if (o.dL_dtau_sum) tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
 }
 
 void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
