@@ -141,13 +141,20 @@ int olsr_forward(const olsr_scene *scene,
  * the device; `num_rendered_dev` (device int32[2]) receives {R, overflow_flag}.
  * Nothing is rendered when R > capacity (overflow_flag = 1).  This is the entry the
  * benchmark and the frame-sharded trainer use; it has no reference counterpart
- * (SURVEY.md §7 step 8). */
+ * (SURVEY.md §7 step 8).
+ *
+ * tile_order_inout (device uint32[tiles], may be NULL): launch-order hint.  On entry it must hold a
+ * permutation of [0, tiles) in which, inside each eighth of the range (one XCD's share), tiles are
+ * sorted by expected work, heaviest first — the identity is fine for a first frame; on exit it holds
+ * exactly that order measured on THIS frame.  Consecutive frames of a SLAM sequence (and the ~100
+ * tracking iterations per frame) see nearly the same per-tile load, so feeding the array back lets the
+ * forward composite start its stragglers first.  The result never depends on the order. */
 int olsr_forward_async(const olsr_scene *scene,
                        void *geometry_buffer, void *binning_buffer, int64_t capacity,
                        void *image_buffer,
                        float *out_color, float *out_language, float *out_depth, float *out_opacity,
                        int32_t *radii, int32_t *n_touched,
-                       int32_t *num_rendered_dev, void *hip_stream);
+                       int32_t *num_rendered_dev, uint32_t *tile_order_inout, void *hip_stream);
 
 /* Backward.  Replaces RasterizeGaussiansBackwardCUDA / RasterizeLanguageGaussiansBackwardCUDA ->
  * Rasterizer::backward / LanguageRasterizer::backward

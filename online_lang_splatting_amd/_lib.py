@@ -46,7 +46,7 @@ def lib():
     L.olsr_forward.argtypes = [scene_p, _abi.ALLOC_FN, vp, _abi.ALLOC_FN, vp, _abi.ALLOC_FN, vp,
                                vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp]
     L.olsr_forward.restype = C.c_int
-    L.olsr_forward_async.argtypes = [scene_p, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.olsr_forward_async.argtypes = [scene_p, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.olsr_forward_async.restype = C.c_int
     L.olsr_backward_scratch_bytes.argtypes, L.olsr_backward_scratch_bytes.restype = [i64, i32], sz
     L.olsr_backward.argtypes = ([scene_p, vp, vp, i32, vp, vp, _abi.ALLOC_FN, vp, vp, i64] + [vp] * 3 + [vp] * 13

@@ -647,7 +647,7 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
 // heaviest tile of chunk x, so stragglers start early while neighbouring tiles still share an L2.
 // Rank sort (len <= a few thousand): rank = #tiles heavier, ties by index -> a permutation.
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
-                                                         int ntiles) {
+                                                         u32* __restrict__ order_copy, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 4
   const int x = blockIdx.x;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
@@ -670,13 +670,15 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
     rank += (w4.w > wi) || (w4.w == wi && j + 3 < i);
   }
   order[start + rank] = (u32)(start + i);
+  if (order_copy != nullptr) order_copy[start + rank] = (u32)(start + i);  // the caller's hint for its next frame
 }
 
-void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st) {
+void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
+                       hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
   tile_order_kernel<<<dim3(8, (len + 255) / 256), 256, sizeof(u32) * (size_t)(len + 4), st>>>(tile_work, tile_order,
-                                                                                            ntiles);
+                                                                                            order_copy, ntiles);
 }
 
 }  // namespace olsr

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
-    u32* __restrict__ tile_work) {
+    u32* __restrict__ tile_work, const u32* __restrict__ order_hint) {
   constexpr int BS = TILE * TILE;
   constexpr int FR = feat_row(F);
   constexpr int NA = 4 + F;  // r g b depth lang[F]
@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
   __shared__ uint2 s_hit[B];
   __shared__ u32 s_work;
 
-  const int tile_id = xcd_remap((int)blockIdx.x, ntiles);
+  // workgroup b runs on XCD b % 8; with a hint it takes the (b / 8)-th heaviest tile of that XCD's chunk as
+  // measured on the caller's previous frame, else the (b / 8)-th tile of the chunk
+  int tile_id = xcd_remap((int)blockIdx.x, ntiles);
+  if (order_hint != nullptr) tile_id = (int)order_hint[tile_id];
   const int tid = threadIdx.x;
   const int w = tid >> 6;
   const int bx = tile_id % gx, by = tile_id / gx;
@@ -205,37 +208,37 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
 template <int TILE, int F>
 static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                         float* out_opacity, int32_t* n_touched, hipStream_t st) {
+                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
   render_fwd_kernel<TILE, F><<<d.ntiles, 256, 0, st>>>(im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles,
                                                        g.means2D, g.conic_opacity, g.depths, colors,
                                                        s.language_precomp, s.background, im.final_T, im.n_contrib,
                                                        out_color, out_language, out_depth, out_opacity, n_touched,
-                                                       b.flags, im.tile_work);
-  launch_tile_order(im.tile_work, im.tile_order, d.ntiles, st);
+                                                       b.flags, im.tile_work, order_inout);
+  launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, st);
 }
 
 template <int TILE>
 static void launch_fwd_f(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, float* oc, float* ol, float* od, float* oo, int32_t* nt,
-                         hipStream_t st) {
+                         uint32_t* ord, hipStream_t st) {
   switch (s.F) {
-    case 0: launch_fwd_t<TILE, 0>(s, d, g, b, im, oc, ol, od, oo, nt, st); break;
-    case 3: launch_fwd_t<TILE, 3>(s, d, g, b, im, oc, ol, od, oo, nt, st); break;
-    case 15: launch_fwd_t<TILE, 15>(s, d, g, b, im, oc, ol, od, oo, nt, st); break;
-    case 16: launch_fwd_t<TILE, 16>(s, d, g, b, im, oc, ol, od, oo, nt, st); break;
-    case 32: launch_fwd_t<TILE, 32>(s, d, g, b, im, oc, ol, od, oo, nt, st); break;
+    case 0: launch_fwd_t<TILE, 0>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
+    case 3: launch_fwd_t<TILE, 3>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
+    case 15: launch_fwd_t<TILE, 15>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
+    case 16: launch_fwd_t<TILE, 16>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
+    case 32: launch_fwd_t<TILE, 32>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
     default: break;
   }
 }
 
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                            const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                           float* out_opacity, int32_t* n_touched, hipStream_t st) {
+                           float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, hipStream_t st) {
   if (d.tile == 15)
-    launch_fwd_f<15>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, st);
+    launch_fwd_f<15>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout, st);
   else
-    launch_fwd_f<16>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, st);
+    launch_fwd_f<16>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout, st);
 }
 
 }  // namespace olsr

@@ -133,7 +133,7 @@ struct BinningProvider {
 
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
-                 int32_t* num_rendered_host, int32_t* num_rendered_dev, hipStream_t st) {
+                 int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st) {
   const FrameDims d = frame_dims(s);
   const size_t N = (size_t)d.W * d.H;
   size_t gb, ib, bb;
@@ -196,7 +196,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   }
   launch_tile_ranges(sorted_keys, (s.P > 0) ? n_host : 0, n_dev, im.ranges, b.flags, st);
   STAGE("tile_ranges");
-  launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, st);
+  launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
+                        st);
   STAGE("render_forward");
 
   if (num_rendered_dev && s.P == 0) HIP_TRY(hipMemsetAsync(num_rendered_dev, 0, 2 * sizeof(int32_t), st));
@@ -251,12 +252,13 @@ int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* ge
   bp.user = binning_user;
   if (num_rendered) *num_rendered = 0;
   return forward_impl(*scene, geom, img, bp, out_color, out_language, out_depth, out_opacity, radii, n_touched,
-                      num_rendered, nullptr, (hipStream_t)hip_stream);
+                      num_rendered, nullptr, nullptr, (hipStream_t)hip_stream);
 }
 
 int olsr_forward_async(const olsr_scene* scene, void* geometry_buffer, void* binning_buffer, int64_t capacity,
                        void* image_buffer, float* out_color, float* out_language, float* out_depth, float* out_opacity,
-                       int32_t* radii, int32_t* n_touched, int32_t* num_rendered_dev, void* hip_stream) {
+                       int32_t* radii, int32_t* n_touched, int32_t* num_rendered_dev, uint32_t* tile_order_inout,
+                       void* hip_stream) {
   int rc = check_scene(scene, false);
   if (rc != OLSR_OK) return rc;
   if (!geometry_buffer || !binning_buffer || !image_buffer || capacity < 0)
@@ -265,7 +267,7 @@ int olsr_forward_async(const olsr_scene* scene, void* geometry_buffer, void* bin
   bp.fixed = binning_buffer;
   bp.capacity = capacity;
   return forward_impl(*scene, geometry_buffer, image_buffer, bp, out_color, out_language, out_depth, out_opacity,
-                      radii, n_touched, nullptr, num_rendered_dev, (hipStream_t)hip_stream);
+                      radii, n_touched, nullptr, num_rendered_dev, tile_order_inout, (hipStream_t)hip_stream);
 }
 
 int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_buffer, int32_t num_rendered,

@@ -40,7 +40,8 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
                            uint32_t* rowbase, uint32_t* partials, int64_t row_capacity, int32_t* counters,
                            int32_t* status_dev, hipStream_t st);
 // backward launch order: inside each XCD's contiguous chunk of tiles, heaviest (most live pairs) first
-void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, int ntiles, hipStream_t st);
+void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
+                       hipStream_t st);
 // ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
                         uint8_t* flags, hipStream_t st);
@@ -48,7 +49,7 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
 // k_render_fwd.hip
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                            const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                           float* out_opacity, int32_t* n_touched, hipStream_t st);
+                           float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, hipStream_t st);
 
 // k_render_bwd.hip
 // (two translation units, one per backward mode, so they compile in parallel)

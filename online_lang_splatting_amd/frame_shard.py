@@ -175,6 +175,10 @@ class RasterWorkspace:
                         depth=torch.empty(1, H, W, **f32), opacity=torch.empty(1, H, W, **f32),
                         radii=torch.empty(P, **i32), n_touched=torch.empty(P, **i32))
         self.num_rendered = torch.zeros(2, **i32)  # {R, overflow flag}, stays on the device
+        # launch-order hint of the forward composite: heaviest tile first per XCD chunk, as measured on this
+        # workspace's previous frame (consecutive SLAM frames load the tiles alike); identity before the first
+        ntiles = ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
+        self.tile_order = torch.arange(ntiles, **i32)
         self.grads = dict(dL_dmeans2D=torch.empty(P, 3, **f32), dL_dconic=torch.empty(P, 4, **f32),
                           dL_dopacity=torch.empty(P, 1, **f32), dL_dcolors=torch.empty(P, 3, **f32),
                           dL_dlanguage=torch.empty(P, F, **f32), dL_ddepths=torch.empty(P, 1, **f32),
@@ -220,7 +224,7 @@ class RasterWorkspace:
             C.byref(self._scene), self.geom.data_ptr(), self.binning.data_ptr(), self.capacity, self.img.data_ptr(),
             o["color"].data_ptr(), o["language"].data_ptr() if self.F > 0 else None, o["depth"].data_ptr(),
             o["opacity"].data_ptr(), o["radii"].data_ptr(), o["n_touched"].data_ptr(), self.num_rendered.data_ptr(),
-            self._stream()))
+            self.tile_order.data_ptr(), self._stream()))
         return o
 
     def backward(self, dL_dcolor, dL_dlanguage, dL_ddepth, bucket=None, first=False, bucket_only=False,

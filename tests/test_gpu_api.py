@@ -99,6 +99,17 @@ def test_workspace_async_equals_dropin_path(hip):
         assert torch.equal(out[k], fg[k]), k
     for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dlanguage", "dL_dtau"):
         assert torch.equal(g[k].reshape(gg[k].shape), gg[k]), k
+    # the launch-order hint never changes a result: any permutation of the tiles gives the same bits, and the
+    # workspace leaves this frame's heaviest-first order behind for the next one
+    ntiles = ws.tile_order.numel()
+    ws.tile_order.copy_(torch.randperm(ntiles, generator=torch.Generator().manual_seed(3)).to(torch.int32))
+    ws.set_scene(**kw)
+    out_p = ws.forward()
+    g_p = ws.backward(dc, dl, dd)
+    for k in ("color", "language", "depth", "opacity", "radii", "n_touched"):
+        assert torch.equal(out_p[k], fg[k]), k
+    assert torch.equal(g_p["dL_dmeans3D"].reshape(gg["dL_dmeans3D"].shape), gg["dL_dmeans3D"])
+    assert torch.equal(torch.sort(ws.tile_order.long()).values.cpu(), torch.arange(ntiles))
     # capacity overflow is reported, nothing is rendered, nothing crashes
     small = RasterWorkspace(sc.P, 320, 240, 15, sc.shs.shape[1], 1000, dev)
     small.set_scene(**kw)
