@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
   constexpr int NA = 4 + F;  // r g b depth lang[F]
   constexpr int B = FWD_BATCH;
 
-  __shared__ float4 s_geo[B + 1];  // {mean x, mean y, conservative power threshold, -}
-  __shared__ float4 s_co[B + 1];   // {conic a, b, c, opacity}
+  // geometry of two consecutive list entries side by side, so that 16-byte LDS reads land as register pairs for
+  // packed fp32 math: {x0 x1 y0 y1} {thr0 thr1 a0 a1} {b0 b1 c0 c1} {op0 op1 - -}
+  __shared__ float4 s_pair[(B / 2) * 4];
   __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
   __shared__ u32 s_id[B];
   __shared__ u32 s_src[B];
@@ -92,6 +93,10 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
     const int cnt = min(B, n - base);
     {
       const int e = tid & (B - 1);
+      if (e == cnt && (cnt & 1) && tid < B) {  // odd tail: the partner slot of the last entry can never be reached
+        float* q = reinterpret_cast<float*>(&s_pair[(e >> 1) * 4]) + 1;
+        q[0] = 0.f; q[2] = 0.f; q[4] = __builtin_inff(); q[6] = 0.f; q[8] = 0.f; q[10] = 0.f; q[12] = 0.f;
+      }
       if (e < cnt) {
         const u32 sp = r0 + (u32)base + (u32)e;
         const u32 u = src[sp];        // emission index of the instance
@@ -106,8 +111,14 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
           // above the error of __logf and of the pinned exp, so that the wave-level early-out
           // below never drops a pair the exact test would keep.
           const float L = -__logf(255.0f * c.w);
-          s_geo[e] = make_float4(m.x, m.y, L - (1e-3f + 1e-4f * fabsf(L)), 0.f);
-          s_co[e] = c;
+          float* q = reinterpret_cast<float*>(&s_pair[(e >> 1) * 4]) + (e & 1);
+          q[0] = m.x;
+          q[2] = m.y;
+          q[4] = L - (1e-3f + 1e-4f * fabsf(L));
+          q[6] = c.x;
+          q[8] = c.y;
+          q[10] = c.z;
+          q[12] = c.w;
         } else {
           float* fr = &s_feat[e * FR];
           fr[0] = colors[3 * (size_t)gid + 0];
@@ -126,36 +137,51 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
     if (done_m != ~0ull) {
       // The lane predicates of CR/forward.cu:449-476 live in scalar registers as 64-bit wave masks: every test
       // is one v_cmp whose result is combined with s_and / s_andn2, "any lane" is an s_cmp, and only the
-      // accumulation runs under a lane mask (inverse_ballot -> exec).  Same tests, same order of arithmetic.
-      for (int j = 0; j < cnt; ++j) {
-        const float4 geo = s_geo[j];
-        const float4 co = s_co[j];
-        const float dx = geo.x - pixfx, dy = geo.y - pixfy;
-        const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-        const u64 live = ~done_m;
-        // wave-level early-out: no live pixel of this slot can reach the alpha floor
-        if ((ballot(!(power < geo.z)) & live) == 0ull) continue;
-        const float alpha = fminf_ref(0.99f, co.w * pinned_expf(power));
-        const float test_T = T * (1 - alpha);
-        const u64 ok_m = ballot(!(power > 0.0f)) & ballot(!(alpha < 1.0f / 255.0f)) & live;
-        const u64 term_m = ok_m & ballot(test_T < 0.0001f);
-        const u64 contrib_m = ok_m & ~term_m;
-        done_m |= term_m;
-        if (contrib_m != 0ull) {
-          if (__builtin_amdgcn_inverse_ballot_w64(contrib_m)) {
-            // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
-            // reference's expression (CR/forward.cu:479-484), and what the oracle restates
-            const v2f* fr2 = reinterpret_cast<const v2f*>(&s_feat[j * FR]);
-            const v2f a2 = {alpha, alpha}, T2 = {T, T};
+      // accumulation runs under a lane mask (inverse_ballot -> exec).  Two list entries are evaluated per
+      // iteration: their geometry, power and exp run on packed fp32 (each component is the IEEE operation of the
+      // scalar code, so the bits are unchanged); the compositing itself stays strictly sequential.
+      const v2f pixx2 = {pixfx, pixfx}, pixy2 = {pixfy, pixfy};
+      for (int j = 0; j < cnt; j += 2) {
+        const float4 q0 = s_pair[(j >> 1) * 4 + 0], q1 = s_pair[(j >> 1) * 4 + 1], q2 = s_pair[(j >> 1) * 4 + 2];
+        const v2f dx = v2f{q0.x, q0.y} - pixx2, dy = v2f{q0.z, q0.w} - pixy2;
+        const v2f ca = {q1.z, q1.w}, cb = {q2.x, q2.y}, cc = {q2.z, q2.w};
+        const v2f power = v2f{-0.5f, -0.5f} * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+        u64 live = ~done_m;
+        // wave-level early-out: no live pixel of this slot can reach the alpha floor of either entry
+        const u64 reach0 = ballot(!(power.x < q1.x)) & live, reach1 = ballot(!(power.y < q1.y)) & live;
+        if ((reach0 | reach1) == 0ull) continue;
+        const float2 op = *reinterpret_cast<const float2*>(&s_pair[(j >> 1) * 4 + 3]);
+        const v2f G = pinned_expf2(power);
+        const float alpha0 = fminf_ref(0.99f, op.x * G.x), alpha1 = fminf_ref(0.99f, op.y * G.y);
 #pragma unroll
-            for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
-            T = test_T;
-            last_contributor = (u32)(base + j + 1);
+        for (int h = 0; h < 2; ++h) {
+          const u64 reach = h ? reach1 : reach0;
+          if (reach == 0ull) continue;
+          const float pw = h ? power.y : power.x, alpha = h ? alpha1 : alpha0;
+          const int jj = j + h;
+          live = ~done_m;
+          const float test_T = T * (1 - alpha);
+          const u64 ok_m = ballot(!(pw > 0.0f)) & ballot(!(alpha < 1.0f / 255.0f)) & live;
+          const u64 term_m = ok_m & ballot(test_T < 0.0001f);
+          const u64 contrib_m = ok_m & ~term_m;
+          done_m |= term_m;
+          if (contrib_m != 0ull) {
+            if (__builtin_amdgcn_inverse_ballot_w64(contrib_m)) {
+              // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
+              // reference's expression (CR/forward.cu:479-484), and what the oracle restates
+              const v2f* fr2 = reinterpret_cast<const v2f*>(&s_feat[jj * FR]);
+              const v2f a2 = {alpha, alpha}, T2 = {T, T};
+#pragma unroll
+              for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
+              T = test_T;
+              last_contributor = (u32)(base + jj + 1);
+            }
+            const u32 tc = (u32)__popcll(contrib_m & ballot(test_T > 0.5f));
+            u32 rec = 0x8000u | tc;
+            if constexpr (TILE == 15) rec |= ((contrib_m & cls_m0) ? 0x100u : 0u) | ((contrib_m & cls_m1) ? 0x200u : 0u);
+            if (lane0) reinterpret_cast<uint16_t*>(s_hit)[4 * jj + w] = (uint16_t)rec;
           }
-          const u32 tc = (u32)__popcll(contrib_m & ballot(test_T > 0.5f));
-          u32 rec = 0x8000u | tc;
-          if constexpr (TILE == 15) rec |= ((contrib_m & cls_m0) ? 0x100u : 0u) | ((contrib_m & cls_m1) ? 0x200u : 0u);
-          if (lane0) reinterpret_cast<uint16_t*>(s_hit)[4 * j + w] = (uint16_t)rec;
+          if (done_m == ~0ull) break;
         }
         if (done_m == ~0ull) break;
       }

@@ -122,6 +122,26 @@ __device__ __forceinline__ float pinned_expf(float x) {
   return e * bits2f((u32)(ni + 127) << 23);
 }
 
+// the same routine on two values at once (packed fp32: every component is the IEEE operation of pinned_expf)
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_ pinned_expf2(v2f_ x) {
+  x.x = __builtin_fmaxf(x.x, -87.0f);
+  x.y = __builtin_fmaxf(x.y, -87.0f);
+  const v2f_ t = x * v2f_{1.44269504088896341f, 1.44269504088896341f};
+  const v2f_ n = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  v2f_ r = __builtin_elementwise_fma(n, v2f_{-0.693359375f, -0.693359375f}, x);
+  r = __builtin_elementwise_fma(n, v2f_{2.12194440e-4f, 2.12194440e-4f}, r);
+  v2f_ p = {1.9875691500e-4f, 1.9875691500e-4f};
+  p = __builtin_elementwise_fma(p, r, v2f_{1.3981999507e-3f, 1.3981999507e-3f});
+  p = __builtin_elementwise_fma(p, r, v2f_{8.3334519073e-3f, 8.3334519073e-3f});
+  p = __builtin_elementwise_fma(p, r, v2f_{4.1665795894e-2f, 4.1665795894e-2f});
+  p = __builtin_elementwise_fma(p, r, v2f_{1.6666665459e-1f, 1.6666665459e-1f});
+  p = __builtin_elementwise_fma(p, r, v2f_{5.0000001201e-1f, 5.0000001201e-1f});
+  const v2f_ e = __builtin_elementwise_fma(p, r * r, r) + v2f_{1.0f, 1.0f};
+  const v2f_ sc = {bits2f((u32)((int)n.x + 127) << 23), bits2f((u32)((int)n.y + 127) << 23)};
+  return e * sc;
+}
+
 // float -> int, truncating and saturating (v_cvt_i32_f32 semantics; NaN -> 0), written out
 // so that the conversion is defined for every input.
 __device__ __forceinline__ int f2i_sat(float v) {
