@@ -12,8 +12,14 @@
 //   * inside a batch the four waves run free: no barrier per splat, a wave leaves the batch as
 //     soon as its 64 pixels are saturated (64-bit ballots), the workgroup stops staging when
 //     all four are;
-//   * n_touched is counted with per-wave popcounts (each wave owns one byte of the splat's LDS
+//   * the kernel is VALU-issue bound, so its inner loop is written for instruction count: the lane
+//     predicates are 64-bit wave masks in scalar registers (v_cmp + s_and, "any lane" = s_cmp, the
+//     accumulation under inverse_ballot), two list entries are evaluated per iteration with their
+//     geometry / power / exp on packed fp32, the accumulation is v_pk_mul_f32 + v_pk_fma_f32;
+//   * n_touched is counted with per-wave popcounts (each wave owns 16 bits of the splat's LDS
 //     record: no LDS atomics) and ONE global integer atomic per (splat, batch);
+//   * tiles are launched heaviest-first inside each XCD's chunk when the caller hands back the
+//     order measured on its previous frame (tile_order_inout of olsr_forward_async);
 //   * the kernel records, per (tile, splat) instance, WHICH 64-pixel slots blended it
 //     (flags[] bits 0-3, indexed by emission position; bits 4-5 say the same for the two packed waves of
 //     the reference-mode backward, see ref15_survives in olsr_device.h).  The backward composite visits only those
