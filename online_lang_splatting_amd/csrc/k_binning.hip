@@ -673,10 +673,23 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
   if (order_copy != nullptr) order_copy[start + rank] = (u32)(start + i);  // the caller's hint for its next frame
 }
 
+// images beyond ~120 k tiles (8K x 8K): a chunk no longer fits the LDS rank sort; keep the natural order
+__global__ __launch_bounds__(256) void tile_order_identity_kernel(u32* __restrict__ order, u32* __restrict__ order_copy,
+                                                                  int ntiles) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntiles) return;
+  order[i] = (u32)i;
+  if (order_copy != nullptr) order_copy[i] = (u32)i;
+}
+
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
+  if (sizeof(u32) * (size_t)(len + 4) > 60 * 1024) {
+    tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_order, order_copy, ntiles);
+    return;
+  }
   tile_order_kernel<<<dim3(8, (len + 255) / 256), 256, sizeof(u32) * (size_t)(len + 4), st>>>(tile_work, tile_order,
                                                                                             order_copy, ntiles);
 }

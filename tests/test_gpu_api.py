@@ -416,6 +416,15 @@ def test_full_size_config5_properties(hip):
     hip.TILE, hip.BWD_MODE, hip.BINNING = 15, 0, 1
 
 
+@pytest.mark.parametrize("W,H,tile", [(7, 5, 15), (16, 16, 16), (4111, 37, 15), (33, 4200, 16)])
+def test_extreme_image_shapes(hip, oracle, W, H, tile):
+    """Images smaller than one tile, exactly one tile, and very wide / very tall strips (hundreds of tiles in one
+    row or column): forward bit-exact and gradients within tolerance against the oracle."""
+    from test_gpu_parity import _check
+    sc = make_scene(1500, W, H, 15, seed=W + H)
+    _check(hip, oracle, sc, seed=3, tile=tile)
+
+
 def test_fused_accumulate_matches_torch_formulation(hip):
     """olsr_accumulate_gradients == GradientBucket's torch specification (the gloo tests' path)."""
     from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket
