@@ -124,8 +124,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one process per GPU over RCCL ("nccl" on ROCm).  OLSR_BENCH_BACKEND=gloo exists only to exercise the N > 1
+        # code path on a box with fewer GPUs than ranks (ranks then share devices; the numbers mean nothing).
+        backend = os.environ.get("OLSR_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -162,16 +167,22 @@ def main():
     capacity = int(R * 1.25) + (1 << 16)
     lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning)
 
+    pending = {}  # bucket id -> outstanding all-reduce handles of that lane's previous frame
+
     def one_step(lane):
         # every rank renders exactly one view per step (weak scaling): its own
         ws, bucket, stream = lane
         with torch.cuda.stream(stream):
             ws.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
             out = ws.forward()
+            # the previous frame's all-reduce of this lane ran while the forward above was enqueued and executed;
+            # the bucket is only rewritten by the backward below
+            for w_ in pending.pop(id(bucket), ()):
+                w_.wait()
             # gradients go straight into the flat bucket (what a mapping step consumes): dL_dmeans3D, dL_dsh,
             # dL_dopacity, dL_dscales, dL_drotations, dL_dlanguage + densification statistics + dL_dtau_sum
             ws.backward(dc, dl, dd, bucket=bucket, first=True, bucket_only=True)
-            bucket.all_reduce()
+            pending[id(bucket)] = bucket.all_reduce(async_op=True)
 
     def timed(nsteps, warmup, pick):
         for _ in range(warmup):
@@ -183,6 +194,10 @@ def main():
         t0 = time.perf_counter()
         for _ in range(nsteps):
             one_step(pick())
+        for lane_ in lanes.lanes:  # the last frames' exchanges belong to the timed region
+            with torch.cuda.stream(lane_[2]):
+                for w_ in pending.pop(id(lane_[1]), ()):
+                    w_.wait()
         issue = time.perf_counter() - t0  # host time to enqueue everything (diagnostic: << el when GPU-bound)
         if dist is not None:
             dist.barrier()

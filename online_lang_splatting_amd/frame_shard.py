@@ -109,13 +109,17 @@ class GradientBucket:
         self.densify[:, 1].add_(vis.to(torch.float32))
         torch.maximum(self.max_radii, radii.to(torch.int32), out=self.max_radii)
 
-    def all_reduce(self, group=None):
-        """The one exchange step.  backend 'nccl' is RCCL on ROCm; 'gloo' in the CPU tests."""
+    def all_reduce(self, group=None, async_op=False):
+        """The one exchange step.  backend 'nccl' is RCCL on ROCm; 'gloo' in the CPU tests.
+        async_op=True returns the pending work handles (call .wait() on each before the buffers are read or
+        written again): the collective then overlaps whatever the issuing stream does next — e.g. the forward
+        of this lane's next frame, which does not touch the bucket."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-            return
-        dist.all_reduce(self.sum_storage, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
+            return []
+        works = [dist.all_reduce(self.sum_storage, op=dist.ReduceOp.SUM, group=group, async_op=async_op),
+                 dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group, async_op=async_op)]
+        return works if async_op else []
 
 
 class FusedAdam:

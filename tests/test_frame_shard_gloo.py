@@ -26,7 +26,9 @@ def _worker(rank, world, port, P, M, F, V, ret):
     for v in views_of_rank(V, rank, world):
         g, radii = _fake_view_grads(P, M, F, v)
         b.accumulate(g, radii)
-    b.all_reduce()
+    works = b.all_reduce(async_op=(rank % 2 == 0))  # both forms must interoperate
+    for w in works:
+        w.wait()
     if rank == 0:
         ret["flat"], ret["densify"], ret["max_radii"] = b.flat.clone(), b.densify.clone(), b.max_radii.clone()
     dist.barrier()

@@ -1,0 +1,47 @@
+"""bench.py's contract line, single process and — to exercise the N > 1 code path on a one-GPU box — two ranks
+sharing the GPU over gloo (OLSR_BENCH_BACKEND=gloo; on a multi-GPU node the driver launches it over RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(out):
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError(out[-2000:])
+
+
+def test_single_process_line():
+    p = subprocess.run([sys.executable, "bench.py", "--config", "1", "--steps", "6", "--warmup", "2"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["isolated"]["frames_in_flight_per_gpu"] == 1
+
+
+def test_two_ranks_frame_sharded_over_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OLSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--config", "1",
+                        "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["views_per_step"] == 2 and d["value"] > 0
+    assert "cpu_baseline" not in d
