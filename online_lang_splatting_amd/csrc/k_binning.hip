@@ -361,7 +361,7 @@ void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, in
 //   emit_big_kernel  persistent grid, one wave per listed Gaussian: near splats cover hundreds to
 //                    thousands of tiles and cluster at the front of the depth order, so they are dealt
 //                    to all waves of the chip and written with coalesced stores.
-constexpr u32 EMIT_BIG = 32;
+constexpr u32 EMIT_BIG = OLSR_BIG_FOOTPRINT;
 constexpr int EMIT_BIG_BLOCKS = 512;
 constexpr int EMIT_THREADS = 1024;  // one list atomic per 1024 Gaussians
 
@@ -418,6 +418,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(int P, const u32* __
   const bool is_big = n > EMIT_BIG;
   const u32 slot = block_list_slot(is_big, &counters[5]);
   if (is_big) big_list[slot] = make_uint4(g, off, n, 0u);
+  // second list, from the back of the same array: medium footprints, for the backward's row sums
+  const bool is_mid = n > OLSR_MID_FOOTPRINT && n <= EMIT_BIG;
+  const u32 mslot = block_list_slot(is_mid, &counters[4]);
+  if (is_mid) big_list[(u32)P - 1u - mslot] = make_uint4(g, off, n, 0u);
 }
 
 template <int TILE>
@@ -582,7 +586,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* 
   if (threadIdx.x == 0) {
     const int32_t ov = ((long long)L > row_capacity) ? 1 : 0;
     rowbase[n] = L;
-    counters[4] = 0;  // the backward's work list starts empty
     counters[6] = (int32_t)L;
     counters[7] = ov;
     if (status_dev) {

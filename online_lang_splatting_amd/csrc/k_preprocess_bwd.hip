@@ -4,18 +4,16 @@
 // Replaces the atomicAdd accumulation of CR/backward.cu:1176-1198 together with
 // computeCov2DCUDA (:150-346), preprocessCUDA / language_preprocessCUDA (:418-539, 541-682),
 // computeCov3D (:350-413) and computeColorFromSH (:21-145).  Two kernels:
-//   row_reduce_*_kernel — sums, per Gaussian, the partial-gradient rows its (instance, slot)
-//     pairs received from the backward composite.  Rows are compacted in emission (= depth)
-//     order, so a Gaussian's rows are ONE dense run [rowbase[u0], rowbase[u0+n]); the kernels
-//     walk the Gaussians in depth order, neighbouring lanes stream neighbouring runs.  A run
-//     longer than RR_BIG rows (near splats cover thousands of tiles) is not looped over by one
-//     lane: it goes to a work list and a second, persistent kernel gives it a whole wave —
-//     64 lanes stride over the rows, then one multi-value butterfly.  Fixed summation order:
-//     bit-reproducible.
+//   row_reduce_big_kernel — sums the partial-gradient rows of the Gaussians listed in more than
+//     OLSR_MID_FOOTPRINT tiles.  Rows are compacted in emission (= depth) order, so a Gaussian's rows are
+//     ONE dense run [rowbase[u0], rowbase[u0+n]); a near splat owns thousands.  The forward's emission
+//     left two work lists behind; a persistent grid gives every listed Gaussian a whole wave — 64 lanes
+//     stride over the rows, then one multi-value butterfly.  Fixed summation order: bit-reproducible.
 //   preprocess_bwd_kernel — the analytic chain, one lane per Gaussian in INDEX order so that
-//     every per-Gaussian input and output is a coalesced access; dL_dmean2D / dL_dconic /
-//     dL_dcolor / dL_ddepth are taken from the reduced row in registers and the four reference
-//     stages are fused.
+//     every per-Gaussian input and output is a coalesced access.  Gaussians with few tiles (most) sum
+//     their own rows inline, in ascending order; dL_dmean2D / dL_dconic / dL_dcolor / dL_ddepth stay
+//     in registers and the four reference stages are fused.  With a gradient bucket the row of the
+//     flat all-reduce buffer is written (or added) by the same kernel, staged through LDS.
 // Every output row is written exactly once (zeros for culled Gaussians), so no memset of the
 // gradient tensors is needed (the reference zero-fills 12 tensors per call,
 // DGR/rasterize_points.cu:386-398).
@@ -55,8 +53,6 @@ __device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
 }
 
 constexpr int RR_THREADS = 256;
-constexpr int RRS_THREADS = 256;     // lane-per-Gaussian pass
-constexpr u32 RR_BIG = 16;           // rows: above this a Gaussian is reduced by a whole wave
 constexpr int RR_BIG_BLOCKS = 2048;  // persistent grid of the wave-per-Gaussian kernel (8 waves/SIMD)
 
 template <int F, int N>
@@ -75,54 +71,16 @@ __device__ __forceinline__ void add_row(const float* __restrict__ rows, u32 row,
   }
 }
 
-// Pass 1: one lane per Gaussian (depth order).  Its rows are the dense run
-// [rowbase[u0], rowbase[u0 + n]) — ascending (tile, slot) order.  Runs of more than RR_BIG rows are
-// appended to big_list (one aggregated atomic per wave; the list order influences no result).
-template <int F>
-__global__ __launch_bounds__(RRS_THREADS) void row_reduce_small_kernel(
-    int P, const u32* __restrict__ order, const u32* __restrict__ offsets, const u32* __restrict__ rowbase,
-    const float* __restrict__ rows, float* __restrict__ gacc, uint4* __restrict__ big_list,
-    int32_t* __restrict__ counters) {
-  constexpr int ROW = grad_row(F);
-  constexpr int NVAL = 10 + F;
-  constexpr int NP = (NVAL + 3) / 4 * 4;  // (the wave-per-Gaussian kernel needs a power of two, this one does not)
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 idx = 0, first = 0, nrows = 0;
-  bool vis = false;  // has instances (a visible Gaussian without any is handled by preprocess_bwd_kernel)
-  if (r < P && counters[7] == 0) {
-    // offsets = inclusive scan of tiles_touched in depth order: the Gaussian's instance run without
-    // gathering radii / tiles_touched by index
-    const u32 u1 = offsets[r], u0 = (r > 0) ? offsets[r - 1] : 0u;
-    if (u1 > u0) {
-      vis = true;
-      idx = order[r];
-      first = rowbase[u0];
-      nrows = rowbase[u1] - first;
-    }
-  }
-  if (vis && nrows <= RR_BIG) {
-    float acc[NP];
-#pragma unroll
-    for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = 0; t < nrows; ++t) add_row<F, NP>(rows, first + t, acc);
-    float4* dst = reinterpret_cast<float4*>(gacc + (size_t)idx * ROW);
-#pragma unroll
-    for (int v4 = 0; v4 < ROW / 4; ++v4)
-      dst[v4] = make_float4(4 * v4 + 0 < NVAL ? acc[4 * v4 + 0] : 0.f, 4 * v4 + 1 < NVAL ? acc[4 * v4 + 1] : 0.f,
-                            4 * v4 + 2 < NVAL ? acc[4 * v4 + 2] : 0.f, 4 * v4 + 3 < NVAL ? acc[4 * v4 + 3] : 0.f);
-  }
-  const bool is_big = nrows > RR_BIG;
-  const u32 slot = block_list_slot(is_big, &counters[4]);
-  if (is_big) big_list[slot] = make_uint4(idx, first, nrows, 0u);
-}
-
-// Pass 2: one wave per long run: 64 lanes stride over the rows, then one multi-value butterfly.
-// Persistent grid; the work count lives on the device; the next item's descriptor is fetched while
-// the current one is reduced.
+// Row sums of the Gaussians listed in more than OLSR_MID_FOOTPRINT tiles (the forward's emission built the two
+// lists: {Gaussian, first instance, #instances}).  One wave per Gaussian: its rows are the dense run
+// [rowbase[u0], rowbase[u0 + n]) — ascending (tile, wave) order; 64 lanes stride over them, then one multi-value
+// butterfly.  Persistent grid; the next item's descriptor is fetched while the current one is reduced.  Every
+// other Gaussian is summed inline by preprocess_bwd_kernel (at most 4 * OLSR_MID_FOOTPRINT rows, typically a few).
 template <int F>
 __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float* __restrict__ rows,
                                                                     float* __restrict__ gacc,
-                                                                    const uint4* __restrict__ big_list,
+                                                                    const uint4* __restrict__ big_list, int P,
+                                                                    const u32* __restrict__ rowbase,
                                                                     const int32_t* __restrict__ counters) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
@@ -131,13 +89,14 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float*
   const int lane = threadIdx.x & 63;
   const int wave = (int)(blockIdx.x * (RR_THREADS / 64) + (threadIdx.x >> 6));
   const int nwaves = (int)(gridDim.x * (RR_THREADS / 64));
-  const int count = counters[4];
-  if (wave >= count) return;
-  uint4 cur = big_list[wave];
+  const int nbig = counters[5], count = nbig + counters[4];  // front list, then the medium list from the back
+  if (wave >= count || counters[7] != 0) return;
+  auto item_at = [&](int i) { return big_list[i < nbig ? i : P - 1 - (i - nbig)]; };
+  uint4 cur = item_at(wave);
   for (int item = wave; item < count; item += nwaves) {
     const int nxt = item + nwaves;
-    const uint4 next = big_list[nxt < count ? nxt : item];
-    const u32 idx = cur.x, first = cur.y, nrows = cur.z;
+    const uint4 next = item_at(nxt < count ? nxt : item);
+    const u32 idx = cur.x, first = rowbase[cur.y], nrows = rowbase[cur.y + cur.z] - first;
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
@@ -308,7 +267,8 @@ __device__ __forceinline__ void cov3d_backward(const float* scale, float mod, co
 template <int F>
 __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     int P, int D, int M, const float* __restrict__ gacc, const u32* __restrict__ tiles_touched,
-    const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
+    const u32* __restrict__ inst_start, const u32* __restrict__ rowbase, const float* __restrict__ rows,
+    const int32_t* __restrict__ counters, const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
     const uint8_t* __restrict__ clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
     float scale_modifier, const float* __restrict__ cov3Ds, const float* __restrict__ view,
     const float* __restrict__ proj, const float* __restrict__ proj_raw, const float* __restrict__ campos, float h_x,
@@ -331,16 +291,25 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float acc[NVAL];
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) acc[v] = 0.f;
-    if (vis && tiles_touched[idx] > 0) {  // (a Gaussian listed in no tile has no row sum: all zeros)
-      const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
+    const u32 ntiles_g = vis ? tiles_touched[idx] : 0u;  // (a Gaussian listed in no tile has no rows: all zeros)
+    if (ntiles_g > OLSR_MID_FOOTPRINT) {
+      if (counters[7] == 0) {  // summed by row_reduce_big_kernel
+        const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
-      for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
-        const float4 x = row[v4];
-        if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] = x.x;
-        if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] = x.y;
-        if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] = x.z;
-        if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
+        for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
+          const float4 x = row[v4];
+          if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] = x.x;
+          if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] = x.y;
+          if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] = x.z;
+          if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
+        }
       }
+    } else if (ntiles_g > 0 && counters[7] == 0) {
+      // the Gaussian's partial-gradient rows are one dense run (emission order): sum them here, in ascending
+      // (tile, wave) order — no intermediate per-Gaussian buffer
+      const u32 u0 = inst_start[idx];
+      const u32 first = rowbase[u0], nrows = rowbase[u0 + ntiles_g] - first;
+      for (u32 t = 0; t < nrows; ++t) add_row<F, NVAL>(rows, first + t, acc);
     }
     // bucket row of this Gaussian, staged in LDS: a lane's 116-byte row would be 29 scattered 4-byte stores,
     // the block's rows together are one contiguous span that is written (or added) coalesced at the end
@@ -694,12 +663,11 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
                         hipStream_t st) {
   const int nb = tau_partial_blocks(s.P);
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
-  row_reduce_small_kernel<F><<<(s.P + RRS_THREADS - 1) / RRS_THREADS, RRS_THREADS, 0, st>>>(
-      s.P, g.depth_order, g.offsets, b.rowbase, rows, g.gacc, g.big_list, g.counters);
-  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, g.counters);
+  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, s.P, b.rowbase, g.counters);
   const size_t bucket_lds = o.bucket_flat ? sizeof(float) * PB_THREADS * (size_t)(11 + 3 * s.M + s.F) : 0;
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, bucket_lds, st>>>(
-      s.P, s.D, s.M, g.gacc, g.tiles_touched, s.means3D, radii, s.shs, g.clamped,
+      s.P, s.D, s.M, g.gacc, g.tiles_touched, g.inst_start, b.rowbase, rows, g.counters, s.means3D, radii, s.shs,
+      g.clamped,
       s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,

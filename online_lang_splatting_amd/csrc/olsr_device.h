@@ -44,7 +44,9 @@ __device__ __forceinline__ u32 block_list_slot(bool flag, int32_t* counter) {
     s_base = tot ? (u32)atomicAdd(counter, (int)tot) : 0u;
   }
   __syncthreads();
-  return s_base + s_cnt[w] + (u32)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+  const u32 slot = s_base + s_cnt[w] + (u32)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+  __syncthreads();  // the scratch may be reused by a second call
+  return slot;
 }
 
 // ---- gfx950 wave reduction of four values at once -----------------------------------------------

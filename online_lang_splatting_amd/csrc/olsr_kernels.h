@@ -8,6 +8,13 @@
 
 namespace olsr {
 
+// Large-footprint Gaussians go through wave-per-Gaussian kernels.  The forward's emission builds two work lists in
+// geometry big_list: listed in more than OLSR_BIG_FOOTPRINT tiles (from the front, count in counters[5]: emission
+// and row sums) and in OLSR_MID_FOOTPRINT+1 .. OLSR_BIG_FOOTPRINT tiles (from the back, count in counters[4]: row
+// sums only — a lane still emits 32 instances faster than a wave does, but sums that many gradient rows slower).
+constexpr uint32_t OLSR_BIG_FOOTPRINT = 32;
+constexpr uint32_t OLSR_MID_FOOTPRINT = 12;
+
 struct FrameDims {
   int W, H, tile, gx, gy, ntiles;
   float focal_x, focal_y;

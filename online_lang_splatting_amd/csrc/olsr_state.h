@@ -69,8 +69,8 @@ struct GeometryState {
                           //      6 = live rows L, 7 = row-capacity overflow
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
-  uint4* big_list;        // [P] work list of large-footprint Gaussians: emission {id, first instance, #instances, radius}
-                          //     (count: counters[5]); reused by the backward {id, first row, #rows} (count: counters[4])
+  uint4* big_list;        // [P] work lists {id, first instance, #instances} built by the emission: large footprints from
+                          //     the front (count: counters[5]), medium ones from the back (count: counters[4])
   static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
     Carver c(buf);
     GeometryState g;
