@@ -60,3 +60,34 @@ def test_two_rank_all_reduce_equals_single_process():
     # the densification statistic is the sum of per-view norms, not the norm of the summed gradient
     summed = sum(_fake_view_grads(P, M, F, v)[0]["dL_dmeans2D"] for v in range(V))
     assert not torch.allclose(ref.densify[:, 0], summed[:, :2].norm(dim=-1))
+
+
+def test_sharding_and_layout_properties():
+    """Property tests of the host logic (hypothesis): views_of_rank is a partition with balanced shares for every
+    (views, world); GradLayout's slices tile [0, width) in the documented order for every (M, F)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 64), st.integers(1, 16))
+    def partition(V, world):
+        shares = [list(views_of_rank(V, r, world)) for r in range(world)]
+        assert sorted(v for s in shares for v in s) == list(range(V))
+        assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+        assert all(v % world == r for r, s in enumerate(shares) for v in s)   # view v -> rank v mod world
+
+    @settings(max_examples=100, deadline=None)
+    @given(st.integers(0, 16), st.sampled_from([0, 3, 15, 16, 32]))
+    def layout(M, F):
+        lay = GradLayout(M, F)
+        assert lay.width == 3 + 3 * M + 1 + 3 + 4 + F
+        sl = lay.slices()
+        names = [n for n, _ in lay.fields]
+        assert names[0] == "means3D" and names[-1] == ("language" if F > 0 else names[-1])
+        pos = 0
+        for n in names:
+            assert sl[n].start == pos
+            pos = sl[n].stop
+        assert pos == lay.width
+
+    partition()
+    layout()
