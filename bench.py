@@ -17,12 +17,21 @@ frames in flight on S HIP streams with S workspaces (frame k on stream k mod S):
 kernels of one frame overlap the compositing kernels of another, and with N > 1 the all-reduce of
 one frame overlaps the compute of the next.  The timed region still issues exactly K steps.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against the 8 TB/s HBM
-peak using the algorithmic byte model of DESIGN.md §6 and its duration measured with HIP
-events on the launch stream over the timed region (with S > 1 kernels of different frames share
-the GPU, so that duration includes co-scheduling); `isolated` repeats the measurement afterwards
-with ONE frame in flight — clean per-kernel durations and the single-frame latency;
-`cpu_baseline` is the CPU oracle (a port — the reference has no CPU path) on one full frame.
+Rank 0 prints ONE JSON line.  `isolated` repeats the measurement with ONE frame in flight: there the
+intervals between the library's HIP events (recorded on the launch stream) ARE the kernel durations, whereas
+with S > 1 an interval also contains the time a kernel queues behind other frames' kernels.  `roofline`
+therefore takes the dominant kernel — the longest stage of the isolated leg — and prices it three ways:
+  * achieved / frac: SURVEY section 8(d)'s per-unit bytes x the units the launch PROCESSES (instances kept by the
+    exact tile binning, `R_binned`) / its duration, against the 8 TB/s HBM peak (the tier's convention);
+  * model_reference_R: the same per-unit bytes x the reference algorithm's units (its num_rendered);
+  * traffic: HBM bytes per launch by the PMC counters (profiles/*_pmc_traffic.json);
+  * valu: the compositing kernels are VALU-issue bound (bound = "valu"): wave-instructions per launch by the
+    PMC counters (profiles/*_pmc_valu.json) / duration against the chip's issue peak of one wave64 VALU
+    instruction per 2 cycles per SIMD (1024 SIMDs x 2.4 GHz / 2).
+`latency_ms` holds median / p10 / p90 of the per-step completion intervals of the timed region and of the
+isolated leg's per-frame GPU time.  `cpu_baseline` is the CPU oracle (a port — the reference has no CPU path) on
+whole frames of the same workload with all host cores and, once, with one thread; the frame it times is checked
+against the GPU's result of the same view.
 """
 import argparse
 import json
@@ -72,6 +81,32 @@ def measured_traffic(kernel_stage, F):
     return None, None
 
 
+def measured_valu(kernel_stage, F):
+    """VALU wave-instructions per launch of the stage's kernel from the newest profiles/*_pmc_valu.json
+    (rocprofv3 --pmc SQ_INSTS_VALU ... of this same command); None when no summary has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    prefix = {"render_forward": "render_fwd_kernel", "render_backward": "render_bwd_kernel"}[kernel_stage]
+    for k, v in d["kernels"].items():
+        if k.startswith(prefix) and f", {F}" in k:
+            return v, os.path.basename(files[-1])
+    return None, None
+
+
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 cycles per instruction
+
+
+def percentiles(xs):
+    if not xs:
+        return None
+    v = sorted(xs)
+    q = lambda f: v[min(len(v) - 1, max(0, int(round(f * (len(v) - 1)))))]  # noqa: E731
+    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "n": len(v)}
+
+
 def device_inputs(sc, cam, dev):
     g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
              rotations=sc.rotations.to(dev), shs=sc.shs.to(dev),
@@ -82,26 +117,52 @@ def device_inputs(sc, cam, dev):
     return g, c
 
 
-def cpu_baseline(sc, seed, budget_s=12.0, max_frames=6):
+def cpu_baseline(sc, seed, gpu=None, budget_s=12.0, max_frames=6, single_thread=True):
     """The oracle (port) on full frames of the same workload, forward+backward, all host cores: whole
-    frames until about `budget_s` seconds of CPU work have been timed (at least one, at most max_frames)."""
+    frames until about `budget_s` seconds of CPU work have been timed (at least one, at most max_frames);
+    then ONE frame on one thread.  `gpu` = (forward outputs, gradient bucket rows) of the same view from the
+    HIP library: the frame the CPU timed must be that frame (images bit-identical, gradients within 1e-4)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from parity_common import run_backend
+    from parity_common import rel_err, run_backend
     from oracle import oracle_C as O
     threads = os.cpu_count() or 1
-    frames, R = 0, 0
-    t0 = time.perf_counter()
+    O.set_threads(threads)
+    frames, R, dt = 0, 0, 0.0
+    checked = None
     while True:
-        fo, _ = run_backend(O, sc, None, seed, 15, _abi.BWD_REFERENCE)
+        t0 = time.perf_counter()
+        fo, go = run_backend(O, sc, None, seed, 15, _abi.BWD_REFERENCE)
+        dt += time.perf_counter() - t0
         R = fo["R"]
-        O.release(fo["geom"])
         frames += 1
-        dt = time.perf_counter() - t0
+        if frames == 1 and gpu is not None:  # (outside the timed sample)
+            out, flat, sl = gpu
+            same = all(torch.equal(out[k].cpu().reshape(fo[k].shape), fo[k]) for k in ("color", "language", "depth", "opacity")
+                       if fo.get(k) is not None and fo[k].numel())
+            worst = 0.0
+            for name, key in (("means3D", "dL_dmeans3D"), ("opacity", "dL_dopacity"), ("scales", "dL_dscales"),
+                              ("rotations", "dL_drotations"), ("language", "dL_dlanguage")):
+                if go[key].numel():
+                    worst = max(worst, rel_err(flat[:, sl[name]].reshape(go[key].shape), go[key])[0])
+            checked = {"forward_bit_identical": bool(same), "gradient_max_rel_err": float(f"{worst:.3e}"),
+                       "ok": bool(same and worst <= 1e-4)}
+        O.release(fo["geom"])
         if dt >= budget_s or frames >= max_frames:
             break
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} full frame(s) of the same workload (P={sc.P}, R={R}), forward+backward, "
-                      f"OpenMP over tiles/Gaussians on {threads} threads, {dt:.2f} s wall"}
+    res = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{frames} full frame(s) of the same workload (P={sc.P}, R={R}), forward+backward, "
+                     f"OpenMP over tiles/Gaussians on {threads} threads, {dt:.2f} s wall",
+           "checked_against_gpu": checked}
+    if single_thread:
+        O.set_threads(1)
+        t1 = time.perf_counter()
+        fo, _ = run_backend(O, sc, None, seed, 15, _abi.BWD_REFERENCE)
+        d1 = time.perf_counter() - t1
+        O.release(fo["geom"])
+        O.set_threads(threads)
+        res["single_thread"] = {"value": round(1.0 / d1, 5), "unit": "frames/s", "cores": 1,
+                                "sample": f"1 full frame of the same workload, {d1:.2f} s wall"}
+    return res
 
 
 def main():
@@ -115,7 +176,7 @@ def main():
     ap.add_argument("--binning", default="ellipse", choices=["ellipse", "rect"],
                     help="ellipse: exact tile lists (default); rect: the reference's bounding-square lists")
     ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (workspaces on separate HIP streams)")
-    ap.add_argument("--isolated-steps", type=int, default=20, help="steps of the single-stream re-measurement (0 = skip)")
+    ap.add_argument("--isolated-steps", type=int, default=30, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,8 +229,9 @@ def main():
     lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning)
 
     pending = {}  # bucket id -> outstanding all-reduce handles of that lane's previous frame
+    step_done = []  # one event per step of the current timed region, recorded on the step's stream
 
-    def one_step(lane):
+    def one_step(lane, record=False):
         # every rank renders exactly one view per step (weak scaling): its own
         ws, bucket, stream = lane
         with torch.cuda.stream(stream):
@@ -183,6 +245,10 @@ def main():
             # dL_dopacity, dL_dscales, dL_drotations, dL_dlanguage + densification statistics + dL_dtau_sum
             ws.backward(dc, dl, dd, bucket=bucket, first=True, bucket_only=True)
             pending[id(bucket)] = bucket.all_reduce(async_op=True)
+            if record:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(stream)
+                step_done.append(ev)
 
     def timed(nsteps, warmup, pick):
         for _ in range(warmup):
@@ -191,9 +257,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
         _lib.set_profiling(rank == 0)
+        step_done.clear()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            one_step(pick())
+            one_step(pick(), record=True)
         for lane_ in lanes.lanes:  # the last frames' exchanges belong to the timed region
             with torch.cuda.stream(lane_[2]):
                 for w_ in pending.pop(id(lane_[1]), ()):
@@ -210,14 +279,22 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per = {}
+        per, frames_ms = {}, []
         for name, ms in st:
             per.setdefault(name, []).append(ms)
-        return float(t.item()), {k: sum(v) / len(v) for k, v in per.items()}
+            if name == "preprocess":
+                frames_ms.append(0.0)
+            if frames_ms:
+                frames_ms[-1] += ms
+        # completion time of every step since the start of the timed region -> intervals between completions
+        done = sorted(ev0.elapsed_time(e) for e in step_done)
+        gaps = [b_ - a_ for a_, b_ in zip([0.0] + done[:-1], done)]
+        lat = {"step_completion_interval_ms": percentiles(gaps), "frame_gpu_ms": percentiles(frames_ms)}
+        return float(t.item()), {k: sum(v) / len(v) for k, v in per.items()}, lat
 
-    elapsed, avg = timed(a.steps, a.warmup, lanes.next_lane)
+    elapsed, avg, lat = timed(a.steps, a.warmup, lanes.next_lane)
     iso = None
-    if a.isolated_steps > 0 and len(lanes) > 1:
+    if a.isolated_steps > 0:
         iso = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
     ws0 = lanes.lanes[0][0]
     Rr, overflow = ws0.rendered()
@@ -229,23 +306,42 @@ def main():
         frames = world * a.steps
         fps = frames / elapsed
         N = W * H
-        model = algorithmic_bytes(P, R_ref, N, 3, F, M)
-        def roofline_of(av):
+        model = algorithmic_bytes(P, Rr, N, 3, F, M)          # units the launches process (exact tile lists)
+        model_ref = algorithmic_bytes(P, R_ref, N, 3, F, M)   # units of the reference algorithm (its num_rendered)
+
+        def roofline_of(av, where):
             comp = {k: av[k] for k in ("render_forward", "render_backward") if k in av}
             if not comp:
                 return None
             dom = max(comp, key=comp.get)
-            achieved = model[dom] / (av[dom] * 1e-3) / 1e9
+            t_s = av[dom] * 1e-3
+            achieved = model[dom] / t_s / 1e9
             traffic, traffic_src = measured_traffic(dom, F) if a.config == 3 else (None, None)
-            return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": int(model[dom]), "avg_launch_ms": round(av[dom], 4)}
-        roof = roofline_of(avg)
+            valu, valu_src = measured_valu(dom, F) if a.config == 3 else (None, None)
+            r = {"bound": "valu", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                 "traffic_source": traffic_src, "units": {"instances_processed": Rr, "pixels": N},
+                 "algorithmic_bytes_per_launch": int(model[dom]), "avg_launch_ms": round(av[dom], 4),
+                 "measured_in": where,
+                 "model_reference_R": {"instances": R_ref, "algorithmic_bytes_per_launch": int(model_ref[dom]),
+                                       "achieved": round(model_ref[dom] / t_s / 1e9, 2),
+                                       "frac": round(model_ref[dom] / t_s / 1e9 / HBM_PEAK_GBS, 5)}}
+            if traffic:
+                r["traffic_frac"] = round(traffic / t_s / 1e9 / HBM_PEAK_GBS, 5)
+            if valu:
+                ips = valu["SQ_INSTS_VALU"] / t_s
+                r["valu"] = {"insts_per_launch": int(valu["SQ_INSTS_VALU"]), "achieved": round(ips / 1e9, 1),
+                             "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s",
+                             "frac": round(ips / VALU_ISSUE_PEAK, 4), "source": valu_src}
+            return r
+        roof = roofline_of(iso[1], "isolated leg, 1 frame in flight: event intervals == kernel durations") \
+            if iso is not None else roofline_of(avg, f"timed region, {len(lanes)} frame(s) in flight")
         gpu_ms = sum(avg.values())
         frame = {"algorithmic_bytes": int(model["frame"]),
                  "achieved_GBs_wall": round(model["frame"] * fps / world / 1e9, 2),
                  "frac_of_8TBs_wall": round(model["frame"] * fps / world / 1e9 / HBM_PEAK_GBS, 5),
+                 "algorithmic_bytes_reference_R": int(model_ref["frame"]),
+                 "frac_of_8TBs_wall_reference_R": round(model_ref["frame"] * fps / world / 1e9 / HBM_PEAK_GBS, 5),
                  "gpu_stage_ms_sum": round(gpu_ms, 4)}
         out = {
             "metric": "rasterizer fwd+bwd frames/sec @500k Gaussians, 1200x680, 15-dim lang"
@@ -261,19 +357,23 @@ def main():
                        "frames_in_flight_per_gpu": len(lanes), "live_gradient_rows": L_rows,
                        "capacity_overflow": bool(overflow or row_overflow)},
             "roofline": roof,
+            "latency_ms": lat,
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "frame_model": frame,
             "target": {"fps": 40.0, "met": fps / world >= 40.0},
         }
         if iso is not None:
-            iso_el, iso_avg = iso
+            iso_el, iso_avg, iso_lat = iso
             out["isolated"] = {"frames_in_flight_per_gpu": 1, "steps": a.isolated_steps,
                                "value": round(world * a.isolated_steps / iso_el, 3), "unit": "frames/s",
                                "ms_per_frame": round(1e3 * iso_el / a.isolated_steps, 4),
-                               "roofline": roofline_of(iso_avg),
+                               "latency_ms": iso_lat,
                                "stage_ms": {k: round(v, 4) for k, v in iso_avg.items()}}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, a.config)
+            lane0 = lanes.lanes[0]
+            sl = lane0[1].layout.slices()
+            out["cpu_baseline"] = cpu_baseline(sc, a.config, gpu=(lane0[0].out, lane0[1].flat.cpu(), sl),
+                                               single_thread=(a.config in (1, 3)))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -224,8 +224,11 @@ int olsr_backward(const olsr_scene *scene, const int32_t *radii,
  * f_rest); parameter arrays hold whatever the caller optimises (raw parameters with scene.activations).
  * exp_avg / exp_avg_sq: [P, 11 + 3M + F] in bucket layout, zero before the first step. */
 typedef struct olsr_adam_params {
-  float lr_xyz, lr_sh_dc, lr_sh_rest, lr_opacity, lr_scale, lr_rotation, lr_language;
-  float beta1, beta2, eps; /* 0.9, 0.999, 1e-15 in the reference */
+  /* doubles, like the Python floats torch.optim.Adam holds: every scalar the update uses (1 - beta1, 1 - beta2,
+   * the bias corrections, step_size = lr / bias_correction1, sqrt(bias_correction2)) is formed in double on the
+   * host and rounded to fp32 once, exactly where torch rounds it */
+  double lr_xyz, lr_sh_dc, lr_sh_rest, lr_opacity, lr_scale, lr_rotation, lr_language;
+  double beta1, beta2, eps; /* 0.9, 0.999, 1e-15 in the reference */
   int32_t step;
   int32_t _pad0;
 } olsr_adam_params;

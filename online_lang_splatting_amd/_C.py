@@ -56,15 +56,23 @@ class _Resizer:
         return self.t.data_ptr()
 
 
+def current_config():
+    """(TILE, BWD_MODE, BINNING) as they stand now.  The autograd layer captures this at forward time and hands it
+    to the matching backward (`cfg=`), so that changing a knob between a forward and its backward — a SLAM loop
+    renders 12 views before it back-propagates — cannot make the backward carve the state buffers differently."""
+    return (TILE, BWD_MODE, BINNING)
+
+
 def _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-           projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug):
+           projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug, cfg=None):
+    tile, bwd_mode, binning = cfg if cfg is not None else current_config()
     keep = [_c(x) for x in (bg, means3D, sh, colors, language, opacity, scales, rotations, cov3D_precomp, viewmatrix,
                             projmatrix, projmatrix_raw, campos)]
     bg_, m_, sh_, col_, lang_, op_, sc_, rot_, cov_, v_, p_, pr_, cp_ = keep
     M = sh_.shape[1] if sh_ is not None else 0
-    s = _abi.make_scene(P=means3D.shape[0], D=degree, M=M, F=F, width=W, height=H, tile=TILE,
-                        prefiltered=prefiltered, debug=debug, bwd_mode=BWD_MODE, tan_fovx=tan_fovx, tan_fovy=tan_fovy,
-                        scale_modifier=scale_modifier, binning=BINNING, background=bg_, means3D=m_, shs=sh_, colors_precomp=col_,
+    s = _abi.make_scene(P=means3D.shape[0], D=degree, M=M, F=F, width=W, height=H, tile=tile,
+                        prefiltered=prefiltered, debug=debug, bwd_mode=bwd_mode, tan_fovx=tan_fovx, tan_fovy=tan_fovy,
+                        scale_modifier=scale_modifier, binning=binning, background=bg_, means3D=m_, shs=sh_, colors_precomp=col_,
                         language_precomp=lang_, opacities=op_, scales=sc_, rotations=rot_, cov3D_precomp=cov_,
                         viewmatrix=v_, projmatrix=p_, projmatrix_raw=pr_, cam_pos=cp_)
     return s, keep
@@ -125,7 +133,7 @@ def rasterize_language_gaussians(bg, means3D, colors, language, opacity, scales,
 
 def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
               projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language, dL_dout_depth, sh,
-              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, want_internal=False):
+              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, want_internal=False, cfg=None):
     _require_gpu(means3D, "means3D")
     dev = means3D.device
     P = means3D.shape[0]
@@ -133,7 +141,7 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
     with torch.cuda.device(dev):
         s, keep = _scene(F, bg, means3D, colors, language, None, scales, rotations, scale_modifier, cov3D_precomp,
                          viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, False,
-                         debug)
+                         debug, cfg=cfg)
         M = s.M
         f32 = dict(dtype=torch.float32, device=dev)
         # written exactly once per row by the library: no torch::zeros (DGR/rasterize_points.cu:386-398)
@@ -167,11 +175,12 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
 
 def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
-                                 dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
-    """RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:243-331."""
+                                 dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                                 cfg=None):
+    """RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:243-331.  `cfg`: see current_config()."""
     g = _backward(0, bg, means3D, radii, colors, None, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                   projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, None, dL_dout_depths, sh, degree,
-                  campos, geomBuffer, R, binningBuffer, imageBuffer, debug)
+                  campos, geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=cfg)
     return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
             g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
 
@@ -179,12 +188,12 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
 def rasterize_language_gaussians_backward(bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
                                           cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy,
                                           dL_dout_color, dL_dout_language, dL_dout_depth, sh, degree, campos,
-                                          geomBuffer, R, binningBuffer, imageBuffer, debug):
-    """RasterizeLanguageGaussiansBackwardCUDA, DGR/rasterize_points.cu:333-455."""
+                                          geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=None):
+    """RasterizeLanguageGaussiansBackwardCUDA, DGR/rasterize_points.cu:333-455.  `cfg`: see current_config()."""
     g = _backward(language.shape[1], bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
                   cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
                   dL_dout_language, dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                  debug)
+                  debug, cfg=cfg)
     return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dlanguage"], g["dL_dopacity"], g["dL_dmeans3D"],
             g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
 

@@ -74,8 +74,8 @@ class OlsrGradBucket(C.Structure):
 class OlsrAdamParams(C.Structure):
     """struct olsr_adam_params, include/olsr.h."""
 
-    _fields_ = [(n, C.c_float) for n in ("lr_xyz", "lr_sh_dc", "lr_sh_rest", "lr_opacity", "lr_scale", "lr_rotation",
-                                          "lr_language", "beta1", "beta2", "eps")] + [("step", C.c_int32), ("_pad0", C.c_int32)]
+    _fields_ = [(n, C.c_double) for n in ("lr_xyz", "lr_sh_dc", "lr_sh_rest", "lr_opacity", "lr_scale", "lr_rotation",
+                                           "lr_language", "beta1", "beta2", "eps")] + [("step", C.c_int32), ("_pad0", C.c_int32)]
 
 
 class OlsrLossParams(C.Structure):

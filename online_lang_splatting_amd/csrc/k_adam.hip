@@ -19,13 +19,20 @@ namespace olsr {
 
 constexpr int ADAM_G = 64;  // Gaussians per block, as in k_accumulate.hip
 
+// every scalar of the update, formed in double on the host and rounded to fp32 once (torch passes Python floats
+// to lerp_ / mul_ / addcmul_ / addcdiv_, which round them to the tensor's dtype)
+struct AdamScalars {
+  float one_minus_beta1, beta2, one_minus_beta2, bias_correction2_sqrt, eps;
+  float neg_step_xyz, neg_step_sh_dc, neg_step_sh_rest, neg_step_opacity, neg_step_scale, neg_step_rotation,
+      neg_step_language;  // -(lr / bias_correction1)
+};
+
 __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int width, const float* __restrict__ flat,
                                                         float* __restrict__ means3D, float* __restrict__ shs,
                                                         float* __restrict__ opacities, float* __restrict__ scales,
                                                         float* __restrict__ rotations, float* __restrict__ language,
                                                         float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-                                                        olsr_adam_params hp, float bias_correction1,
-                                                        float bias_correction2_sqrt) {
+                                                        AdamScalars hp) {
   const int g0 = blockIdx.x * ADAM_G;
   const int ng = min(ADAM_G, P - g0);
   const int count = ng * width;
@@ -37,20 +44,19 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int
     const int c = e - gl * width;
     const size_t g = (size_t)(g0 + gl);
     float* p;
-    float lr;
-    if (c < 3) { p = means3D + 3 * g + c; lr = hp.lr_xyz; }
-    else if (c < 3 + sh_w) { p = shs + g * sh_w + (c - 3); lr = (c < 6) ? hp.lr_sh_dc : hp.lr_sh_rest; }
-    else if (c < 4 + sh_w) { p = opacities + g; lr = hp.lr_opacity; }
-    else if (c < 7 + sh_w) { p = scales + 3 * g + (c - 4 - sh_w); lr = hp.lr_scale; }
-    else if (c < 11 + sh_w) { p = rotations + 4 * g + (c - 7 - sh_w); lr = hp.lr_rotation; }
-    else { p = language + g * F + (c - 11 - sh_w); lr = hp.lr_language; }
+    float neg_step;
+    if (c < 3) { p = means3D + 3 * g + c; neg_step = hp.neg_step_xyz; }
+    else if (c < 3 + sh_w) { p = shs + g * sh_w + (c - 3); neg_step = (c < 6) ? hp.neg_step_sh_dc : hp.neg_step_sh_rest; }
+    else if (c < 4 + sh_w) { p = opacities + g; neg_step = hp.neg_step_opacity; }
+    else if (c < 7 + sh_w) { p = scales + 3 * g + (c - 4 - sh_w); neg_step = hp.neg_step_scale; }
+    else if (c < 11 + sh_w) { p = rotations + 4 * g + (c - 7 - sh_w); neg_step = hp.neg_step_rotation; }
+    else { p = language + g * F + (c - 11 - sh_w); neg_step = hp.neg_step_language; }
     const float grad = flat[base + e];
     float m = exp_avg[base + e], v = exp_avg_sq[base + e];
-    m = m + (grad - m) * (1.0f - hp.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * hp.beta2 + (1.0f - hp.beta2) * grad * grad; // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const float denom = sqrtf(v) / bias_correction2_sqrt + hp.eps;
-    const float step_size = lr / bias_correction1;
-    *p = *p + (-step_size) * (m / denom);               // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m = m + (grad - m) * hp.one_minus_beta1;              // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * hp.beta2 + hp.one_minus_beta2 * grad * grad;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) / hp.bias_correction2_sqrt + hp.eps;
+    *p = *p + neg_step * (m / denom);                     // param.addcdiv_(exp_avg, denom, value=-step_size)
     exp_avg[base + e] = m;
     exp_avg_sq[base + e] = v;
   }
@@ -61,12 +67,24 @@ void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const flo
                       float* exp_avg_sq, hipStream_t st) {
   if (P <= 0) return;
   const int width = 11 + 3 * M + F;
-  // the scalar bias corrections are formed in double like torch's Python-float arithmetic
-  const double bc1 = 1.0 - pow((double)hp.beta1, (double)hp.step);
-  const double bc2 = 1.0 - pow((double)hp.beta2, (double)hp.step);
+  // torch/optim/adam.py, _single_tensor_adam: Python-float (double) arithmetic for every scalar
+  const double bc1 = 1.0 - pow(hp.beta1, (double)hp.step);
+  const double bc2 = 1.0 - pow(hp.beta2, (double)hp.step);
+  AdamScalars k;
+  k.one_minus_beta1 = (float)(1.0 - hp.beta1);
+  k.beta2 = (float)hp.beta2;
+  k.one_minus_beta2 = (float)(1.0 - hp.beta2);
+  k.bias_correction2_sqrt = (float)sqrt(bc2);
+  k.eps = (float)hp.eps;
+  k.neg_step_xyz = (float)(-(hp.lr_xyz / bc1));
+  k.neg_step_sh_dc = (float)(-(hp.lr_sh_dc / bc1));
+  k.neg_step_sh_rest = (float)(-(hp.lr_sh_rest / bc1));
+  k.neg_step_opacity = (float)(-(hp.lr_opacity / bc1));
+  k.neg_step_scale = (float)(-(hp.lr_scale / bc1));
+  k.neg_step_rotation = (float)(-(hp.lr_rotation / bc1));
+  k.neg_step_language = (float)(-(hp.lr_language / bc1));
   adam_step_kernel<<<(P + ADAM_G - 1) / ADAM_G, 256, 0, st>>>(P, M, F, width, flat, means3D, shs, opacities, scales,
-                                                             rotations, language, exp_avg, exp_avg_sq, hp, (float)bc1,
-                                                             (float)sqrt(bc2));
+                                                             rotations, language, exp_avg, exp_avg_sq, k);
 }
 
 }  // namespace olsr

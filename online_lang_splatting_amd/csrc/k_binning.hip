@@ -584,7 +584,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* 
   const int64_t n = bounded_n(n_host, n_dev);
   const u32 L = block_prefix_of_partials(partials, nb);
   if (threadIdx.x == 0) {
-    const int32_t ov = ((long long)L > row_capacity) ? 1 : 0;
+    // a forward that overflowed its instance capacity (counters[2]) emitted nothing: inst_start / rowbase / rows of
+    // this frame do not exist, so the backward must not read them — report it like a row-capacity overflow (every
+    // later kernel then writes zero gradients)
+    const int32_t ov = ((long long)L > row_capacity || counters[2] != 0) ? 1 : 0;
     rowbase[n] = L;
     counters[6] = (int32_t)L;
     counters[7] = ov;
@@ -600,10 +603,9 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
                            int32_t* status_dev, hipStream_t st) {
   const int shift = packed_ref15 ? 4 : 0;
   const u32 mask = packed_ref15 ? 3u : 15u;
-  if (n_host <= 0) {
-    (void)hipMemsetAsync(rowbase, 0, sizeof(u32), st);
-    (void)hipMemsetAsync(counters + 4, 0, 4 * sizeof(int32_t), st);
-    if (status_dev) (void)hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), st);
+  if (n_host <= 0) {  // zero instance capacity: no rows; an overflowed forward is still reported (counters[2])
+    rows_finalize_kernel<<<1, SCAN_THREADS, 0, st>>>(partials, 0, 0, n_dev, rowbase, (long long)row_capacity, counters,
+                                                     status_dev);
     return;
   }
   const int nb = scan_blocks(n_host);

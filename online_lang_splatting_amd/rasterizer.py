@@ -51,12 +51,14 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
                 raster_settings):
         rs = raster_settings
+        cfg = _C.current_config()  # tile / backward mode / binning of THIS forward, reused by its backward
         (num_rendered, color, radii, geom, binning, img, depth, opacity, n_touched) = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             *_settings_args(rs), rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
             rs.debug)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.olsr_cfg = cfg
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
         return color, radii, depth, opacity, n_touched
@@ -69,7 +71,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          grad_rotations, grad_tau) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             *_settings_args(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-            binning, img, rs.debug)
+            binning, img, rs.debug, cfg=ctx.olsr_cfg)
         grad_theta, grad_rho = _split_tau(grad_tau)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
@@ -82,6 +84,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, language_precomp, opacities, scales, rotations,
                 cov3Ds_precomp, theta, rho, raster_settings):
         rs = raster_settings
+        cfg = _C.current_config()
         (num_rendered, color, language, radii, geom, binning, img, depth, opacity,
          n_touched) = _C.rasterize_language_gaussians(
             rs.bg, means3D, colors_precomp, language_precomp, opacities, scales, rotations, rs.scale_modifier,
@@ -89,6 +92,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
             rs.prefiltered, rs.debug)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.olsr_cfg = cfg
         ctx.save_for_backward(colors_precomp, language_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
@@ -104,7 +108,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
          grad_sh, grad_scales, grad_rotations, grad_tau) = _C.rasterize_language_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, language_precomp, scales, rotations, rs.scale_modifier,
             cov3Ds_precomp, *_settings_args(rs), grad_out_color, grad_out_language, grad_out_depth, sh, rs.sh_degree,
-            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug)
+            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, cfg=ctx.olsr_cfg)
         grad_theta, grad_rho = _split_tau(grad_tau)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_language_precomp, grad_opacities,
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)

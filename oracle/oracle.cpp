@@ -30,6 +30,8 @@
 #include <cstring>
 #include <vector>
 
+#include <omp.h>
+
 #include "../include/olsr.h"
 
 namespace {
@@ -1051,6 +1053,10 @@ int64_t oracle_get_field(void* h, const char* name, void* dst) {
 }
 
 float oracle_expf_probe(float x) { return oracle_expf(x); }
+
+// OpenMP team size of the following calls (bench.py's cpu_baseline: all host cores, and one thread)
+void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int oracle_get_threads() { return omp_get_max_threads(); }
 
 // distCUDA2 / SimpleKNN::knn (/root/reference/submodules/simple-knn/spatial.cu:15-26,
 // simple_knn.cu:131-145,185-221): mean of the squared distances to the 3 nearest neighbours.  The

@@ -56,10 +56,19 @@ def lib():
         L.oracle_get_field.restype = C.c_int64
         L.oracle_knn_mean_dist2.argtypes = [C.c_int32, vp, vp]
         L.oracle_knn_mean_dist2.restype = C.c_int
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_get_threads.restype = C.c_int
         L.oracle_expf_probe.argtypes = [C.c_float]
         L.oracle_expf_probe.restype = C.c_float
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads of the following oracle calls; returns the previous setting."""
+    prev = lib().oracle_get_threads()
+    lib().oracle_set_threads(int(n))
+    return prev
 
 
 class _State:

@@ -32,7 +32,7 @@ for r in csv.DictReader(open(os.path.join(src, "stats", "s_kernel_stats.csv"))):
                                    pct=float(r["Percentage"]))
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    if not re.search(r"render_|row_reduce|preprocess|radix|emit|scan|tile_ranges|tau_final|finalize", k):
+    if not re.search(r"render_|row_|preprocess|radix|sort_pass|emit|scan|tile_|tau_final|finalize|depth_", k):
         continue
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out[k] = dict(FETCH_SIZE_KiB=round(f, 1), WRITE_SIZE_KiB=round(w, 1),
@@ -45,5 +45,39 @@ if os.path.exists(os.path.join(src, "stats1", "s_kernel_stats.csv")):
 for name in ("bench", "bench_cfg1", "bench_cfg2", "bench_cfg5"):
     if os.path.exists(os.path.join(src, name + ".json")) and os.path.getsize(os.path.join(src, name + ".json")):
         shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
+# ---- SQ passes: what bounds the kernels (VALU issue).  Durations from the one-frame-in-flight trace.
+stats1 = {}
+p1 = os.path.join(src, "stats1", "s_kernel_stats.csv")
+if os.path.exists(p1):
+    for r in csv.DictReader(open(p1)):
+        stats1[short(r["Name"])] = float(r["AverageNs"]) / 1e3
+sq = collections.defaultdict(dict)
+for sub in ("sq_a", "sq_b"):
+    path = os.path.join(src, sub, "p_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    names = {r["Counter_Name"] for r in csv.DictReader(open(path))}
+    for c in sorted(names):
+        for k, v in mean_counter(path, c).items():
+            sq[k][c] = v
+valu = {}
+for k, d in sq.items():
+    if not re.search(r"render_|preprocess|radix|sort_pass|emit|scan|row_", k) or "SQ_INSTS_VALU" not in d:
+        continue
+    e = {c: int(v) for c, v in d.items()}
+    us = stats1.get(k) or stats.get(k, {}).get("avg_us")
+    if us:
+        e["avg_us_1_in_flight"] = round(us, 2)
+        # one wave64 VALU instruction per 2 cycles per SIMD-32; 1024 SIMDs at 2.4 GHz
+        e["valu_issue_frac_of_peak"] = round(d["SQ_INSTS_VALU"] / (us * 1e-6) / (1024 * 2.4e9 / 2), 4)
+    if d.get("SQ_WAVE_CYCLES"):
+        e["valu_active_over_wave_cycles"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_WAVE_CYCLES"], 4) if "SQ_ACTIVE_INST_VALU" in d else None
+        e["wait_inst_lds_over_wave_cycles"] = round(d.get("SQ_WAIT_INST_LDS", 0) / d["SQ_WAVE_CYCLES"], 4)
+    valu[k] = e
+if valu:
+    json.dump(dict(tag=tag, note="means per launch over the dispatches of one rocprofv3 --pmc run each (sq_a: SQ_INSTS_VALU "
+                   "SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS; sq_b: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY "
+                   "SQ_WAIT_INST_LDS), one frame in flight; SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles",
+                   kernels=valu), open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_us"])[:12]:
     print(f"{k:40s} {v['avg_us']:9.2f} us  traffic {v['traffic_bytes']/1e6:9.1f} MB")

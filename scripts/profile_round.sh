@@ -1,19 +1,22 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + separate FETCH_SIZE / WRITE_SIZE
-# PMC passes of the benchmark command.  Outputs under gpurun_out/<tag>/ ; summarise afterwards with
-# scripts/pmc_to_json.py and copy the summaries into profiles/.
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of the benchmark command
+# (FETCH_SIZE, WRITE_SIZE, two SQ passes — counters are collected in their own runs, with --kernel-trace only).
+# Outputs under gpurun_out/<tag>/ ; summarise afterwards with scripts/pmc_to_json.py <tag> and commit profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 STEPS=${2:-20}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline > $OUT/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_write.log 2>&1
+B="python bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B --steps $STEPS --warmup 5 > $OUT/bench_stats.log 2>&1
 # the same kernels with ONE frame in flight (no co-scheduling): per-kernel durations of the `isolated` leg
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- python bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --streams 1 > $OUT/bench_stats1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- $B --steps $STEPS --warmup 5 --streams 1 --isolated-steps 0 > $OUT/bench_stats1.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $B --steps 3 --warmup 1 --streams 1 --isolated-steps 0 > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $B --steps 3 --warmup 1 --streams 1 --isolated-steps 0 > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq_a -o p -- $B --steps 3 --warmup 1 --streams 1 --isolated-steps 0 > $OUT/bench_sq_a.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq_b -o p -- $B --steps 3 --warmup 1 --streams 1 --isolated-steps 0 > $OUT/bench_sq_b.log 2>&1
 python bench.py --steps 60 --warmup 12 > $OUT/bench.json 2> $OUT/bench.err
 for c in 1 2 5; do python bench.py --config $c --steps 40 --warmup 8 > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err; done
 rm -f $OUT/*/*.db
-ls -R $OUT | head -30
+ls -R $OUT | head -40

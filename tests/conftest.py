@@ -13,6 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` tests are skipped (not errored) on a host without a GPU; OLSR_REQUIRE_GPU=1 keeps them hard."""
+    if os.environ.get("OLSR_REQUIRE_GPU") == "1":
+        return
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="no GPU: the -m gpu tests need a real MI355X")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle_C
@@ -22,11 +39,16 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def hip():
-    """The product `_C` surface; the HIP library must be built (no fallback)."""
+    """The product `_C` surface; the HIP library must be built (no fallback).  Without a GPU the `-m gpu` tests are
+    SKIPPED, so a plain `pytest tests` on a CPU box is green; OLSR_REQUIRE_GPU=1 (the GPU runner) turns the skip
+    into a hard failure."""
     import torch
+    if not torch.cuda.is_available():
+        if os.environ.get("OLSR_REQUIRE_GPU") == "1":
+            raise AssertionError("OLSR_REQUIRE_GPU=1 but torch.cuda.is_available() is False")
+        pytest.skip("no GPU: the -m gpu tests need a real MI355X")
     from online_lang_splatting_amd import build
     build.build()
     from online_lang_splatting_amd import _C, _lib
     _lib.lib()
-    assert torch.cuda.is_available(), "GPU tests need cuda:0"
     return _C

@@ -83,3 +83,45 @@ def rel_err(a, b):
         return 0.0, 0.0
     err = (a - b).abs().max().item()
     return err / (b.abs().max().item() + 1e-30), err
+
+
+# north_star / SURVEY.md section 7: "at least 99.99 % of elements within 1e-4 rel (+1e-6 abs), bounded outliers".
+# The absolute term is 1e-6 of the tensor's largest magnitude (gradients span many decades; an absolute 1e-6
+# would be meaningless for tensors of order 1e-9).
+ELEM_RTOL = 1e-4
+ELEM_ATOL_REL = 1e-6
+ELEM_MIN_FRACTION = 0.9999
+
+
+def elementwise_report(a, b, rtol=ELEM_RTOL, atol_rel=ELEM_ATOL_REL):
+    """Per-ELEMENT comparison of `a` (tested) with `b` (oracle).
+    Returns dict(n, frac_within, worst, worst_abs, max_ref): frac_within = fraction of elements with
+    |a-b| <= rtol*|b| + atol_rel*max|b|; worst = the largest |a-b| / (|b| + atol_rel*max|b| / rtol), i.e. the
+    worst element's error in units of the same mixed tolerance (worst <= rtol <=> every element passes)."""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    if a.numel() == 0:
+        return dict(n=0, frac_within=1.0, worst=0.0, worst_abs=0.0, max_ref=0.0)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = b.abs().max().item()
+    diff = (a - b).abs()
+    if not bool(torch.isfinite(diff).all()):
+        return dict(n=a.numel(), frac_within=0.0, worst=float("inf"), worst_abs=float("inf"), max_ref=scale)
+    floor = atol_rel * scale
+    within = diff <= rtol * b.abs() + floor
+    worst = (diff / (b.abs() + floor / rtol + 1e-300)).max().item()
+    return dict(n=a.numel(), frac_within=within.double().mean().item(), worst=worst,
+                worst_abs=diff.max().item(), max_ref=scale)
+
+
+def assert_elementwise(a, b, name, worst_bound, log=None, min_fraction=ELEM_MIN_FRACTION):
+    """Asserts the element-wise criterion and a bound on the worst element (in relative units, see
+    elementwise_report); prints both (pytest -s / the failure message) and appends them to `log`."""
+    r = elementwise_report(a, b)
+    line = (f"{name:24s} n={r['n']:>9d} within={100.0 * r['frac_within']:.5f}% worst_rel={r['worst']:.3e} "
+            f"worst_abs={r['worst_abs']:.3e} max|ref|={r['max_ref']:.3e}")
+    print(line)
+    if log is not None:
+        log.append(dict(name=name, **r))
+    assert r["frac_within"] >= min_fraction, "element-wise criterion: " + line
+    assert r["worst"] <= worst_bound, f"worst element above {worst_bound:g}: " + line
+    return r

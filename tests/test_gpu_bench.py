@@ -27,9 +27,17 @@ def test_single_process_line():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _last_json(p.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"]
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    roof = d["roofline"]
+    assert roof["bound"] == "valu" and roof["unit"] == "GB/s" and 0 < roof["frac"] < 1
+    assert roof["units"]["instances_processed"] <= roof["model_reference_R"]["instances"]
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert cpu["checked_against_gpu"]["ok"], cpu["checked_against_gpu"]   # the CPU timed the frame the GPU rendered
+    assert cpu["single_thread"]["cores"] == 1 and cpu["single_thread"]["value"] > 0
     assert d["isolated"]["frames_in_flight_per_gpu"] == 1
+    for leg in (d["latency_ms"], d["isolated"]["latency_ms"]):
+        q = leg["step_completion_interval_ms"]
+        assert q["p10"] <= q["median"] <= q["p90"] and q["n"] >= 1
 
 
 def test_two_ranks_frame_sharded_over_gloo():
