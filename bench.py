@@ -27,7 +27,8 @@ therefore takes the dominant kernel â€” the longest stage of the isolated leg â€
   * traffic: HBM bytes per launch by the PMC counters (profiles/*_pmc_traffic.json);
   * valu: the compositing kernels are VALU-issue bound (bound = "valu"): wave-instructions per launch by the
     PMC counters (profiles/*_pmc_valu.json) / duration against the chip's issue peak of one wave64 VALU
-    instruction per 2 cycles per SIMD (1024 SIMDs x 2.4 GHz / 2).
+    instruction per quad-cycle per SIMD (1024 SIMDs x 2.4 GHz / 4; the counters show SQ_ACTIVE_INST_VALU ==
+    SQ_INSTS_VALU quad-cycles for every kernel, packed instructions included).
 `latency_ms` holds median / p10 / p90 of the per-step completion intervals of the timed region and of the
 isolated leg's per-frame GPU time.  `cpu_baseline` is the CPU oracle (a port â€” the reference has no CPU path) on
 whole frames of the same workload with all host cores and, once, with one thread; the frame it times is checked
@@ -96,7 +97,11 @@ def measured_valu(kernel_stage, F):
     return None, None
 
 
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # wave64 VALU instructions / s: 256 CUs x 4 SIMD-32, 2 cycles per instruction
+# wave64 VALU instructions / s the chip can issue: 256 CUs x 4 SIMDs, ONE instruction per quad-cycle (4 clocks) per SIMD.
+# Evidence (profiles/*_pmc_valu.json): SQ_ACTIVE_INST_VALU (quad-cycles) == SQ_INSTS_VALU for every kernel, packed-fp32
+# instructions included â€” an instruction holds the SIMD's issue for 4 clocks whether it is v_fma_f32 or v_pk_fma_f32
+# (which is why packed math pays), and at ~1 resident wave issuing per SIMD the composite kernels sit at 80-96 % of it.
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0
 
 
 def percentiles(xs):
@@ -332,7 +337,8 @@ def main():
                 ips = valu["SQ_INSTS_VALU"] / t_s
                 r["valu"] = {"insts_per_launch": int(valu["SQ_INSTS_VALU"]), "achieved": round(ips / 1e9, 1),
                              "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s",
-                             "frac": round(ips / VALU_ISSUE_PEAK, 4), "source": valu_src}
+                             "frac": round(ips / VALU_ISSUE_PEAK, 4),
+                             "busy_by_counters": valu.get("valu_busy"), "source": valu_src}
             return r
         roof = roofline_of(iso[1], "isolated leg, 1 frame in flight: event intervals == kernel durations") \
             if iso is not None else roofline_of(avg, f"timed region, {len(lanes)} frame(s) in flight")

@@ -1,0 +1,413 @@
+// k_sort.hip — stable LSD radix sort with ONE kernel per pass.
+//
+// Replaces cub::DeviceRadixSort::SortPairs (CR/rasterizer_impl.cu:478-483) together with k_binning.hip's split
+// into a P-sized depth sort and an R-sized tile sort.  The multi-kernel passes of launch_radix_sort (histogram ->
+// device-wide scan -> scatter, k_binning.hip) spend most of their time in launch latency when the whole sort is a
+// few MB: 123-block grids of 4 waves on a 256-CU part, 8 launches to sort 4 MB.  Here a pass is one launch:
+//
+//   * the digit totals of ALL passes of a sort are counted up front in one read of the keys (sort_hist_kernel) —
+//     keys do not change between LSD passes, only their order does;
+//   * a block takes its chunk in TICKET order (dynamic block id from one atomic), counts its digits, PUBLISHES the
+//     counts (one 32-bit word per digit: bit 31 = ready, the data is the flag — no fence), and sums the counts of all
+//     its predecessors, spinning on the few that are not published yet.  A predecessor never waits for anything
+//     before publishing and has already started (it holds an earlier ticket), so the wait is deadlock-free under any
+//     dispatch order.  This is the chained-scan idea of Onesweep without its serial look-back: on MI355X every
+//     block of a 500 k-key sort is resident at once, a look-back chain would be walked in lockstep, while summing
+//     published counts is a batch of independent, coalesced L2 reads (<= blocks x digits words);
+//   * 1024-thread blocks (16 waves) with 2-8 keys per thread keep a CU's LDS and issue slots busy where the old
+//     4-wave blocks ran 16 dependent ranking rounds per wave;
+//   * ranking: per-wave digit counters in LDS, 64-bit ballots for the rank inside a round of 64 keys (match-any
+//     over the digit bits), then the block's keys are ordered by digit in LDS so that every digit's run leaves with
+//     consecutive lanes -> coalesced stores.
+// The last tile-sort pass also derives the per-tile ranges (identifyTileRanges, CR/rasterizer_impl.cu:116-138) and
+// skips the sorted keys nobody reads; the first one clears the liveness flags of the frame's instances.
+#include "olsr_device.h"
+#include "olsr_kernels.h"
+
+namespace olsr {
+
+constexpr u32 FS_READY = 0x80000000u;
+constexpr int FS_T = FUSED_SORT_THREADS;  // 1024
+constexpr int FS_W = FS_T / 64;           // 16 waves
+
+__device__ __forceinline__ int64_t fs_bounded_n(int64_t n_host, const int32_t* n_dev) {
+  if (n_dev) {
+    const int64_t nd = (int64_t)(*n_dev);
+    return nd < n_host ? nd : n_host;
+  }
+  return n_host;
+}
+
+__device__ __forceinline__ u32 fs_wave_incl_scan(u32 v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+// exclusive prefix across the 1024 threads of a block; s_w: 16 words of LDS scratch (reusable after return)
+__device__ __forceinline__ u32 fs_block_excl_scan(u32 v, u32* s_w) {
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const u32 incl = fs_wave_incl_scan(v);
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  u32 base = 0;
+#pragma unroll
+  for (int i = 0; i < FS_W; ++i) base += (i < w) ? s_w[i] : 0u;
+  __syncthreads();
+  return base + incl - v;
+}
+
+__device__ __forceinline__ u32 fs_load_status(const u32* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fs_store_status(u32* p, u32 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- digit totals of every pass of a sort, one read of the keys ---------------------------------------------
+// hist[p][d] += #keys whose digit p is d (hist zeroed by an earlier kernel of the frame); digits are `db` bits wide.
+// `house` (block 0 only, may be null): the frame's bookkeeping that used to be finalize_counts_kernel.
+struct FrameHousekeeping {
+  const u32* part_rect;   // preprocess' per-block partial sums
+  const u32* part_count;
+  int nparts;
+  long long capacity;
+  int32_t* counters;
+  int32_t* num_rendered_dev;
+  u32* ranges;
+  int nranges;  // 2 * tiles
+};
+
+__global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
+                                                         const int32_t* __restrict__ n_dev, int passes, int db,
+                                                         u32* __restrict__ hist, FrameHousekeeping house,
+                                                         int do_house) {
+  __shared__ u32 h[4][256];
+  __shared__ u32 s_red[2][FS_W];
+  const int tid = threadIdx.x;
+  h[0][tid & 255] = 0;  // 1024 threads: four of them per bin, same value
+  h[tid >> 8][tid & 255] = 0;
+  __syncthreads();
+  const int64_t n = fs_bounded_n(n_host, n_dev);
+  const u32 mask = (1u << db) - 1u;
+  const int64_t stride = (int64_t)gridDim.x * FS_T * 4;
+  for (int64_t i0 = ((int64_t)blockIdx.x * FS_T + tid) * 4; i0 < n; i0 += stride) {
+    u32 k[4];
+    if (i0 + 4 <= n) {
+      const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
+      k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k[j] = (i0 + j < n) ? keys[i0 + j] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i0 + j < n) {
+        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k[j] >> (db * p)) & mask], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int p = tid >> 8, d = tid & 255;
+    if (p < passes && h[p][d] != 0) atomicAdd(&hist[p * 256 + d], h[p][d]);
+  }
+  if (do_house && blockIdx.x == 0) {
+    // the frame's counters: R = sum of the per-Gaussian instance counts (preprocess' block partials), the reference's
+    // num_rendered (rect binning), overflow against the caller's capacity; work-list and row counters reset;
+    // tile ranges set to "empty" (start = UINT_MAX, end = 0: the last tile-sort pass lowers / raises them with atomics)
+    u32 rect = 0, cnt = 0;
+    for (int i = tid; i < house.nparts; i += FS_T) {
+      rect += house.part_rect[i];
+      cnt += house.part_count[i];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      rect += __shfl_xor(rect, m);
+      cnt += __shfl_xor(cnt, m);
+    }
+    if ((tid & 63) == 0) {
+      s_red[0][tid >> 6] = rect;
+      s_red[1][tid >> 6] = cnt;
+    }
+    for (int i = tid; i < house.nranges; i += FS_T) house.ranges[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
+    __syncthreads();
+    if (tid == 0) {
+      rect = 0;
+      cnt = 0;
+      for (int i = 0; i < FS_W; ++i) {
+        rect += s_red[0][i];
+        cnt += s_red[1][i];
+      }
+      const bool ok = (long long)cnt <= house.capacity && cnt <= 0x7FFFFFFFu;
+      house.counters[0] = (int32_t)cnt;
+      house.counters[1] = ok ? (int32_t)cnt : 0;
+      house.counters[2] = ok ? 0 : 1;
+      house.counters[3] = (int32_t)rect;
+      house.counters[4] = 0;
+      house.counters[5] = 0;
+      house.counters[6] = 0;
+      house.counters[7] = 0;
+      if (house.num_rendered_dev) {
+        house.num_rendered_dev[0] = (int32_t)cnt;
+        house.num_rendered_dev[1] = ok ? 0 : 1;
+      }
+    }
+  }
+}
+
+// ---- one pass ---------------------------------------------------------------------------------------------
+// FLAGS (runtime, uniform): bit 0 = values are the identity (first tile-sort pass; also clears flags_clear[i]),
+// bit 1 = do not write the sorted keys (last pass of a sort), bit 2 = derive tile ranges (last tile-sort pass).
+constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4;
+
+template <int DB, int KPT>
+__global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__ keys_in,
+                                                         const u32* __restrict__ vals_in, int64_t n_host,
+                                                         const int32_t* __restrict__ n_dev, int shift,
+                                                         const u32* __restrict__ ghist, u32* status, u32* ticket,
+                                                         u32* __restrict__ keys_out, u32* __restrict__ vals_out,
+                                                         int fsf, uint8_t* __restrict__ flags_clear, u32* ranges) {
+  constexpr u32 NB = 1u << DB;
+  constexpr u32 DMASK = NB - 1u;
+  constexpr int CHUNK = FS_T * KPT;
+  constexpr int G = FS_T / (int)NB;  // predecessor rows read concurrently
+  constexpr int U = 8;               // ... times loads in flight per thread
+  extern __shared__ __attribute__((aligned(16))) u32 fs_smem[];
+  u32* cnt = fs_smem;              // [16][NB] per-wave digit counts -> per-wave local starts
+  u32* dstart = cnt + FS_W * NB;   // [NB + 1] local start of digit d inside the block (+ sentinel)
+  u32* gbase = dstart + NB + 4;    // [NB] global start of this block's run of digit d
+  u32* part = gbase + NB;          // [G][NB] partial predecessor sums
+  u32* ex_key = part + FS_T;       // [CHUNK]
+  u32* ex_val = ex_key + CHUNK;    // [CHUNK]
+  __shared__ u32 s_bid;
+  __shared__ u32 s_w[FS_W];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_bid = atomicAdd(ticket, 1u);
+  for (u32 i = tid; i < FS_W * NB; i += FS_T) cnt[i] = 0;
+  __syncthreads();
+  const u32 b = s_bid;
+  const int64_t n = fs_bounded_n(n_host, n_dev);
+  const int64_t bbase = (int64_t)b * CHUNK;
+  if (bbase >= n) return;  // (an empty block has only empty successors: nobody waits for it)
+  const int64_t wbase = bbase + (int64_t)w * (64 * KPT);
+
+  u32 key[KPT], val[KPT];
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+    val[r] = (fsf & FSF_IDENTITY) ? (u32)i : (valid ? vals_in[i] : 0u);
+    if (valid) atomicAdd(&cnt[w * NB + ((key[r] >> shift) & DMASK)], 1u);
+    if ((fsf & FSF_IDENTITY) && valid) flags_clear[i] = 0;
+  }
+  __syncthreads();
+
+  // thread d owns digit d: counts of the 16 waves -> block total (published) and per-wave starts
+  const u32 d = (u32)tid;
+  u32 c[FS_W];
+  u32 tot = 0;
+  if (d < NB) {
+#pragma unroll
+    for (int i = 0; i < FS_W; ++i) {
+      c[i] = cnt[i * NB + d];
+      tot += c[i];
+    }
+    fs_store_status(&status[(size_t)b * NB + d], FS_READY | tot);
+  }
+  const u32 start = fs_block_excl_scan(d < NB ? tot : 0u, s_w);
+  const u32 gdig = fs_block_excl_scan(d < NB ? ghist[d] : 0u, s_w);
+  if (d < NB) {
+    dstart[d] = start;
+    u32 run = start;
+#pragma unroll
+    for (int i = 0; i < FS_W; ++i) {
+      cnt[i * NB + d] = run;
+      run += c[i];
+    }
+    if (d == NB - 1) dstart[NB] = run;
+  }
+  // counts of all predecessors: G rows at a time, U loads in flight per thread, spinning only on unpublished words
+  {
+    const u32 dd = (u32)tid & DMASK, g = (u32)tid >> DB;
+    u32 sum = 0;
+    for (u32 bp0 = g; bp0 < b; bp0 += G * U) {
+      u32 s[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u32 bp = bp0 + (u32)u * G;
+        s[u] = (bp < b) ? fs_load_status(&status[(size_t)bp * NB + dd]) : FS_READY;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u32 bp = bp0 + (u32)u * G;
+        while (!(s[u] & FS_READY)) {
+          __builtin_amdgcn_s_sleep(1);
+          s[u] = fs_load_status(&status[(size_t)bp * NB + dd]);
+        }
+        sum += s[u] & ~FS_READY;
+      }
+    }
+    part[g * NB + dd] = sum;
+  }
+  __syncthreads();
+  if (d < NB) {
+    u32 pred = 0;
+#pragma unroll
+    for (int q = 0; q < G; ++q) pred += part[q * NB + d];
+    gbase[d] = gdig + pred;
+  }
+  __syncthreads();
+
+  // rank: wave w walks its 64 * KPT consecutive keys in KPT rounds of 64; inside a round the rank among equal
+  // digits comes from ballots, the running per-wave start from LDS -> order inside the block = ascending input index
+  volatile u32* my = cnt + w * NB;
+  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int64_t i = wbase + r * 64 + lane;
+    const bool valid = i < n;
+    const u32 dg = (key[r] >> shift) & DMASK;
+    u64 peers = ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < DB; ++bit) {
+      const bool one = (dg >> bit) & 1u;
+      const u64 bm = ballot(one);
+      peers &= one ? bm : ~bm;
+    }
+    if (valid) {
+      const u32 rank = (u32)__popcll(peers & lt_mask);
+      const u32 st0 = my[dg];
+      if (rank == 0) my[dg] = st0 + (u32)__popcll(peers);
+      ex_key[st0 + rank] = key[r];
+      ex_val[st0 + rank] = val[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+
+  const int64_t rem = n - bbase;
+  const u32 nvalid = rem >= CHUNK ? (u32)CHUNK : (u32)rem;
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const u32 slot = (u32)k * FS_T + (u32)tid;
+    if (slot < nvalid) {
+      const u32 kk = ex_key[slot];
+      const u32 dg = (kk >> shift) & DMASK;
+      const u32 ds = dstart[dg];
+      const u32 pos = gbase[dg] + (slot - ds);
+      if (!(fsf & FSF_NO_KEYS)) keys_out[pos] = kk;
+      vals_out[pos] = ex_val[slot];
+      if (fsf & FSF_RANGES) {
+        // After the last pass equal keys (tile ids) are contiguous, and inside one digit's run of this block the
+        // keys ascend (the input was sorted by the lower digits).  A tile's range starts where the key changes;
+        // the head / tail of a block's digit run may continue a tile of the neighbouring block, so those use
+        // atomicMin / atomicMax (ranges were initialised to {UINT_MAX, 0}); the true boundary always wins.
+        const bool head = (slot == ds);
+        const bool tail = (slot + 1 == dstart[dg + 1]) || (slot + 1 == nvalid);
+        if (head || ex_key[slot - 1] != kk) atomicMin(&ranges[2 * kk], pos);
+        if (tail || ex_key[slot + 1] != kk) atomicMax(&ranges[2 * kk + 1], pos + 1u);
+      }
+    }
+  }
+}
+
+template <int DB, int KPT>
+static void launch_pass_t(const u32* kin, const u32* vin, int64_t n_host, const int32_t* n_dev, int shift,
+                          const u32* ghist, u32* status, u32* ticket, u32* kout, u32* vout, int fsf, uint8_t* flags,
+                          u32* ranges, int nblk, hipStream_t st) {
+  constexpr size_t NB = 1u << DB;
+  constexpr size_t smem = sizeof(u32) * (FS_W * NB + NB + 4 + NB + FS_T + 2 * (size_t)FS_T * KPT);
+  static bool attr_set = false;  // (per instantiation) blocks above 64 KB of LDS need the opt-in
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_pass_kernel<DB, KPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  sort_pass_kernel<DB, KPT><<<nblk, FS_T, smem, st>>>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout,
+                                                      vout, fsf, flags, ranges);
+}
+
+template <int DB>
+static void launch_pass_k(int kpt, const u32* kin, const u32* vin, int64_t n_host, const int32_t* n_dev, int shift,
+                          const u32* ghist, u32* status, u32* ticket, u32* kout, u32* vout, int fsf, uint8_t* flags,
+                          u32* ranges, int nblk, hipStream_t st) {
+  switch (kpt) {
+    case 2: launch_pass_t<DB, 2>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout, vout, fsf, flags, ranges, nblk, st); break;
+    case 4: launch_pass_t<DB, 4>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout, vout, fsf, flags, ranges, nblk, st); break;
+    default: launch_pass_t<DB, 8>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout, vout, fsf, flags, ranges, nblk, st); break;
+  }
+}
+
+int fused_sort_digit_bits(int bits, int* passes_out) {
+  const int passes = (bits + 7) / 8;
+  int db = (bits + passes - 1) / passes;
+  if (db < 4) db = 4;  // (digits wider than the key are harmless: the upper bits are zero)
+  if (passes_out) *passes_out = passes;
+  return db;
+}
+
+bool fused_sort_applicable(int64_t n_host, int bits) {
+  return n_host > 0 && bits <= 32 && sort_plan(n_host).nblk <= FUSED_SORT_MAX_BLOCKS;
+}
+
+void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
+                      const FusedHouse* house, hipStream_t st) {
+  int passes;
+  const int db = fused_sort_digit_bits(bits, &passes);
+  FrameHousekeeping h{};
+  if (house) {
+    h.part_rect = house->part_rect;
+    h.part_count = house->part_count;
+    h.nparts = house->nparts;
+    h.capacity = house->capacity;
+    h.counters = house->counters;
+    h.num_rendered_dev = house->num_rendered_dev;
+    h.ranges = house->ranges;
+    h.nranges = house->nranges;
+  }
+  int64_t nb = (n_host + (int64_t)FS_T * 16 - 1) / ((int64_t)FS_T * 16);  // ~16 keys per thread
+  if (nb < 1) nb = 1;
+  if (nb > 512) nb = 512;
+  sort_hist_kernel<<<(int)nb, FS_T, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0);
+}
+
+// Sorts (key, val) pairs on the low `bits` bits of key, ceil(bits / 8) passes.  hist / status / tickets must have been
+// zeroed and hist filled by launch_sort_hist.  Returns 0 if the result ends in (key_a, val_a), 1 if in (key_b, val_b).
+int launch_sort_fused(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
+                      const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
+                      hipStream_t st) {
+  if (n_host <= 0) return 0;
+  int passes;
+  const int db = fused_sort_digit_bits(bits, &passes);
+  const SortPlan plan = sort_plan(n_host);
+  const size_t NB = (size_t)1 << db;
+  u32 *kin = b.key_a, *kout = b.key_b, *vin = b.val_a, *vout = b.val_b;
+  int where = 0;
+  for (int p = 0; p < passes; ++p) {
+    int fsf = 0;
+    if (p == 0 && vals_in_identity) fsf |= FSF_IDENTITY;
+    if (p == passes - 1) fsf |= FSF_NO_KEYS | (ranges ? FSF_RANGES : 0);
+    u32* stat = status + (size_t)p * plan.nblk * NB;
+#define OLSR_PASS(DBV)                                                                                                \
+  case DBV:                                                                                                           \
+    launch_pass_k<DBV>(plan.kpt, kin, vin, n_host, n_dev, db * p, hist + 256 * p, stat, tickets + p, kout, vout, fsf, \
+                       flags_clear, ranges, plan.nblk, st);                                                           \
+    break;
+    switch (db) {
+      OLSR_PASS(4) OLSR_PASS(5) OLSR_PASS(6) OLSR_PASS(7) OLSR_PASS(8)
+      default: break;
+    }
+#undef OLSR_PASS
+    u32* t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+    where ^= 1;
+  }
+  return where;
+}
+
+}  // namespace olsr

@@ -29,6 +29,27 @@ constexpr int SCAN_CHUNK = 4096;
 inline int sort_blocks(long long n) { return (int)((n + SORT_CHUNK - 1) / SORT_CHUNK); }
 inline int scan_blocks(long long n) { return (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK); }
 
+// Fused sort passes (k_sort.hip): one 1024-thread block per chunk of 1024 * kpt keys, kpt in {2, 4, 8} chosen so that
+// a P- or R-sized sort has a few hundred blocks (every block reads the digit counts of all its predecessors).
+struct SortPlan {
+  int kpt;
+  int nblk;
+};
+constexpr int FUSED_SORT_THREADS = 1024;
+constexpr int FUSED_SORT_MAX_BLOCKS = 4096;  // beyond: the multi-kernel passes (histogram, device-wide scan, scatter)
+inline SortPlan sort_plan(long long n) {
+  int kpt = 2;
+  while (kpt < 8 && (n + 1024LL * kpt - 1) / (1024LL * kpt) > 512) kpt *= 2;
+  return SortPlan{kpt, (int)((n + 1024LL * kpt - 1) / (1024LL * kpt))};
+}
+inline size_t fused_status_words(long long n, int passes) {
+  const SortPlan p = sort_plan(n);
+  return (p.nblk <= FUSED_SORT_MAX_BLOCKS) ? (size_t)passes * (size_t)p.nblk * 256 : 0;
+}
+// single-pass scans (emission offsets, row compaction): elements per 1024-thread block
+constexpr int EMIT_CHUNK = 1024;
+constexpr int ROWS_CHUNK = 16384;
+
 struct Carver {
   char* base;
   size_t off = 0;
@@ -59,7 +80,7 @@ struct GeometryState {
   uint32_t* val_a;        // [P] Gaussian ids (ping)
   uint32_t* val_b;        // [P] (pong)
   uint32_t* depth_order;  // alias of the buffer holding the final order (val_a after 4 passes)
-  uint32_t* offsets;      // [P] inclusive scan of tiles_touched in depth order
+  uint32_t* offsets;      // [P] (multi-kernel fallback only) inclusive scan of tiles_touched in depth order
   uint32_t* inst_start;   // [P] Gaussian id -> emission index of its first instance
   uint32_t* radix_table;  // [256 * sort_blocks(P)]
   uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
@@ -71,6 +92,15 @@ struct GeometryState {
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
   uint4* big_list;        // [P] work lists {id, first instance, #instances} built by the emission: large footprints from
                           //     the front (count: counters[5]), medium ones from the back (count: counters[4])
+  // ---- words the fused kernels synchronise through; zeroed by preprocess at the start of every forward
+  uint32_t* sync_words;   // start of the zeroed region
+  size_t sync_count;      // its length in 32-bit words
+  uint32_t* tickets;      // [16] dynamic block ids: 0-3 depth passes, 4 scan+emit
+  uint32_t* sort_hist;    // [4][256] digit totals of the four depth passes
+  uint32_t* sort_status;  // [4][blocks][256] per-block digit counts of the depth passes (bit 31 = published)
+  uint32_t* emit_status;  // [ceil(P / EMIT_CHUNK)] per-block instance totals of the fused scan + emission
+  uint32_t* part_rect;    // [ceil(P / 256)] preprocess' per-block sums: instances of the reference's rect binning
+  uint32_t* part_count;   // [ceil(P / 256)] ... and instances this frame emits
   static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
     Carver c(buf);
     GeometryState g;
@@ -96,6 +126,19 @@ struct GeometryState {
     g.tau_partials = c.take<float>(6 * ((P + 127) / 128) + 6);
     g.gacc = c.take<float>(P * (size_t)grad_row_floats);
     g.big_list = c.take<uint4>(P);
+    {
+      const size_t st_words = fused_status_words((long long)P, 4);
+      const size_t emit_blocks = (P + EMIT_CHUNK - 1) / EMIT_CHUNK + 1;
+      g.sync_count = 16 + 4 * 256 + st_words + emit_blocks;
+      g.sync_count = (g.sync_count + 3) / 4 * 4;  // zeroed with 16-byte stores
+      g.sync_words = c.take<uint32_t>(g.sync_count);
+      g.tickets = g.sync_words;
+      g.sort_hist = g.tickets + 16;
+      g.emit_status = g.sort_hist + 4 * 256;
+      g.sort_status = g.emit_status + emit_blocks;
+    }
+    g.part_rect = c.take<uint32_t>((P + 255) / 256 + 1);
+    g.part_count = c.take<uint32_t>((P + 255) / 256 + 1);
     bytes = c.total();
     return g;
   }
@@ -130,6 +173,13 @@ struct BinningState {
   uint32_t* radix_table;   // [256 * sort_blocks(R)]
   uint32_t* scan_partials; // [scan_blocks(max(table, R)) + 1]
   uint32_t* rowbase;     // [R + 1] emission index -> first compact row of the instance (backward)
+  // ---- words the fused kernels synchronise through; zeroed by the emission at the start of every forward
+  uint32_t* sync_words;
+  size_t sync_count;
+  uint32_t* tickets;     // [16]: 0-3 tile-sort passes, 8 row compaction, 9 its done counter
+  uint32_t* tile_hist;   // [4][256] digit totals of the tile-sort passes
+  uint32_t* tile_status; // [4][blocks][256]
+  uint32_t* row_status;  // [ceil((R + 1) / ROWS_CHUNK)] per-block live-row totals of the row compaction
   static BinningState carve(void* buf, size_t R, size_t& bytes) {
     Carver c(buf);
     BinningState b;
@@ -143,6 +193,17 @@ struct BinningState {
     b.radix_table = c.take<uint32_t>(table);
     b.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)(table > R ? table : R)) + 1);
     b.rowbase = c.take<uint32_t>(R + 1);
+    {
+      const size_t st_words = fused_status_words((long long)R, 4);
+      const size_t row_blocks = (R + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK + 1;
+      b.sync_count = 16 + 4 * 256 + st_words + row_blocks;
+      b.sync_count = (b.sync_count + 3) / 4 * 4;
+      b.sync_words = c.take<uint32_t>(b.sync_count);
+      b.tickets = b.sync_words;
+      b.tile_hist = b.tickets + 16;
+      b.row_status = b.tile_hist + 4 * 256;
+      b.tile_status = b.row_status + row_blocks;  // last: only the part a frame's passes use is zeroed
+    }
     bytes = c.total();
     return b;
   }

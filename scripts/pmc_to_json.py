@@ -68,9 +68,18 @@ for k, d in sq.items():
     us = stats1.get(k) or stats.get(k, {}).get("avg_us")
     if us:
         e["avg_us_1_in_flight"] = round(us, 2)
-        # one wave64 VALU instruction per 2 cycles per SIMD-32; 1024 SIMDs at 2.4 GHz
-        e["valu_issue_frac_of_peak"] = round(d["SQ_INSTS_VALU"] / (us * 1e-6) / (1024 * 2.4e9 / 2), 4)
+        # one wave64 VALU instruction per quad-cycle per SIMD (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles);
+        # 1024 SIMDs at the 2.4 GHz peak clock
+        e["valu_issue_frac_of_peak"] = round(d["SQ_INSTS_VALU"] / (us * 1e-6) / (1024 * 2.4e9 / 4), 4)
+    if d.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in d:
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines -> kernel duration in clocks; VALU-active quad-cycles
+        # x 4 over 1024 SIMDs -> fraction of the kernel during which a SIMD issues VALU work (clock-independent)
+        e["kernel_clocks"] = int(d["SQ_BUSY_CYCLES"] / 32)
+        e["valu_busy"] = round(d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (d["SQ_BUSY_CYCLES"] / 32), 4)
+        if us:
+            e["effective_clock_GHz"] = round(d["SQ_BUSY_CYCLES"] / 32 / (us * 1e-6) / 1e9, 3)
     if d.get("SQ_WAVE_CYCLES"):
+        e["resident_waves_per_simd"] = round(d["SQ_WAVE_CYCLES"] * 4 / 1024 / (d["SQ_BUSY_CYCLES"] / 32), 2) if d.get("SQ_BUSY_CYCLES") else None
         e["valu_active_over_wave_cycles"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_WAVE_CYCLES"], 4) if "SQ_ACTIVE_INST_VALU" in d else None
         e["wait_inst_lds_over_wave_cycles"] = round(d.get("SQ_WAIT_INST_LDS", 0) / d["SQ_WAVE_CYCLES"], 4)
     valu[k] = e

@@ -116,6 +116,23 @@ def test_workspace_async_equals_dropin_path(hip):
     o2 = small.forward()
     R, overflow = small.rendered()
     assert overflow and R == fg["R"] and float(o2["opacity"].abs().max()) == 0.0
+    # ... and a backward after the overflowed forward reports it and writes ZERO gradients: the frame's instance
+    # tables were never written, so nothing of them may be read (first on the fresh workspace, then again after a
+    # valid frame has left its tables behind in the same buffers)
+    for attempt in range(2):
+        if attempt == 1:
+            big = RasterWorkspace(sc.P, 320, 240, 15, sc.shs.shape[1], int(fg["R"] * 1.2) + 1000, dev)
+            big.set_scene(**kw)
+            big.forward()
+            big.backward(dc, dl, dd)
+            small.geom.copy_(big.geom)          # stale but plausible inst_start / offsets / counters of another frame
+            small.set_scene(**kw)
+            small.forward()
+            assert small.rendered()[1]
+        gz = small.backward(dc, dl, dd)
+        assert small.backward_status()[1], "an overflowed forward must surface in the backward's status"
+        for k, v in gz.items():
+            assert float(v.abs().max()) == 0.0, (attempt, k)
     # backward scratch too small for the live (instance, slot) rows: reported, not a crash
     L, ov = ws.backward_status()
     assert not ov and 0 < L <= 4 * fg["R"]
