@@ -24,6 +24,7 @@ UNITS = [
     ("olsr_api.hip", "olsr_api.o", []),
     ("k_preprocess.hip", "k_preprocess.o", []),
     ("k_binning.hip", "k_binning.o", []),
+    ("k_sort.hip", "k_sort.o", []),
     ("k_render_fwd.hip", "k_render_fwd.o", []),
     ("k_render_bwd.hip", "k_render_bwd_ref.o", ["-DOLSR_BWD_TU_MODE=0"]),
     ("k_render_bwd.hip", "k_render_bwd_exact.o", ["-DOLSR_BWD_TU_MODE=1"]),

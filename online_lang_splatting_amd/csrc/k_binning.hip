@@ -310,106 +310,134 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
   return where;
 }
 
-// ------------------------------------------------------------------------------- offsets
-// One small block that also does the frame's housekeeping, so that no separate memset launches are
-// needed: tile ranges zeroed (identifyTileRanges only writes tiles that own instances), the
-// work-list and row counters of this frame reset.
-__global__ __launch_bounds__(256) void finalize_counts_kernel(const u32* offsets, int P, long long capacity,
-                                                              int32_t* counters, int32_t* num_rendered_dev,
-                                                              const u32* rect_partials, int nparts, u32* ranges,
-                                                              int nranges) {
-  __shared__ u32 s_rect[4];
-  for (int i = threadIdx.x; i < nranges; i += 256) ranges[i] = 0u;
-  if (threadIdx.x >= 4 && threadIdx.x < 8) counters[threadIdx.x] = 0;
-  // the reference's num_rendered (rect binning): sum of preprocess' per-block partials
-  u32 rect = 0;
-  for (int i = threadIdx.x; i < nparts; i += 256) rect += rect_partials[i];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) rect += __shfl_xor(rect, m);
-  if ((threadIdx.x & 63) == 0) s_rect[threadIdx.x >> 6] = rect;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    rect = s_rect[0] + s_rect[1] + s_rect[2] + s_rect[3];
-    counters[3] = (int32_t)rect;
-    const u32 R = (P > 0) ? offsets[P - 1] : 0u;
-    const bool ok = (long long)R <= capacity && R <= 0x7FFFFFFFu;
-    counters[0] = (int32_t)R;
-    counters[1] = ok ? (int32_t)R : 0;
-    counters[2] = ok ? 0 : 1;
-    if (num_rendered_dev) {
-      num_rendered_dev[0] = (int32_t)R;
-      num_rendered_dev[1] = ok ? 0 : 1;
-    }
-  }
-}
-
-// cub::DeviceScan::InclusiveSum over tiles_touched (CR/rasterizer_impl.cu:451), taken in depth order
-void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, int32_t* num_rendered_dev,
-                             uint32_t* ranges, int ntiles, hipStream_t st) {
-  device_scan<LoadGather, true>(LoadGather{g.tiles_touched, g.depth_order}, (int64_t)P, g.offsets, g.scan_partials, st);
-  finalize_counts_kernel<<<1, 256, 0, st>>>(g.offsets, P, (long long)capacity, g.counters, num_rendered_dev,
-                                            reinterpret_cast<const u32*>(g.tau_partials), (P + 255) / 256, ranges,
-                                            2 * ntiles);
-}
-
 // ------------------------------------------------------------------------------- emission
-// duplicateWithKeys (CR/rasterizer_impl.cu:70-111).  The depth half of the reference's key is implied
-// by the emission order; only the tile id is written.
-//   emit_kernel      one thread per depth rank; a Gaussian with <= EMIT_BIG instances is written by its
-//                    lane (consecutive ranks own adjacent output runs), larger ones go to a work list
-//                    (one aggregated atomic per wave; the list order influences no result);
+// cub::DeviceScan::InclusiveSum + duplicateWithKeys (CR/rasterizer_impl.cu:451, 70-111) in ONE kernel.  The depth
+// half of the reference's key is implied by the emission order; only the tile id is written.
+//   scan_emit_kernel  one thread per depth rank.  The instance count of the Gaussian comes with its emission record
+//                    (one 16-byte gather in depth order); the block scans its 1024 counts, publishes the total and
+//                    obtains the sum of all earlier blocks by decoupled look-back (one 64-bit status word per block:
+//                    aggregate, later inclusive prefix; a wave inspects 64 predecessors per step) — no separate scan
+//                    launches, no offsets array.  A Gaussian with <= EMIT_BIG instances is then written by its lane
+//                    (consecutive ranks own adjacent output runs), larger ones go to a work list (one aggregated
+//                    atomic per block; the list order influences no result);
 //   emit_big_kernel  persistent grid, one wave per listed Gaussian: near splats cover hundreds to
 //                    thousands of tiles and cluster at the front of the depth order, so they are dealt
 //                    to all waves of the chip and written with coalesced stores.
 constexpr u32 EMIT_BIG = OLSR_BIG_FOOTPRINT;
 constexpr int EMIT_BIG_BLOCKS = 512;
-constexpr int EMIT_THREADS = 1024;  // one list atomic per 1024 Gaussians
+constexpr int EMIT_THREADS = EMIT_CHUNK;  // 1024: one list atomic per 1024 Gaussians
+
+typedef unsigned long long lb_word;  // look-back status: bit 63 = aggregate published, bit 62 = inclusive prefix
+constexpr lb_word LB_AGG = 1ull << 63, LB_INCL = 1ull << 62, LB_VAL = (1ull << 62) - 1ull;
+__device__ __forceinline__ lb_word lb_load(const lb_word* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lb_store(lb_word* p, lb_word v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Sum of the totals of blocks [0, b), called by ONE full wave of block b (which has published its aggregate).
+// Blocks take their index from a ticket, so every predecessor has started and publishes without waiting.
+__device__ __forceinline__ lb_word lb_exclusive_prefix(const lb_word* status, u32 b) {
+  const int lane = lane_id();
+  lb_word excl = 0;
+  for (long long top = (long long)b - 1; top >= 0; top -= 64) {
+    const long long j = top - lane;
+    lb_word sv = LB_INCL;  // (before block 0: an inclusive prefix of zero)
+    if (j >= 0) {
+      sv = lb_load(&status[j]);
+      while (!(sv & (LB_AGG | LB_INCL))) {
+        __builtin_amdgcn_s_sleep(1);
+        sv = lb_load(&status[j]);
+      }
+    }
+    const u64 incl = ballot((sv & LB_INCL) != 0);
+    const int first = incl ? (int)__builtin_ctzll(incl) : 64;  // nearest predecessor whose prefix is known
+    lb_word v = (lane <= first) ? (sv & LB_VAL) : 0ull;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    excl += v;
+    if (incl) break;
+  }
+  return excl;
+}
 
 template <int TILE>
-__global__ __launch_bounds__(EMIT_THREADS) void emit_kernel(int P, const u32* __restrict__ order,
-                                                            const u32* __restrict__ offsets,
-                                                            const float4* __restrict__ emit_rec, int ellipse, int W,
-                                                            int H, int gx, int gy, int32_t* __restrict__ counters,
-                                                            u32* __restrict__ keys, u32* __restrict__ inst_gid,
-                                                            u32* __restrict__ inst_start,
-                                                            uint4* __restrict__ big_list) {
-  if (counters[2] != 0) return;  // overflow: nothing is emitted (uniform)
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 g = 0, n = 0, off = 0;
+__global__ __launch_bounds__(EMIT_THREADS) void scan_emit_kernel(
+    int P, const u32* __restrict__ order, const float4* __restrict__ emit_rec, int ellipse, int W, int H, int gx, int gy,
+    int32_t* __restrict__ counters, lb_word* status, u32* ticket, uint4* __restrict__ bin_sync, int bin_sync_quads,
+    u32* __restrict__ keys, u32* __restrict__ inst_gid, u32* __restrict__ inst_start, uint4* __restrict__ big_list) {
+  __shared__ u32 s_bid;
+  __shared__ u32 s_wsum[EMIT_THREADS / 64];
+  __shared__ lb_word s_base;
+  // the words the tile sort and the row compaction synchronise through live in the binning buffer, which exists only
+  // from here on (the drop-in entry allocates it after the instance count is known)
+  for (int q = (int)(blockIdx.x * EMIT_THREADS + threadIdx.x); q < bin_sync_quads; q += (int)(gridDim.x * EMIT_THREADS))
+    bin_sync[q] = make_uint4(0u, 0u, 0u, 0u);
+  if (counters[2] != 0) return;  // more instances than the caller's capacity: nothing is emitted (uniform)
+  if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const u32 b = s_bid;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = (int)(b * EMIT_THREADS + threadIdx.x);
+  u32 g = 0, n = 0;
+  float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r < P) {
     g = order[r];
-    // offsets is the inclusive scan of tiles_touched in depth order: both neighbours are coalesced reads
-    const u32 incl = offsets[r];
-    const u32 prev = (r > 0) ? offsets[r - 1] : 0u;
-    n = incl - prev;  // == tiles_touched[g]; 0 for culled Gaussians, whose record is stale
-    off = prev;
-    if (n > 0) {
-      inst_start[g] = off;
-      if (n <= EMIT_BIG) {
-        const float4 r0 = emit_rec[2 * (size_t)g], r1 = emit_rec[2 * (size_t)g + 1];
-        const int rad = __float_as_int(r1.z);
-        const Rect rc = get_rect<TILE>(r0.x, r0.y, rad, gx, gy);
-        u32 o = off;
-        if (!ellipse) {
-          for (int y = rc.y0; y < rc.y1; y++)
-            for (int x = rc.x0; x < rc.x1; x++) {
-              keys[o] = (u32)(y * gx + x);
-              inst_gid[o] = g;
-              o++;
-            }
-        } else {
-          // exact binning: the same row spans preprocess counted (same function, same inputs)
-          const CullEllipse e = cull_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rad);
-          int ya, yb;
-          cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
-          for (int y = ya; y < yb; y++) {
-            int xa, xb;
-            cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
-            for (int x = xa; x < xb; x++) {
-              keys[o] = (u32)(y * gx + x);
-              inst_gid[o] = g;
-              o++;
-            }
+    r1 = emit_rec[2 * (size_t)g + 1];
+    n = __float_as_uint(r1.w);  // instances of the Gaussian; 0 when culled
+  }
+  // block-wide exclusive scan of n
+  u32 incl = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  u32 wbase = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < EMIT_THREADS / 64; ++i) {
+    const u32 c = s_wsum[i];
+    wbase += (i < w) ? c : 0u;
+    total += c;
+  }
+  if (w == 0) {
+    if (lane == 0) lb_store(&status[b], (b == 0 ? LB_INCL : LB_AGG) | (lb_word)total);
+    const lb_word base = (b == 0) ? 0ull : lb_exclusive_prefix(status, b);
+    if (lane == 0) {
+      if (b != 0) lb_store(&status[b], LB_INCL | (base + (lb_word)total));
+      s_base = base;
+    }
+  }
+  __syncthreads();
+  const u32 off = (u32)s_base + wbase + incl - n;
+  if (n > 0) {
+    inst_start[g] = off;
+    if (n <= EMIT_BIG) {
+      const float4 r0 = emit_rec[2 * (size_t)g];
+      const int rad = __float_as_int(r1.z);
+      const Rect rc = get_rect<TILE>(r0.x, r0.y, rad, gx, gy);
+      u32 o = off;
+      if (!ellipse) {
+        for (int y = rc.y0; y < rc.y1; y++)
+          for (int x = rc.x0; x < rc.x1; x++) {
+            keys[o] = (u32)(y * gx + x);
+            inst_gid[o] = g;
+            o++;
+          }
+      } else {
+        // exact binning: the same row spans preprocess counted (same function, same inputs)
+        const CullEllipse e = cull_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rad);
+        int ya, yb;
+        cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
+        for (int y = ya; y < yb; y++) {
+          int xa, xb;
+          cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
+          for (int x = xa; x < xb; x++) {
+            keys[o] = (u32)(y * gx + x);
+            inst_gid[o] = g;
+            o++;
           }
         }
       }
@@ -490,29 +518,35 @@ __global__ __launch_bounds__(256) void emit_big_kernel(const uint4* __restrict__
   }
 }
 
-void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
-                 const BinningState& b, hipStream_t st) {
-  (void)radii;
+void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                 int64_t bin_sync_words, hipStream_t st) {
   if (s.P <= 0) return;
   const int nb = (s.P + EMIT_THREADS - 1) / EMIT_THREADS;
   const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
+  lb_word* status = reinterpret_cast<lb_word*>(g.emit_status);
+  uint4* bsync = reinterpret_cast<uint4*>(b.sync_words);
+  const int quads = (int)((bin_sync_words + 3) / 4);
   if (d.tile == 15) {
-    emit_kernel<15><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.offsets, g.emit_rec, ellipse, d.W, d.H, d.gx,
-                                                 d.gy, g.counters, b.key_a, b.inst_gid, g.inst_start, g.big_list);
+    scan_emit_kernel<15><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
+                                                      g.counters, status, g.tickets + 4, bsync, quads, b.key_a,
+                                                      b.inst_gid, g.inst_start, g.big_list);
     emit_big_kernel<15><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
                                                          g.counters, b.key_a, b.inst_gid);
   } else {
-    emit_kernel<16><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.offsets, g.emit_rec, ellipse, d.W, d.H, d.gx,
-                                                 d.gy, g.counters, b.key_a, b.inst_gid, g.inst_start, g.big_list);
+    scan_emit_kernel<16><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
+                                                      g.counters, status, g.tickets + 4, bsync, quads, b.key_a,
+                                                      b.inst_gid, g.inst_start, g.big_list);
     emit_big_kernel<16><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
                                                          g.counters, b.key_a, b.inst_gid);
   }
 }
 
 // ------------------------------------------------------------------------------- row compaction
-// Exclusive scan of popcount(flags[u] & 15) — how many slot rows each instance owns.  Same
-// three-kernel scan as above, specialised so that a thread fetches its 16 flag bytes with ONE
-// 16-byte load (the flag array is 256-byte aligned and padded to a multiple of 16).
+// Exclusive scan of popcount(flags[u]) — how many slot rows each instance owns — in ONE kernel: a 1024-thread block
+// covers 16384 instances (a thread fetches its 16 flag bytes with one 16-byte load: the flag array is 256-byte aligned
+// and padded to a multiple of 16), publishes its total and gets the sum of the earlier blocks by decoupled look-back
+// (lb_exclusive_prefix above).  The status words and the ticket are zeroed by the forward's emission; because a
+// backward may be repeated on the same forward, the last block to finish zeroes them again for the next launch.
 // rows per instance = popcount((flag >> shift) & mask): shift 0 / mask 15 = one row per forward slot,
 // shift 4 / mask 3 = one row per packed survivor wave (reference mode, 15x15 tiles)
 __device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, int64_t base, int64_t n, int shift,
@@ -531,88 +565,109 @@ __device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, i
   for (int k = 0; k < 16; ++k) v[k] = (u32)__popc((w4[k >> 2] >> (8 * (k & 3) + shift)) & mask);
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void popc_reduce_kernel(const uint8_t* __restrict__ flags, int64_t n_host,
-                                                                  const int32_t* __restrict__ n_dev, int shift,
-                                                                  u32 mask, u32* __restrict__ partials) {
-  static_assert(SCAN_ITEMS == 16, "one 16-byte load per thread");
+constexpr int ROWS_THREADS = 1024;
+static_assert(ROWS_CHUNK == ROWS_THREADS * 16, "one 16-byte load of flags per thread");
+
+__global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
+    const uint8_t* __restrict__ flags, int64_t n_host, const int32_t* __restrict__ n_dev, int shift, u32 mask,
+    u32* __restrict__ rowbase, lb_word* status, u32* sync /* [0] ticket, [1] finished blocks */,
+    long long row_capacity, int32_t* __restrict__ counters, int32_t* __restrict__ status_dev) {
+  __shared__ u32 s_bid;
+  __shared__ u32 s_wsum[ROWS_THREADS / 64];
+  __shared__ lb_word s_base;
+  __shared__ u32 s_last;
+  if (threadIdx.x == 0) s_bid = atomicAdd(&sync[0], 1u);
+  __syncthreads();
+  const u32 b = s_bid;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t n = bounded_n(n_host, n_dev);  // flags beyond the instances of this frame are stale
-  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
-  u32 v[16];
-  load_popc16(flags, base, n, shift, mask, v);
-  u32 s = 0;
+  const int64_t bbase = (int64_t)b * ROWS_CHUNK;
+  if (bbase <= n) {  // (the block that holds index n writes the total; later blocks have nothing to do)
+    const int64_t base = bbase + (int64_t)threadIdx.x * 16;
+    u32 v[16];
+    load_popc16(flags, base, n, shift, mask, v);
+    u32 sum = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) s += v[k];
-  u32 total;
-  block_excl_scan_256(s, &total);
-  if (threadIdx.x == 0) partials[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void popc_apply_kernel(const uint8_t* __restrict__ flags, int64_t n_host,
-                                                                 const int32_t* __restrict__ n_dev, int shift,
-                                                                 u32 mask, const u32* __restrict__ partials,
-                                                                 u32* __restrict__ out) {
-  const int64_t n = bounded_n(n_host, n_dev);
-  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
-  u32 v[16];
-  load_popc16(flags, base, n, shift, mask, v);
-  u32 s = 0;
+    for (int k = 0; k < 16; ++k) sum += v[k];
+    u32 incl = sum;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) s += v[k];
-  u32 run = block_excl_scan_256(s, nullptr) + block_prefix_of_partials(partials, blockIdx.x);
-  u32 o[16];
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wsum[w] = incl;
+    __syncthreads();
+    u32 wbase = 0, total = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    o[k] = run;
-    run += v[k];
+    for (int i = 0; i < ROWS_THREADS / 64; ++i) {
+      const u32 c = s_wsum[i];
+      wbase += (i < w) ? c : 0u;
+      total += c;
+    }
+    if (w == 0) {
+      if (lane == 0) lb_store(&status[b], (b == 0 ? LB_INCL : LB_AGG) | (lb_word)total);
+      const lb_word pre = (b == 0) ? 0ull : lb_exclusive_prefix(status, b);
+      if (lane == 0) {
+        if (b != 0) lb_store(&status[b], LB_INCL | (pre + (lb_word)total));
+        s_base = pre;
+      }
+    }
+    __syncthreads();
+    u32 run = (u32)s_base + wbase + incl - sum;
+    u32 o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      o[k] = run;
+      run += v[k];
+    }
+    if (base + 16 <= n) {
+      uint4* dst = reinterpret_cast<uint4*>(rowbase + base);
+      dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+      dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+      dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+    } else {
+      for (int k = 0; k < 16; ++k)
+        if (base + k < n) rowbase[base + k] = o[k];
+    }
+    if (base <= n && n < base + 16) {  // the thread whose span holds index n: the grand total
+      const lb_word L = (lb_word)o[(int)(n - base)];  // flags at and beyond n count as zero, so this is the total
+      // a forward that overflowed its instance capacity (counters[2]) emitted nothing: inst_start / rowbase / rows
+      // of this frame do not exist, so the backward must not read them — report it like a row-capacity overflow
+      // (every later kernel then writes zero gradients)
+      const int32_t ov = ((long long)L > row_capacity || counters[2] != 0) ? 1 : 0;
+      rowbase[n] = (u32)L;
+      counters[6] = (int32_t)L;
+      counters[7] = ov;
+      if (status_dev) {
+        status_dev[0] = (int32_t)L;
+        status_dev[1] = ov;
+      }
+    }
   }
-  if (base + 16 <= n) {
-    uint4* dst = reinterpret_cast<uint4*>(out + base);
-    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
-    dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
-  } else {
-    for (int k = 0; k < 16; ++k)
-      if (base + k < n) out[base + k] = o[k];
-  }
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void rows_finalize_kernel(const u32* partials, int nb, int64_t n_host,
-                                                                    const int32_t* n_dev, u32* rowbase,
-                                                                    long long row_capacity, int32_t* counters,
-                                                                    int32_t* status_dev) {
-  const int64_t n = bounded_n(n_host, n_dev);
-  const u32 L = block_prefix_of_partials(partials, nb);
-  if (threadIdx.x == 0) {
-    // a forward that overflowed its instance capacity (counters[2]) emitted nothing: inst_start / rowbase / rows of
-    // this frame do not exist, so the backward must not read them — report it like a row-capacity overflow (every
-    // later kernel then writes zero gradients)
-    const int32_t ov = ((long long)L > row_capacity || counters[2] != 0) ? 1 : 0;
-    rowbase[n] = L;
-    counters[6] = (int32_t)L;
-    counters[7] = ov;
-    if (status_dev) {
-      status_dev[0] = (int32_t)L;
-      status_dev[1] = ov;
+  // self-reset for a repeated backward on the same forward: whoever finishes last has seen every block done
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&sync[1], 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (s_last) {
+    for (u32 i = threadIdx.x; i < gridDim.x; i += ROWS_THREADS) lb_store(&status[i], 0ull);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
 void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, bool packed_ref15,
-                           uint32_t* rowbase, uint32_t* partials, int64_t row_capacity, int32_t* counters,
-                           int32_t* status_dev, hipStream_t st) {
+                           uint32_t* rowbase, uint32_t* row_status, uint32_t* sync, int64_t row_capacity,
+                           int32_t* counters, int32_t* status_dev, hipStream_t st) {
   const int shift = packed_ref15 ? 4 : 0;
   const u32 mask = packed_ref15 ? 3u : 15u;
-  if (n_host <= 0) {  // zero instance capacity: no rows; an overflowed forward is still reported (counters[2])
-    rows_finalize_kernel<<<1, SCAN_THREADS, 0, st>>>(partials, 0, 0, n_dev, rowbase, (long long)row_capacity, counters,
-                                                     status_dev);
-    return;
-  }
-  const int nb = scan_blocks(n_host);
-  popc_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, partials);
-  popc_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, partials, rowbase);
-  rows_finalize_kernel<<<1, SCAN_THREADS, 0, st>>>(partials, nb, n_host, n_dev, rowbase, (long long)row_capacity,
-                                                   counters, status_dev);
+  if (n_host < 0) n_host = 0;
+  const int nb = (int)((n_host + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK);  // index n itself belongs to a block
+  row_compaction_kernel<<<nb, ROWS_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, rowbase,
+                                                     reinterpret_cast<lb_word*>(row_status), sync,
+                                                     (long long)row_capacity, counters, status_dev);
 }
 
 // ------------------------------------------------------------------------------- ranges
@@ -653,29 +708,40 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
 // Rank sort (len <= a few thousand): rank = #tiles heavier, ties by index -> a permutation.
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
                                                          u32* __restrict__ order_copy, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 4
+  extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
   const int x = blockIdx.x;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   const int len = q + (x < r ? 1 : 0);
-  const int len4 = (len + 3) & ~3;
-  for (int j = threadIdx.x; j < len4; j += blockDim.x) s_work[j] = (j < len) ? work[start + j] : 0u;
+  if (len == 0) return;  // (fewer than 8 tiles: this XCD's chunk is empty)
+  const int len64 = (len + 63) & ~63;
+  for (int j = threadIdx.x; j < len64; j += blockDim.x) s_work[j] = (j < len) ? work[start + j] : 0u;
   __syncthreads();
-  const int i = blockIdx.y * blockDim.x + threadIdx.x;  // one tile per thread
-  if (i >= len) return;
-  const u32 wi = s_work[i];
+  // 16 tiles per block, 16 lanes per tile: lane s of a tile's row compares against the entries j = 4 s + 64 k ..
+  // (one 16-byte LDS read each), the 16 partial ranks are summed inside the row with DPP rotations.  The zero padding
+  // never outranks anything (a padded slot j >= len has weight 0 <= wi and j > i).
+  const int i = blockIdx.y * 16 + (threadIdx.x >> 4);  // tile (clamped: every lane takes part in the row sum)
+  const int sub = threadIdx.x & 15;
+  const int ii = i < len ? i : len - 1;
+  const u32 wi = s_work[ii];
   int rank = 0;
-  // wave-uniform 16-byte LDS broadcast reads, four comparisons each; the zero padding never outranks anything
-  // (a padded slot j >= len has weight 0 <= wi and j > i)
-  for (int j = 0; j < len4; j += 4) {
+  for (int j = 4 * sub; j < len64; j += 64) {
     const uint4 w4 = *reinterpret_cast<const uint4*>(&s_work[j]);
-    rank += (w4.x > wi) || (w4.x == wi && j < i);
-    rank += (w4.y > wi) || (w4.y == wi && j + 1 < i);
-    rank += (w4.z > wi) || (w4.z == wi && j + 2 < i);
-    rank += (w4.w > wi) || (w4.w == wi && j + 3 < i);
+    rank += (w4.x > wi) || (w4.x == wi && j < ii);
+    rank += (w4.y > wi) || (w4.y == wi && j + 1 < ii);
+    rank += (w4.z > wi) || (w4.z == wi && j + 2 < ii);
+    rank += (w4.w > wi) || (w4.w == wi && j + 3 < ii);
   }
-  order[start + rank] = (u32)(start + i);
-  if (order_copy != nullptr) order_copy[start + rank] = (u32)(start + i);  // the caller's hint for its next frame
+  float rf = (float)rank;  // (exact: ranks are far below 2^24)
+  rf += dpp_mov<0x128>(rf);  // row_ror:8
+  rf += dpp_mov<0x124>(rf);  // row_ror:4
+  rf += dpp_mov<0x122>(rf);  // row_ror:2
+  rf += dpp_mov<0x121>(rf);  // row_ror:1
+  if (sub == 0 && i < len) {
+    const int rk = (int)rf;
+    order[start + rk] = (u32)(start + i);
+    if (order_copy != nullptr) order_copy[start + rk] = (u32)(start + i);  // the caller's hint for its next frame
+  }
 }
 
 // images beyond ~120 k tiles (8K x 8K): a chunk no longer fits the LDS rank sort; keep the natural order
@@ -691,12 +757,12 @@ void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t
                        hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
-  if (sizeof(u32) * (size_t)(len + 4) > 60 * 1024) {
+  if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
     tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_order, order_copy, ntiles);
     return;
   }
-  tile_order_kernel<<<dim3(8, (len + 255) / 256), 256, sizeof(u32) * (size_t)(len + 4), st>>>(tile_work, tile_order,
-                                                                                            order_copy, ntiles);
+  tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(tile_work, tile_order,
+                                                                                           order_copy, ntiles);
 }
 
 }  // namespace olsr

@@ -77,12 +77,15 @@ __device__ __forceinline__ u32 preprocess_one(
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
-    int ellipse, int act) {
+    int ellipse, int act, u32& count_out) {
+  count_out = 0;
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
   tiles_touched[idx] = 0;
   sort_key[idx] = 0xFFFFFFFFu;
   sort_val[idx] = (u32)idx;
+  // the emission reads the instance count from the record (one gather in depth order): zero for culled Gaussians
+  emit_rec[2 * (size_t)idx + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // in_frustum, CR/auxiliary.h:139-164
   const f3 p_orig = {orig_points[3 * (size_t)idx], orig_points[3 * (size_t)idx + 1], orig_points[3 * (size_t)idx + 2]};
@@ -171,6 +174,7 @@ __device__ __forceinline__ u32 preprocess_one(
     }
   }
   tiles_touched[idx] = count;
+  count_out = count;
   emit_rec[2 * (size_t)idx] = make_float4(pix_x, pix_y, conic.x, conic.y);
   emit_rec[2 * (size_t)idx + 1] = make_float4(conic.z, t2, __int_as_float(irad), __uint_as_float(count));
   return area;
@@ -186,34 +190,49 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
-    int ellipse, int act, u32* __restrict__ rect_partials) {
-  __shared__ u32 s_area[4];
+    int ellipse, int act, u32* __restrict__ rect_partials, u32* __restrict__ count_partials,
+    uint4* __restrict__ sync_words, int sync_quads) {
+  __shared__ u32 s_area[4], s_cnt[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 area = 0;
+  // the words the frame's fused kernels synchronise through (tickets, digit histograms, published block counts):
+  // zeroed here, at the head of the frame, by as many threads as there are 16-byte pieces
+  if (idx < sync_quads) sync_words[idx] = make_uint4(0u, 0u, 0u, 0u);
+  u32 area = 0, count = 0;
   if (idx < P)
     area = preprocess_one<TILE>(idx, D, M, orig_points, scales, scale_modifier, rotations, opacities, shs, clamped,
                                 cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, W, H, tan_fovx,
                                 tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy,
-                                tiles_touched, emit_rec, sort_key, sort_val, n_touched, prefiltered, ellipse, act);
-  // instances of the reference's rect binning (its num_rendered): one partial per block, summed by
-  // finalize_counts_kernel (7.8 k same-address atomics would cost more than the whole kernel)
+                                tiles_touched, emit_rec, sort_key, sort_val, n_touched, prefiltered, ellipse, act,
+                                count);
+  // instances of the reference's rect binning (its num_rendered) and instances this frame emits: one partial per
+  // block each, summed by the next kernel (7.8 k same-address atomics would cost more than the whole kernel)
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) area += __shfl_xor(area, m);
-  if ((threadIdx.x & 63) == 0) s_area[threadIdx.x >> 6] = area;
+  for (int m = 32; m >= 1; m >>= 1) {
+    area += __shfl_xor(area, m);
+    count += __shfl_xor(count, m);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_area[threadIdx.x >> 6] = area;
+    s_cnt[threadIdx.x >> 6] = count;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) rect_partials[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
+  if (threadIdx.x == 0 && (int)(blockIdx.x * blockDim.x) < P) {  // (blocks beyond P only zero sync words)
+    rect_partials[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
+    count_partials[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  }
 }
 
 void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometryState& g, int32_t* radii,
                        int32_t* n_touched, hipStream_t st) {
   if (s.P <= 0) return;
-  const int nb = (s.P + 255) / 256;
+  const int sync_quads = (int)(g.sync_count / 4);
+  const int nb = (max(s.P, sync_quads) + 255) / 256;  // (the sync words are far fewer than the Gaussians)
 #define OLSR_PRE_ARGS                                                                                                 \
   s.P, s.D, s.M, s.means3D, s.scales, s.scale_modifier, s.rotations, s.opacities, s.shs, g.clamped, s.cov3D_precomp,  \
       s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
       g.emit_rec, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
-      s.activations, reinterpret_cast<u32*>(g.tau_partials)
+      s.activations, g.part_rect, g.part_count, reinterpret_cast<uint4*>(g.sync_words), sync_quads
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

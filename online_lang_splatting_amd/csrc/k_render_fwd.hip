@@ -36,7 +36,7 @@ constexpr int FWD_BATCH = 128;
 
 template <int TILE, int F>
 __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
-    const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
+    const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
@@ -67,7 +67,15 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
   const int tid = threadIdx.x;
   const int w = tid >> 6;
   const int bx = tile_id % gx, by = tile_id / gx;
-  const u32 r0 = ranges[2 * tile_id], r1 = ranges[2 * tile_id + 1];
+  u32 r0 = ranges[2 * tile_id], r1 = ranges[2 * tile_id + 1];
+  if (r1 <= r0) {  // a tile without instances still holds the initial {UINT_MAX, 0}: leave {0, 0} behind like the
+    r0 = 0;        // reference's cudaMemset + identifyTileRanges (CR/rasterizer_impl.cu:485-493)
+    r1 = 0;
+    if (threadIdx.x == 0) {
+      ranges_rw[2 * tile_id] = 0;
+      ranges_rw[2 * tile_id + 1] = 0;
+    }
+  }
   const int n = (int)(r1 - r0);
 
   const int rank = tid;
@@ -242,7 +250,7 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                          const ImageState& im, float* out_color, float* out_language, float* out_depth,
                          float* out_opacity, int32_t* n_touched, uint32_t* order_inout, hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
-  render_fwd_kernel<TILE, F><<<d.ntiles, 256, 0, st>>>(im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles,
+  render_fwd_kernel<TILE, F><<<d.ntiles, 256, 0, st>>>(im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles,
                                                        g.means2D, g.conic_opacity, g.depths, colors,
                                                        s.language_precomp, s.background, im.final_T, im.n_contrib,
                                                        out_color, out_language, out_depth, out_opacity, n_touched,

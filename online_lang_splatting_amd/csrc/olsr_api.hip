@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -131,6 +132,25 @@ struct BinningProvider {
   int64_t capacity = -1;  // async mode when >= 0
 };
 
+// OLSR_SORT_LEGACY=1 forces the multi-kernel radix passes (the fallback of sorts too large for the fused ones), so
+// that both paths can be tested at any size
+bool force_legacy_sort() {
+  const char* e = std::getenv("OLSR_SORT_LEGACY");
+  return e && e[0] == '1';
+}
+
+// a pinned word for the instance count of the drop-in (synchronising) entry: the copy is asynchronous and the host
+// waits on an event, so the GPU keeps sorting while the host allocates the binning buffer
+struct PinnedCount {
+  int32_t* p = nullptr;
+  hipEvent_t ev = nullptr;
+  ~PinnedCount() {
+    if (p) (void)hipHostFree(p);
+    if (ev) (void)hipEventDestroy(ev);
+  }
+};
+thread_local PinnedCount g_pinned;
+
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
                  int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st) {
@@ -150,28 +170,45 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     HIP_TRY(hipMemsetAsync(im.ranges, 0, sizeof(uint32_t) * 2 * (size_t)d.ntiles, st));
   }
 
+  const bool legacy = force_legacy_sort();
+  const bool sync_mode = bp.capacity < 0;
   int64_t n_host = 0;
   BinningState b{};
   if (s.P > 0) {
-    launch_preprocess(s, d, g, radii, n_touched, st);
+    launch_preprocess(s, d, g, radii, n_touched, st);  // also zeroes the geometry buffer's synchronisation words
     STAGE("preprocess");
+    // digit totals of the four depth passes in one read of the keys + the frame's counters (instances emitted,
+    // the reference's num_rendered, overflow against the capacity), tile ranges reset to "empty"
+    FusedHouse house{g.part_rect, g.part_count, (s.P + 255) / 256, sync_mode ? 0x7FFFFFFFLL : (long long)bp.capacity,
+                     g.counters, num_rendered_dev, im.ranges, 2 * d.ntiles};
+    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, st);
+    if (sync_mode) {
+      if (!g_pinned.p) {
+        HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 2 * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&g_pinned.ev, hipEventDisableTiming));
+      }
+      HIP_TRY(hipMemcpyAsync(g_pinned.p, g.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(g_pinned.ev, st));
+    }
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
-    launch_radix_sort(sb, s.P, nullptr, 32, false, st);
+    if (!legacy && fused_sort_applicable(s.P, 32))
+      launch_sort_fused(sb, s.P, nullptr, 32, false, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr, st);
+    else
+      launch_radix_sort(sb, s.P, nullptr, 32, false, st);
     STAGE("depth_sort");
-    launch_instance_offsets(g, s.P, bp.capacity >= 0 ? bp.capacity : 0x7FFFFFFFLL, num_rendered_dev, im.ranges,
-                            d.ntiles, st);
-    STAGE("instance_offsets");
   }
 
   void* bin_buf = nullptr;
-  if (bp.capacity >= 0) {
+  if (!sync_mode) {
     n_host = bp.capacity;
     bin_buf = bp.fixed;
   } else {
     int32_t R = 0;
     if (s.P > 0) {
-      HIP_TRY(hipMemcpyAsync(&R, g.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));  // the reference's blocking D2H, CR/rasterizer_impl.cu:454-455
+      // the reference's blocking D2H (CR/rasterizer_impl.cu:454-455) — but the count was ready before the depth sort,
+      // which keeps running while the host waits here and allocates
+      HIP_TRY(hipEventSynchronize(g_pinned.ev));
+      R = g_pinned.p[0];
       if (R < 0) return fail(OLSR_ERR_CAPACITY, "instance count exceeds 2^31-1");
     }
     n_host = R;
@@ -183,19 +220,32 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   b = BinningState::carve(bin_buf, (size_t)n_host, bb);
   const int32_t* n_dev = &g.counters[1];
 
-  const uint32_t* sorted_keys = b.key_a;
-  if (s.P > 0 && n_host > 0) {
-    launch_emit(s, d, g, radii, b, st);
+  if (s.P > 0) {
+    const int tbits = tile_bits(d.ntiles);
+    int tpasses = 0;
+    const int tdb = fused_sort_digit_bits(tbits, &tpasses);
+    const bool fused_tiles = !legacy && fused_sort_applicable(n_host, tbits);
+    // synchronisation words of the binning buffer that this frame uses (zeroed by the emission kernel)
+    const int64_t bin_sync_words =
+        (b.tile_status - b.sync_words) +
+        (fused_tiles ? (int64_t)tpasses * sort_plan(n_host).nblk * ((int64_t)1 << tdb) : 0);
+    launch_emit(s, d, g, b, bin_sync_words, st);
     STAGE("emit");
-    // arrange the value ping-pong so that the last pass always lands in b.src
-    const bool odd = tile_sort_where(d.ntiles) != 0;
-    SortBuffers sb{b.key_a, b.key_b, odd ? b.val_b : b.src, odd ? b.src : b.val_b, b.radix_table, b.scan_partials};
-    const int where = launch_radix_sort(sb, n_host, n_dev, tile_bits(d.ntiles), true, st);
-    if (where) sorted_keys = b.key_b;
-    STAGE("tile_sort");
+    if (n_host > 0) {
+      // arrange the value ping-pong so that the last pass always lands in b.src
+      const bool odd = tile_sort_where(d.ntiles) != 0;
+      SortBuffers sb{b.key_a, b.key_b, odd ? b.val_b : b.src, odd ? b.src : b.val_b, b.radix_table, b.scan_partials};
+      if (fused_tiles) {
+        launch_sort_hist(b.key_a, n_host, n_dev, tbits, b.tile_hist, nullptr, st);
+        // the first pass also clears the liveness flags, the last one derives the tile ranges
+        launch_sort_fused(sb, n_host, n_dev, tbits, true, b.tile_hist, b.tile_status, b.tickets, b.flags, im.ranges, st);
+      } else {
+        const int where = launch_radix_sort(sb, n_host, n_dev, tbits, true, st);
+        launch_tile_ranges(where ? b.key_b : b.key_a, n_host, n_dev, im.ranges, b.flags, st);
+      }
+      STAGE("tile_sort");
+    }
   }
-  launch_tile_ranges(sorted_keys, (s.P > 0) ? n_host : 0, n_dev, im.ranges, b.flags, st);
-  STAGE("tile_ranges");
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
                         st);
   STAGE("render_forward");
@@ -311,7 +361,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
 
   // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended
   const bool packed_ref15 = (s.bwd_mode == OLSR_BWD_REFERENCE && s.tile == 15);
-  launch_row_compaction(b.flags, num_rendered, &g.counters[1], packed_ref15, b.rowbase, b.scan_partials,
+  launch_row_compaction(b.flags, num_rendered, &g.counters[1], packed_ref15, b.rowbase, b.row_status, b.tickets + 8,
                         scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, status_dev, st);
   STAGE("row_compaction");
   if (scratch_alloc) {
@@ -459,7 +509,6 @@ const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t 
   if (!std::strcmp(name, "clamped")) return g.clamped;
   if (!std::strcmp(name, "tiles_touched")) return g.tiles_touched;
   if (!std::strcmp(name, "depth_order")) return g.depth_order;
-  if (!std::strcmp(name, "offsets")) return g.offsets;
   if (!std::strcmp(name, "counters")) return g.counters;
   return nullptr;
 }

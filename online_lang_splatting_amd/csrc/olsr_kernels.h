@@ -34,24 +34,47 @@ struct SortBuffers {
 // Returns 0 if the result ends in (key_a,val_a), 1 if in (key_b,val_b).
 int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
                       hipStream_t st);
-// scan of tiles_touched in depth order + the frame's counters; also zeroes `ranges` (2 * ntiles) and the
-// work-list / row counters
-void launch_instance_offsets(const GeometryState& g, int P, int64_t capacity, int32_t* num_rendered_dev,
-                             uint32_t* ranges, int ntiles, hipStream_t st);
-void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const int32_t* radii,
-                 const BinningState& b, hipStream_t st);
-// exclusive scan of popcount(flags & 15) over [0, n] -> rowbase[0..n]; counters[6] = total live rows,
-// counters[7] = (total > row_capacity)
+// fused scan of the per-Gaussian instance counts (depth order) + emission of the instances; also zeroes the first
+// bin_sync_words words of the binning buffer's synchronisation area
+void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                 int64_t bin_sync_words, hipStream_t st);
+// exclusive scan of popcount(flags) over [0, n] -> rowbase[0..n] in one kernel; counters[6] = total live rows,
+// counters[7] = (total > row_capacity) or the forward's instance overflow
 // packed_ref15: rows per instance = packed survivor waves (flag bits 4-5) instead of forward slots (bits 0-3)
+// row_status / sync: BinningState::row_status and tickets + 8 (zeroed by the forward, re-zeroed by the kernel itself)
 void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, bool packed_ref15,
-                           uint32_t* rowbase, uint32_t* partials, int64_t row_capacity, int32_t* counters,
-                           int32_t* status_dev, hipStream_t st);
+                           uint32_t* rowbase, uint32_t* row_status, uint32_t* sync, int64_t row_capacity,
+                           int32_t* counters, int32_t* status_dev, hipStream_t st);
 // backward launch order: inside each XCD's contiguous chunk of tiles, heaviest (most live pairs) first
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        hipStream_t st);
 // ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
                         uint8_t* flags, hipStream_t st);
+
+// k_sort.hip — one kernel per radix pass (digit counts published per block, see the file header)
+struct FusedHouse {  // the frame's bookkeeping done by block 0 of the depth sort's histogram kernel
+  const uint32_t* part_rect;
+  const uint32_t* part_count;
+  int nparts;
+  long long capacity;
+  int32_t* counters;
+  int32_t* num_rendered_dev;
+  uint32_t* ranges;  // initialised to {UINT_MAX, 0} per tile (empty)
+  int nranges;
+};
+bool fused_sort_applicable(int64_t n_host, int bits);
+int fused_sort_digit_bits(int bits, int* passes_out);
+// digit totals of all passes (hist[pass][256], zeroed beforehand); optionally the frame's bookkeeping
+void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
+                      const FusedHouse* house, hipStream_t st);
+// stable sort on the low `bits` bits; status: [passes][sort_plan(n_host).nblk][1 << digit bits] zeroed words, tickets:
+// one zeroed word per pass.  flags_clear (with vals_in_identity): byte i is cleared for every element; ranges: the
+// last pass derives per-key [start, end) (keys must then be tile ids).  Returns where the result ends (0: a, 1: b);
+// the sorted keys of the LAST pass are not written.
+int launch_sort_fused(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
+                      const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
+                      hipStream_t st);
 
 // k_render_fwd.hip
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,

@@ -80,7 +80,6 @@ struct GeometryState {
   uint32_t* val_a;        // [P] Gaussian ids (ping)
   uint32_t* val_b;        // [P] (pong)
   uint32_t* depth_order;  // alias of the buffer holding the final order (val_a after 4 passes)
-  uint32_t* offsets;      // [P] (multi-kernel fallback only) inclusive scan of tiles_touched in depth order
   uint32_t* inst_start;   // [P] Gaussian id -> emission index of its first instance
   uint32_t* radix_table;  // [256 * sort_blocks(P)]
   uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
@@ -98,7 +97,7 @@ struct GeometryState {
   uint32_t* tickets;      // [16] dynamic block ids: 0-3 depth passes, 4 scan+emit
   uint32_t* sort_hist;    // [4][256] digit totals of the four depth passes
   uint32_t* sort_status;  // [4][blocks][256] per-block digit counts of the depth passes (bit 31 = published)
-  uint32_t* emit_status;  // [ceil(P / EMIT_CHUNK)] per-block instance totals of the fused scan + emission
+  uint32_t* emit_status;  // [ceil(P / EMIT_CHUNK)] x 64 bit: per-block instance totals of the fused scan + emission
   uint32_t* part_rect;    // [ceil(P / 256)] preprocess' per-block sums: instances of the reference's rect binning
   uint32_t* part_count;   // [ceil(P / 256)] ... and instances this frame emits
   static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
@@ -117,7 +116,6 @@ struct GeometryState {
     g.val_a = c.take<uint32_t>(P);
     g.val_b = c.take<uint32_t>(P);
     g.depth_order = g.val_a;
-    g.offsets = c.take<uint32_t>(P);
     g.inst_start = c.take<uint32_t>(P);
     const size_t table = 256 * (size_t)sort_blocks((long long)P);
     g.radix_table = c.take<uint32_t>(table);
@@ -128,7 +126,7 @@ struct GeometryState {
     g.big_list = c.take<uint4>(P);
     {
       const size_t st_words = fused_status_words((long long)P, 4);
-      const size_t emit_blocks = (P + EMIT_CHUNK - 1) / EMIT_CHUNK + 1;
+      const size_t emit_blocks = 2 * ((P + EMIT_CHUNK - 1) / EMIT_CHUNK + 1);  // 64-bit look-back words
       g.sync_count = 16 + 4 * 256 + st_words + emit_blocks;
       g.sync_count = (g.sync_count + 3) / 4 * 4;  // zeroed with 16-byte stores
       g.sync_words = c.take<uint32_t>(g.sync_count);
@@ -179,7 +177,7 @@ struct BinningState {
   uint32_t* tickets;     // [16]: 0-3 tile-sort passes, 8 row compaction, 9 its done counter
   uint32_t* tile_hist;   // [4][256] digit totals of the tile-sort passes
   uint32_t* tile_status; // [4][blocks][256]
-  uint32_t* row_status;  // [ceil((R + 1) / ROWS_CHUNK)] per-block live-row totals of the row compaction
+  uint32_t* row_status;  // [ceil((R + 1) / ROWS_CHUNK)] x 64 bit: per-block live-row totals of the row compaction
   static BinningState carve(void* buf, size_t R, size_t& bytes) {
     Carver c(buf);
     BinningState b;
@@ -195,7 +193,7 @@ struct BinningState {
     b.rowbase = c.take<uint32_t>(R + 1);
     {
       const size_t st_words = fused_status_words((long long)R, 4);
-      const size_t row_blocks = (R + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK + 1;
+      const size_t row_blocks = 2 * ((R + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK + 1);  // 64-bit look-back words
       b.sync_count = 16 + 4 * 256 + st_words + row_blocks;
       b.sync_count = (b.sync_count + 3) / 4 * 4;
       b.sync_words = c.take<uint32_t>(b.sync_count);

@@ -263,6 +263,41 @@ def test_transparent_scene_walks_whole_lists(hip, oracle):
     _check(hip, oracle, sc, seed=9, mode=_abi.BWD_EXACT)
 
 
+def test_multi_kernel_sort_fallback(hip, oracle, monkeypatch):
+    """Sorts too large for the one-kernel-per-pass radix passes (> 33 M keys) fall back to histogram -> device-wide
+    scan -> scatter launches; OLSR_SORT_LEGACY=1 forces that path at any size so it keeps meeting the oracle."""
+    monkeypatch.setenv("OLSR_SORT_LEGACY", "1")
+    _check(hip, oracle, make_scene(6000, 200, 150, 15, seed=73), seed=4)
+    _check(hip, oracle, make_scene(3000, 157, 101, 0, seed=74), seed=5, tile=16, mode=_abi.BWD_EXACT)
+    monkeypatch.delenv("OLSR_SORT_LEGACY")
+    _check(hip, oracle, make_scene(6000, 200, 150, 15, seed=73), seed=4)
+
+
+def test_repeated_backward_on_one_forward(hip):
+    """The row compaction's look-back state is re-armed by the kernel itself: a backward may be repeated on the same
+    forward (autograd's retain_graph, or the test above) and must give the same bits every time."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    dev = torch.device(DEV)
+    sc = make_scene(30000, 400, 300, 15, seed=75)
+    cam = sc.camera
+    ws = RasterWorkspace(sc.P, 400, 300, 15, sc.shs.shape[1], 1_500_000, dev)
+    ws.set_scene(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+                 rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev),
+                 viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+                 projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+                 tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(1))
+    ws.forward()
+    first = {k: v.clone() for k, v in ws.backward(dc, dl, dd).items()}
+    st0 = ws.backward_status()
+    for _ in range(4):
+        again = ws.backward(dc, dl, dd)
+        assert ws.backward_status() == st0
+        for k in first:
+            assert torch.equal(again[k], first[k]), k
+    assert st0[0] > 0 and not st0[1]
+
+
 def test_config1_rgb_forward(hip, oracle):
     """BASELINE.json configs[0]: 10 k Gaussians, 256x256, RGB-only (SH degree 3)."""
     from online_lang_splatting_amd.scene import make_config_scene
