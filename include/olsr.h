@@ -342,6 +342,12 @@ const void *olsr_image_field(const void *image_buffer, int32_t width, int32_t he
 void olsr_set_profiling(int enable);
 int olsr_get_stage_times(const char **names, float *ms, int max);
 
+/* Debug aid (kernel tuning): while a device buffer of max_launches * max_blocks * 8 uint64 is set, every block of the
+ * next radix-sort passes issued by this thread records the shader clock at its phase boundaries ({ticket, keys
+ * counted, counts published, ranked, predecessors summed, written}; index (launch * max_blocks + block) * 8 + phase).
+ * NULL switches it off. */
+void olsr_debug_sort_timing(unsigned long long *device_buffer, int max_blocks, int max_launches);
+
 const char *olsr_last_error(void);
 const char *olsr_version(void);
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libolsr.so")
 EXPORTS = (
     "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_backward_scratch_bytes", "olsr_forward", "olsr_forward_async",
     "olsr_backward", "olsr_accumulate_gradients", "olsr_mapping_loss", "olsr_mapping_loss_scratch_bytes", "olsr_tracking_loss", "olsr_knn_mean_dist2", "olsr_knn_scratch_bytes", "olsr_adam_step", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
-    "olsr_set_profiling", "olsr_get_stage_times", "olsr_last_error", "olsr_version",
+    "olsr_set_profiling", "olsr_get_stage_times", "olsr_debug_sort_timing", "olsr_last_error", "olsr_version",
 )
 
 _lib = None

@@ -314,10 +314,9 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 // cub::DeviceScan::InclusiveSum + duplicateWithKeys (CR/rasterizer_impl.cu:451, 70-111) in ONE kernel.  The depth
 // half of the reference's key is implied by the emission order; only the tile id is written.
 //   scan_emit_kernel  one thread per depth rank.  The instance count of the Gaussian comes with its emission record
-//                    (one 16-byte gather in depth order); the block scans its 1024 counts, publishes the total and
-//                    obtains the sum of all earlier blocks by decoupled look-back (one 64-bit status word per block:
-//                    aggregate, later inclusive prefix; a wave inspects 64 predecessors per step) — no separate scan
-//                    launches, no offsets array.  A Gaussian with <= EMIT_BIG instances is then written by its lane
+//                    (one 16-byte gather in depth order); the block scans its 1024 counts and adds the totals of all
+//                    earlier blocks, which the last pass of the depth sort accumulated while it scattered the
+//                    Gaussians to their depth ranks — no separate scan launches, no offsets array, no waiting.  A Gaussian with <= EMIT_BIG instances is then written by its lane
 //                    (consecutive ranks own adjacent output runs), larger ones go to a work list (one aggregated
 //                    atomic per block; the list order influences no result);
 //   emit_big_kernel  persistent grid, one wave per listed Gaussian: near splats cover hundreds to
@@ -327,56 +326,62 @@ constexpr u32 EMIT_BIG = OLSR_BIG_FOOTPRINT;
 constexpr int EMIT_BIG_BLOCKS = 512;
 constexpr int EMIT_THREADS = EMIT_CHUNK;  // 1024: one list atomic per 1024 Gaussians
 
-typedef unsigned long long lb_word;  // look-back status: bit 63 = aggregate published, bit 62 = inclusive prefix
-constexpr lb_word LB_AGG = 1ull << 63, LB_INCL = 1ull << 62, LB_VAL = (1ull << 62) - 1ull;
-__device__ __forceinline__ lb_word lb_load(const lb_word* p) {
+// Block totals of a single-pass scan: two 32-bit words per block, {READY | total, READY | inclusive prefix}, zeroed
+// before the launch; published and polled with relaxed agent-scope accesses (the data is the flag).
+constexpr u32 LB_READY = 0x80000000u;
+__device__ __forceinline__ u32 lb_load(const u32* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void lb_store(lb_word* p, lb_word v) {
+__device__ __forceinline__ void lb_store(u32* p, u32 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Sum of the totals of blocks [0, b), called by ONE full wave of block b (which has published its aggregate).
-// Blocks take their index from a ticket, so every predecessor has started and publishes without waiting.
-__device__ __forceinline__ lb_word lb_exclusive_prefix(const lb_word* status, u32 b) {
-  const int lane = lane_id();
-  lb_word excl = 0;
-  for (long long top = (long long)b - 1; top >= 0; top -= 64) {
-    const long long j = top - lane;
-    lb_word sv = LB_INCL;  // (before block 0: an inclusive prefix of zero)
-    if (j >= 0) {
-      sv = lb_load(&status[j]);
-      while (!(sv & (LB_AGG | LB_INCL))) {
-        __builtin_amdgcn_s_sleep(1);
-        sv = lb_load(&status[j]);
-      }
-    }
-    const u64 incl = ballot((sv & LB_INCL) != 0);
-    const int first = incl ? (int)__builtin_ctzll(incl) : 64;  // nearest predecessor whose prefix is known
-    lb_word v = (lane <= first) ? (sv & LB_VAL) : 0ull;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    excl += v;
-    if (incl) break;
+__device__ __forceinline__ u32 lb_wait(const u32* p) {
+  u32 v = lb_load(p);
+  // (bounded: a predecessor publishes within microseconds; a corrupted state buffer must not hang the GPU)
+  for (int spin = 0; !(v & LB_READY) && spin < (1 << 22); ++spin) {
+    __builtin_amdgcn_s_sleep(1);
+    v = lb_load(p);
   }
+  return v & ~LB_READY;
+}
+// Sum of the totals of blocks [0, b), for ALL threads of block b (which publishes `total` here).  Blocks take their
+// index from a ticket, so every predecessor has started and publishes without waiting for anyone: the look-back is
+// ONE batch — every thread fetches the total of one predecessor (a dependent trip to the fabric costs ~2 us, a chain
+// of 64-wide windows costs one per window).  Only beyond THREADS predecessors does a block wait for an inclusive
+// prefix (that of the last block of the previous group of THREADS).
+template <int THREADS>
+__device__ __forceinline__ u32 lb_block_exclusive(u32* status, u32 b, u32 total, u32* s_red /* [THREADS / 64 + 1] */) {
+  const u32 tid = threadIdx.x;
+  const u32 first = b & ~(u32)(THREADS - 1);
+  if (tid == 0) lb_store(&status[2 * b], LB_READY | total);
+  u32 v = 0;
+  if (first + tid < b) v = lb_wait(&status[2 * (first + tid)]);
+  if (tid == THREADS - 1 && first > 0) v += lb_wait(&status[2 * (first - 1) + 1]);  // (first + tid >= b for this thread)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if ((tid & 63) == 0) s_red[tid >> 6] = v;
+  __syncthreads();
+  u32 excl = 0;
+#pragma unroll
+  for (int i = 0; i < THREADS / 64; ++i) excl += s_red[i];
+  if (tid == 0) lb_store(&status[2 * b + 1], LB_READY | (excl + total));
+  __syncthreads();  // (s_red may be reused)
   return excl;
 }
 
 template <int TILE>
 __global__ __launch_bounds__(EMIT_THREADS) void scan_emit_kernel(
     int P, const u32* __restrict__ order, const float4* __restrict__ emit_rec, int ellipse, int W, int H, int gx, int gy,
-    int32_t* __restrict__ counters, lb_word* status, u32* ticket, uint4* __restrict__ bin_sync, int bin_sync_quads,
+    int32_t* __restrict__ counters, const u32* __restrict__ block_totals, uint4* __restrict__ bin_sync,
+    int bin_sync_quads,
     u32* __restrict__ keys, u32* __restrict__ inst_gid, u32* __restrict__ inst_start, uint4* __restrict__ big_list) {
-  __shared__ u32 s_bid;
-  __shared__ u32 s_wsum[EMIT_THREADS / 64];
-  __shared__ lb_word s_base;
+  __shared__ u32 s_wsum[EMIT_THREADS / 64 + 1];
   // the words the tile sort and the row compaction synchronise through live in the binning buffer, which exists only
   // from here on (the drop-in entry allocates it after the instance count is known)
   for (int q = (int)(blockIdx.x * EMIT_THREADS + threadIdx.x); q < bin_sync_quads; q += (int)(gridDim.x * EMIT_THREADS))
     bin_sync[q] = make_uint4(0u, 0u, 0u, 0u);
   if (counters[2] != 0) return;  // more instances than the caller's capacity: nothing is emitted (uniform)
-  if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
-  __syncthreads();
-  const u32 b = s_bid;
+  const u32 b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = (int)(b * EMIT_THREADS + threadIdx.x);
   u32 g = 0, n = 0;
@@ -402,16 +407,20 @@ __global__ __launch_bounds__(EMIT_THREADS) void scan_emit_kernel(
     wbase += (i < w) ? c : 0u;
     total += c;
   }
-  if (w == 0) {
-    if (lane == 0) lb_store(&status[b], (b == 0 ? LB_INCL : LB_AGG) | (lb_word)total);
-    const lb_word base = (b == 0) ? 0ull : lb_exclusive_prefix(status, b);
-    if (lane == 0) {
-      if (b != 0) lb_store(&status[b], LB_INCL | (base + (lb_word)total));
-      s_base = base;
-    }
-  }
   __syncthreads();
-  const u32 off = (u32)s_base + wbase + incl - n;
+  // first instance of this block = instances of all earlier blocks: the last depth-sort pass left every block's
+  // total behind (emit_totals), so no block waits for another one here
+  u32 pre = 0;
+  for (u32 j = threadIdx.x; j < b; j += EMIT_THREADS) pre += block_totals[j];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m);
+  if (lane == 0) s_wsum[w] = pre;
+  __syncthreads();
+  u32 base = 0;
+#pragma unroll
+  for (int i = 0; i < EMIT_THREADS / 64; ++i) base += s_wsum[i];
+  (void)total;
+  const u32 off = base + wbase + incl - n;
   if (n > 0) {
     inst_start[g] = off;
     if (n <= EMIT_BIG) {
@@ -518,23 +527,45 @@ __global__ __launch_bounds__(256) void emit_big_kernel(const uint4* __restrict__
   }
 }
 
+// per-emission-block instance totals for a depth order that did not come from the fused sort (multi-kernel passes)
+__global__ __launch_bounds__(EMIT_THREADS) void emit_totals_kernel(int P, const u32* __restrict__ order,
+                                                                   const float4* __restrict__ emit_rec,
+                                                                   u32* __restrict__ totals) {
+  __shared__ u32 s_w[EMIT_THREADS / 64];
+  const int r = (int)(blockIdx.x * EMIT_THREADS + threadIdx.x);
+  u32 n = (r < P) ? __float_as_uint(emit_rec[2 * (size_t)order[r] + 1].w) : 0u;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 t = 0;
+    for (int i = 0; i < EMIT_THREADS / 64; ++i) t += s_w[i];
+    totals[blockIdx.x] = t;
+  }
+}
+void launch_emit_totals(const uint32_t* order, int P, const float4* emit_rec, uint32_t* emit_totals, hipStream_t st) {
+  if (P <= 0) return;
+  emit_totals_kernel<<<(P + EMIT_THREADS - 1) / EMIT_THREADS, EMIT_THREADS, 0, st>>>(P, order, emit_rec, emit_totals);
+}
+
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                  int64_t bin_sync_words, hipStream_t st) {
   if (s.P <= 0) return;
   const int nb = (s.P + EMIT_THREADS - 1) / EMIT_THREADS;
   const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
-  lb_word* status = reinterpret_cast<lb_word*>(g.emit_status);
+  const u32* status = g.emit_status;  // per-block instance totals, accumulated by the depth sort's last pass
   uint4* bsync = reinterpret_cast<uint4*>(b.sync_words);
   const int quads = (int)((bin_sync_words + 3) / 4);
   if (d.tile == 15) {
     scan_emit_kernel<15><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
-                                                      g.counters, status, g.tickets + 4, bsync, quads, b.key_a,
+                                                      g.counters, status, bsync, quads, b.key_a,
                                                       b.inst_gid, g.inst_start, g.big_list);
     emit_big_kernel<15><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
                                                          g.counters, b.key_a, b.inst_gid);
   } else {
     scan_emit_kernel<16><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
-                                                      g.counters, status, g.tickets + 4, bsync, quads, b.key_a,
+                                                      g.counters, status, bsync, quads, b.key_a,
                                                       b.inst_gid, g.inst_start, g.big_list);
     emit_big_kernel<16><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
                                                          g.counters, b.key_a, b.inst_gid);
@@ -570,11 +601,10 @@ static_assert(ROWS_CHUNK == ROWS_THREADS * 16, "one 16-byte load of flags per th
 
 __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
     const uint8_t* __restrict__ flags, int64_t n_host, const int32_t* __restrict__ n_dev, int shift, u32 mask,
-    u32* __restrict__ rowbase, lb_word* status, u32* sync /* [0] ticket, [1] finished blocks */,
+    u32* __restrict__ rowbase, u32* status, u32* sync /* [0] ticket, [1] finished blocks */,
     long long row_capacity, int32_t* __restrict__ counters, int32_t* __restrict__ status_dev) {
   __shared__ u32 s_bid;
-  __shared__ u32 s_wsum[ROWS_THREADS / 64];
-  __shared__ lb_word s_base;
+  __shared__ u32 s_wsum[ROWS_THREADS / 64 + 1];
   __shared__ u32 s_last;
   if (threadIdx.x == 0) s_bid = atomicAdd(&sync[0], 1u);
   __syncthreads();
@@ -604,39 +634,37 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
       wbase += (i < w) ? c : 0u;
       total += c;
     }
-    if (w == 0) {
-      if (lane == 0) lb_store(&status[b], (b == 0 ? LB_INCL : LB_AGG) | (lb_word)total);
-      const lb_word pre = (b == 0) ? 0ull : lb_exclusive_prefix(status, b);
-      if (lane == 0) {
-        if (b != 0) lb_store(&status[b], LB_INCL | (pre + (lb_word)total));
-        s_base = pre;
-      }
-    }
     __syncthreads();
-    u32 run = (u32)s_base + wbase + incl - sum;
-    u32 o[16];
+    const u32 pre = lb_block_exclusive<ROWS_THREADS>(status, b, total, s_wsum);
+    u32 run = pre + wbase + incl - sum;
+    // (static indices only: a dynamically indexed private array would be promoted to 64 KB of LDS)
+    u32 L = 0;
+    const int at_n = (base <= n && n < base + 16) ? (int)(n - base) : -1;
+    uint4 q4[4];
+    u32* o = reinterpret_cast<u32*>(q4);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       o[k] = run;
+      L = (k == at_n) ? run : L;
       run += v[k];
     }
     if (base + 16 <= n) {
       uint4* dst = reinterpret_cast<uint4*>(rowbase + base);
-      dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-      dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-      dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
-      dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+      dst[0] = q4[0];
+      dst[1] = q4[1];
+      dst[2] = q4[2];
+      dst[3] = q4[3];
     } else {
+#pragma unroll
       for (int k = 0; k < 16; ++k)
         if (base + k < n) rowbase[base + k] = o[k];
     }
-    if (base <= n && n < base + 16) {  // the thread whose span holds index n: the grand total
-      const lb_word L = (lb_word)o[(int)(n - base)];  // flags at and beyond n count as zero, so this is the total
+    if (at_n >= 0) {  // the thread whose span holds index n: flags at and beyond n count as zero, so L is the total
       // a forward that overflowed its instance capacity (counters[2]) emitted nothing: inst_start / rowbase / rows
       // of this frame do not exist, so the backward must not read them — report it like a row-capacity overflow
       // (every later kernel then writes zero gradients)
       const int32_t ov = ((long long)L > row_capacity || counters[2] != 0) ? 1 : 0;
-      rowbase[n] = (u32)L;
+      rowbase[n] = L;
       counters[6] = (int32_t)L;
       counters[7] = ov;
       if (status_dev) {
@@ -650,7 +678,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
   if (threadIdx.x == 0) s_last = (atomicAdd(&sync[1], 1u) == gridDim.x - 1u) ? 1u : 0u;
   __syncthreads();
   if (s_last) {
-    for (u32 i = threadIdx.x; i < gridDim.x; i += ROWS_THREADS) lb_store(&status[i], 0ull);
+    for (u32 i = threadIdx.x; i < 2 * gridDim.x; i += ROWS_THREADS) lb_store(&status[i], 0u);
     if (threadIdx.x == 0) {
       __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -666,7 +694,7 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
   if (n_host < 0) n_host = 0;
   const int nb = (int)((n_host + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK);  // index n itself belongs to a block
   row_compaction_kernel<<<nb, ROWS_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, rowbase,
-                                                     reinterpret_cast<lb_word*>(row_status), sync,
+                                                     row_status, sync,
                                                      (long long)row_capacity, counters, status_dev);
 }
 

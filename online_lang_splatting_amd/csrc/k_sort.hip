@@ -8,8 +8,9 @@
 //   * the digit totals of ALL passes of a sort are counted up front in one read of the keys (sort_hist_kernel) —
 //     keys do not change between LSD passes, only their order does;
 //   * a block takes its chunk in TICKET order (dynamic block id from one atomic), counts its digits, PUBLISHES the
-//     counts (one 32-bit word per digit: bit 31 = ready, the data is the flag — no fence), and sums the counts of all
-//     its predecessors, spinning on the few that are not published yet.  A predecessor never waits for anything
+//     counts (one 16-bit word per digit: bit 15 = ready, the data is the flag — no fence), and sums the counts of all
+//     its predecessors — ONE batch of independent 16-byte loads per thread (eight digits each), spinning only on the
+//     few words that are not published yet: every dependent trip to the fabric costs ~2 us, so there is exactly one.  A predecessor never waits for anything
 //     before publishing and has already started (it holds an earlier ticket), so the wait is deadlock-free under any
 //     dispatch order.  This is the chained-scan idea of Onesweep without its serial look-back: on MI355X every
 //     block of a 500 k-key sort is resident at once, a look-back chain would be walked in lockstep, while summing
@@ -29,6 +30,7 @@ namespace olsr {
 constexpr u32 FS_READY = 0x80000000u;
 constexpr int FS_T = FUSED_SORT_THREADS;  // 1024
 constexpr int FS_W = FS_T / 64;           // 16 waves
+constexpr int FS_SPIN_LIMIT = 1 << 22;    // ~0.1 s of polling
 
 __device__ __forceinline__ int64_t fs_bounded_n(int64_t n_host, const int32_t* n_dev) {
   if (n_dev) {
@@ -60,11 +62,15 @@ __device__ __forceinline__ u32 fs_block_excl_scan(u32 v, u32* s_w) {
   return base + incl - v;
 }
 
-__device__ __forceinline__ u32 fs_load_status(const u32* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void fs_store_status(u32* p, u32 v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Published digit counts: one 16-bit word per digit (bit 15 = ready, count <= 8192 below), eight of them per 16-byte
+// granule.  Granules are written and read whole with agent-scope (sc1: write-through / L1-bypassing) accesses; every
+// 16-bit word carries its own ready bit, so a reader needs no ordering between them.
+typedef unsigned short u16;
+constexpr u32 FS_READY16 = 0x8000u;
+constexpr u32 FS_READY_PAIR = 0x80008000u;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool fs_granule_ready(const u32x4& v) {
+  return ((v.x & v.y & v.z & v.w) & FS_READY_PAIR) == FS_READY_PAIR;
 }
 
 // ---- digit totals of every pass of a sort, one read of the keys ---------------------------------------------
@@ -105,8 +111,19 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (i0 + j < n) {
-        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k[j] >> (db * p)) & mask], 1u);
+      const bool valid = i0 + j < n;
+      for (int p = 0; p < passes; ++p) {
+        const u32 dg = (k[j] >> (db * p)) & mask;
+        // the high digits of depth keys (sign, exponent) and of tile ids are nearly constant across a wave: 64 lanes
+        // on one LDS counter serialise, so a wave whose valid lanes all agree adds its population with one lane
+        const u64 vm = ballot(valid);
+        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)(valid ? dg : 0xFFFFu));
+        const bool uniform = vm != 0ull && ballot(valid && dg == d0) == vm;  // (d0 of an invalid lane matches nothing)
+        if (uniform) {
+          if (lane_id() == 0) atomicAdd(&h[p][d0], (u32)__popcll(vm));
+        } else if (valid) {
+          atomicAdd(&h[p][dg], 1u);
+        }
       }
     }
   }
@@ -159,37 +176,68 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
   }
 }
 
+// ---- optional phase timing (olsr_debug_sort_timing): block b of every pass launched while it is set records the
+// shader clock (s_memtime) at its phase boundaries into timing[(launch * max_blocks + b) * 8 + phase]
+struct SortTiming {
+  unsigned long long* buf = nullptr;
+  int max_blocks = 0, max_launches = 0, launch = 0;
+};
+static thread_local SortTiming g_timing;
+void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_launches) {
+  g_timing.buf = buf;
+  g_timing.max_blocks = max_blocks;
+  g_timing.max_launches = max_launches;
+  g_timing.launch = 0;
+}
+#define FS_STAMP(k)                                                                  \
+  do {                                                                               \
+    if (timing != nullptr && tid == 0) timing[(size_t)b * 8 + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
+
 // ---- one pass ---------------------------------------------------------------------------------------------
 // FLAGS (runtime, uniform): bit 0 = values are the identity (first tile-sort pass; also clears flags_clear[i]),
 // bit 1 = do not write the sorted keys (last pass of a sort), bit 2 = derive tile ranges (last tile-sort pass).
-constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4;
+// bit 3 = last depth pass: add every Gaussian's instance count (emit_rec[2 g + 1].w) to the total of the emission block
+// its final depth rank falls in (emit_totals[rank / EMIT_CHUNK]), so the emission needs no scan of its own.
+constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4, FSF_EMIT_TOTALS = 8, FSF_NO_TICKET = 16;
+constexpr int FS_ALWAYS_RESIDENT_BLOCKS = 256;  // one 1024-thread block per CU fits whatever its LDS size
 
 template <int DB, int KPT>
 __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__ keys_in,
                                                          const u32* __restrict__ vals_in, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int shift,
-                                                         const u32* __restrict__ ghist, u32* status, u32* ticket,
+                                                         const u32* __restrict__ ghist, u16* status, u32* ticket,
                                                          u32* __restrict__ keys_out, u32* __restrict__ vals_out,
-                                                         int fsf, uint8_t* __restrict__ flags_clear, u32* ranges) {
+                                                         int fsf, uint8_t* __restrict__ flags_clear, u32* ranges,
+                                                         const u32* __restrict__ inst_count, u32* emit_totals,
+                                                         unsigned long long* timing) {
   constexpr u32 NB = 1u << DB;
   constexpr u32 DMASK = NB - 1u;
   constexpr int CHUNK = FS_T * KPT;
-  constexpr int G = FS_T / (int)NB;  // predecessor rows read concurrently
-  constexpr int U = 8;               // ... times loads in flight per thread
+  constexpr int C = (int)NB / 8;   // 16-byte status granules per block row
+  constexpr int RPB = FS_T / C;    // predecessor rows read per batch (one granule per thread)
+  constexpr int U = 8;             // batches in flight per thread: one round covers 8 * RPB >= 256 predecessors
   extern __shared__ __attribute__((aligned(16))) u32 fs_smem[];
-  u32* cnt = fs_smem;              // [16][NB] per-wave digit counts -> per-wave local starts
+  u32* cnt = fs_smem;              // [16][NB] per-wave digit counts -> per-wave local starts; later the look-back partials
   u32* dstart = cnt + FS_W * NB;   // [NB + 1] local start of digit d inside the block (+ sentinel)
   u32* gbase = dstart + NB + 4;    // [NB] global start of this block's run of digit d
-  u32* part = gbase + NB;          // [G][NB] partial predecessor sums
-  u32* ex_key = part + FS_T;       // [CHUNK]
-  u32* ex_val = ex_key + CHUNK;    // [CHUNK]
+  u16* pub = reinterpret_cast<u16*>(gbase + NB);  // [NB] this block's published row (16-byte aligned)
+  u32* ex_key = gbase + NB + NB / 2;  // [CHUNK]
+  u32* ex_val = ex_key + CHUNK;       // [CHUNK]
   __shared__ u32 s_bid;
   __shared__ u32 s_w[FS_W];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) s_bid = atomicAdd(ticket, 1u);
+  // chunk index: the launch order (blockIdx) when the whole grid is resident at once (at most one block per CU: a
+  // spinning block then never keeps a predecessor from starting), else a ticket
+  if (tid == 0) s_bid = (fsf & FSF_NO_TICKET) ? blockIdx.x : atomicAdd(ticket, 1u);
   for (u32 i = tid; i < FS_W * NB; i += FS_T) cnt[i] = 0;
   __syncthreads();
   const u32 b = s_bid;
+  FS_STAMP(0);
+  if (timing != nullptr && tid == 0) {
+    timing[(size_t)b * 8 + 6] = (unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15);  // HW_REG_XCC_ID
+    timing[(size_t)b * 8 + 7] = (unsigned long long)blockIdx.x;
+  }
   const int64_t n = fs_bounded_n(n_host, n_dev);
   const int64_t bbase = (int64_t)b * CHUNK;
   if (bbase >= n) return;  // (an empty block has only empty successors: nobody waits for it)
@@ -206,6 +254,7 @@ __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__
     if ((fsf & FSF_IDENTITY) && valid) flags_clear[i] = 0;
   }
   __syncthreads();
+  FS_STAMP(1);
 
   // thread d owns digit d: counts of the 16 waves -> block total (published) and per-wave starts
   const u32 d = (u32)tid;
@@ -217,9 +266,15 @@ __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__
       c[i] = cnt[i * NB + d];
       tot += c[i];
     }
-    fs_store_status(&status[(size_t)b * NB + d], FS_READY | tot);
+    pub[d] = (u16)(FS_READY16 | tot);
   }
   const u32 start = fs_block_excl_scan(d < NB ? tot : 0u, s_w);
+  // publish this block's row: NB / 8 granules of eight 16-bit counts, write-through (sc1)
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)(gridDim.x * NB * 2u), 0x00020000);
+  if (tid < C) {
+    const u32x4 g4 = *reinterpret_cast<const u32x4*>(pub + 8 * tid);
+    __builtin_amdgcn_raw_buffer_store_b128(g4, rsrc, (int)((b * NB + 8u * (u32)tid) * 2u), 0, /*sc1*/ 16);
+  }
   const u32 gdig = fs_block_excl_scan(d < NB ? ghist[d] : 0u, s_w);
   if (d < NB) {
     dstart[d] = start;
@@ -231,64 +286,93 @@ __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__
     }
     if (d == NB - 1) dstart[NB] = run;
   }
-  // counts of all predecessors: G rows at a time, U loads in flight per thread, spinning only on unpublished words
+  __syncthreads();
+  FS_STAMP(2);
+
+  // rank: wave w walks its 64 * KPT consecutive keys in KPT rounds of 64; inside a round the rank among equal
+  // digits comes from ballots, the running per-wave start from LDS -> order inside the block = ascending input index.
+  // (Done BEFORE the look-back: it needs nothing from other blocks, and meanwhile their counts become visible — a
+  // look-back issued right after the publish finds nothing ready and thousands of polling waves slow every publish.)
   {
-    const u32 dd = (u32)tid & DMASK, g = (u32)tid >> DB;
-    u32 sum = 0;
-    for (u32 bp0 = g; bp0 < b; bp0 += G * U) {
-      u32 s[U];
+    volatile u32* my = cnt + w * NB;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+      const int64_t i = wbase + r * 64 + lane;
+      const bool valid = i < n;
+      const u32 dg = (key[r] >> shift) & DMASK;
+      u64 peers = ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < DB; ++bit) {
+        const bool one = (dg >> bit) & 1u;
+        const u64 bm = ballot(one);
+        peers &= one ? bm : ~bm;
+      }
+      if (valid) {
+        const u32 rank = (u32)__popcll(peers & lt_mask);
+        const u32 st0 = my[dg];
+        if (rank == 0) my[dg] = st0 + (u32)__popcll(peers);
+        ex_key[st0 + rank] = key[r];
+        ex_val[st0 + rank] = val[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  FS_STAMP(3);
+
+  // counts of all predecessors: every thread owns one granule column (8 digits) of RPB-strided rows; U independent
+  // 16-byte loads in flight, spinning only on granules that are not fully published yet
+  {
+    const int gc = tid % C, rsub = tid / C;
+    u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    for (u32 bp0 = 0; bp0 < b; bp0 += RPB * U) {
+      u32x4 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const u32 bp = bp0 + (u32)u * G;
-        s[u] = (bp < b) ? fs_load_status(&status[(size_t)bp * NB + dd]) : FS_READY;
+        const u32 row = bp0 + (u32)rsub + (u32)u * RPB;
+        v[u] = u32x4{FS_READY_PAIR, FS_READY_PAIR, FS_READY_PAIR, FS_READY_PAIR};  // (beyond b: ready, zero counts)
+        if (row < b) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((row * NB + 8u * (u32)gc) * 2u), 0, 16);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const u32 bp = bp0 + (u32)u * G;
-        while (!(s[u] & FS_READY)) {
-          __builtin_amdgcn_s_sleep(1);
-          s[u] = fs_load_status(&status[(size_t)bp * NB + dd]);
+        const u32 row = bp0 + (u32)rsub + (u32)u * RPB;
+        // (bounded: a predecessor publishes within microseconds; a corrupted state buffer must not hang the GPU)
+        for (int spin = 0; !fs_granule_ready(v[u]) && spin < FS_SPIN_LIMIT; ++spin) {
+          __builtin_amdgcn_s_sleep(4);
+          v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((row * NB + 8u * (u32)gc) * 2u), 0, 16);
         }
-        sum += s[u] & ~FS_READY;
+        acc[0] += v[u].x & 0x7FFFu;
+        acc[1] += (v[u].x >> 16) & 0x7FFFu;
+        acc[2] += v[u].y & 0x7FFFu;
+        acc[3] += (v[u].y >> 16) & 0x7FFFu;
+        acc[4] += v[u].z & 0x7FFFu;
+        acc[5] += (v[u].z >> 16) & 0x7FFFu;
+        acc[6] += v[u].w & 0x7FFFu;
+        acc[7] += (v[u].w >> 16) & 0x7FFFu;
       }
     }
-    part[g * NB + dd] = sum;
+    // lanes of a wave that own the same granule column differ in the lane bits >= log2(C): fold them, then the lanes
+    // < C hold the wave's partial sums of their eight digits (cnt is dead after the ranking: reused as [16][NB])
+#pragma unroll
+    for (int m = C; m < 64; m <<= 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], m);
+    }
+    if (lane < C) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cnt[w * NB + lane * 8 + i] = acc[i];
+    }
   }
   __syncthreads();
   if (d < NB) {
     u32 pred = 0;
 #pragma unroll
-    for (int q = 0; q < G; ++q) pred += part[q * NB + d];
+    for (int i = 0; i < FS_W; ++i) pred += cnt[i * NB + d];
     gbase[d] = gdig + pred;
   }
   __syncthreads();
-
-  // rank: wave w walks its 64 * KPT consecutive keys in KPT rounds of 64; inside a round the rank among equal
-  // digits comes from ballots, the running per-wave start from LDS -> order inside the block = ascending input index
-  volatile u32* my = cnt + w * NB;
-  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-  for (int r = 0; r < KPT; ++r) {
-    const int64_t i = wbase + r * 64 + lane;
-    const bool valid = i < n;
-    const u32 dg = (key[r] >> shift) & DMASK;
-    u64 peers = ballot(valid);
-#pragma unroll
-    for (int bit = 0; bit < DB; ++bit) {
-      const bool one = (dg >> bit) & 1u;
-      const u64 bm = ballot(one);
-      peers &= one ? bm : ~bm;
-    }
-    if (valid) {
-      const u32 rank = (u32)__popcll(peers & lt_mask);
-      const u32 st0 = my[dg];
-      if (rank == 0) my[dg] = st0 + (u32)__popcll(peers);
-      ex_key[st0 + rank] = key[r];
-      ex_val[st0 + rank] = val[r];
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
+  FS_STAMP(4);
 
   const int64_t rem = n - bbase;
   const u32 nvalid = rem >= CHUNK ? (u32)CHUNK : (u32)rem;
@@ -301,7 +385,29 @@ __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__
       const u32 ds = dstart[dg];
       const u32 pos = gbase[dg] + (slot - ds);
       if (!(fsf & FSF_NO_KEYS)) keys_out[pos] = kk;
-      vals_out[pos] = ex_val[slot];
+      const u32 vv = ex_val[slot];
+      vals_out[pos] = vv;
+      if (fsf & FSF_EMIT_TOTALS) {
+        // pos is the Gaussian's final depth rank.  Lanes are consecutive slots: runs of consecutive ranks, so the
+        // emission block (rank / 1024) is piecewise constant across the wave — a segmented scan, and only the last
+        // lane of every piece adds its piece's sum: one to three atomics per wave instead of 64.
+        const u32 cntg = inst_count[vv];  // (P x 4 bytes: stays in L2, unlike the 32-byte emission records)
+        const u32 bucket = pos / (u32)EMIT_CHUNK;
+        u32 run = cntg;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+          const u32 o = __shfl_up(run, sft);
+          const u32 ob = __shfl_up(bucket, sft);
+          if (lane >= sft && ob == bucket) run += o;
+        }
+        // (a piece longer than the shift distance is covered because pieces are contiguous: equality with the lane
+        //  sft below implies equality with every lane in between)
+        const u32 nb_ = __shfl_down(bucket, 1);
+        const u64 act = ballot(true);  // (evaluated by every active lane: NOT inside the short-circuit below)
+        const bool next_active = (act >> ((lane + 1) & 63)) & 1ull;
+        const bool last = (lane == 63) || !next_active || nb_ != bucket;
+        if (last && run) atomicAdd(&emit_totals[bucket], run);
+      }
       if (fsf & FSF_RANGES) {
         // After the last pass equal keys (tile ids) are contiguous, and inside one digit's run of this block the
         // keys ascend (the input was sorted by the lower digits).  A tile's range starts where the key changes;
@@ -314,32 +420,50 @@ __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__
       }
     }
   }
+  FS_STAMP(5);
 }
 
+struct PassArgs {
+  const u32 *kin, *vin;
+  int64_t n_host;
+  const int32_t* n_dev;
+  int shift;
+  const u32* ghist;
+  u16* status;
+  u32* ticket;
+  u32 *kout, *vout;
+  int fsf;
+  uint8_t* flags;
+  u32* ranges;
+  const u32* inst_count;
+  u32* emit_totals;
+  int nblk;
+};
+
 template <int DB, int KPT>
-static void launch_pass_t(const u32* kin, const u32* vin, int64_t n_host, const int32_t* n_dev, int shift,
-                          const u32* ghist, u32* status, u32* ticket, u32* kout, u32* vout, int fsf, uint8_t* flags,
-                          u32* ranges, int nblk, hipStream_t st) {
+static void launch_pass_t(const PassArgs& a, hipStream_t st) {
   constexpr size_t NB = 1u << DB;
-  constexpr size_t smem = sizeof(u32) * (FS_W * NB + NB + 4 + NB + FS_T + 2 * (size_t)FS_T * KPT);
+  constexpr size_t smem = sizeof(u32) * (FS_W * NB + NB + 4 + NB + NB / 2 + 2 * (size_t)FS_T * KPT);
   static bool attr_set = false;  // (per instantiation) blocks above 64 KB of LDS need the opt-in
   if (!attr_set && smem > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_pass_kernel<DB, KPT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  sort_pass_kernel<DB, KPT><<<nblk, FS_T, smem, st>>>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout,
-                                                      vout, fsf, flags, ranges);
+  unsigned long long* timing = nullptr;
+  if (g_timing.buf && g_timing.launch < g_timing.max_launches && a.nblk <= g_timing.max_blocks)
+    timing = g_timing.buf + (size_t)(g_timing.launch++) * g_timing.max_blocks * 8;
+  sort_pass_kernel<DB, KPT><<<a.nblk, FS_T, smem, st>>>(a.kin, a.vin, a.n_host, a.n_dev, a.shift, a.ghist, a.status,
+                                                        a.ticket, a.kout, a.vout, a.fsf, a.flags, a.ranges,
+                                                        a.inst_count, a.emit_totals, timing);
 }
 
 template <int DB>
-static void launch_pass_k(int kpt, const u32* kin, const u32* vin, int64_t n_host, const int32_t* n_dev, int shift,
-                          const u32* ghist, u32* status, u32* ticket, u32* kout, u32* vout, int fsf, uint8_t* flags,
-                          u32* ranges, int nblk, hipStream_t st) {
+static void launch_pass_k(int kpt, const PassArgs& a, hipStream_t st) {
   switch (kpt) {
-    case 2: launch_pass_t<DB, 2>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout, vout, fsf, flags, ranges, nblk, st); break;
-    case 4: launch_pass_t<DB, 4>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout, vout, fsf, flags, ranges, nblk, st); break;
-    default: launch_pass_t<DB, 8>(kin, vin, n_host, n_dev, shift, ghist, status, ticket, kout, vout, fsf, flags, ranges, nblk, st); break;
+    case 2: launch_pass_t<DB, 2>(a, st); break;
+    case 4: launch_pass_t<DB, 4>(a, st); break;
+    default: launch_pass_t<DB, 8>(a, st); break;
   }
 }
 
@@ -370,9 +494,10 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
     h.ranges = house->ranges;
     h.nranges = house->nranges;
   }
-  int64_t nb = (n_host + (int64_t)FS_T * 16 - 1) / ((int64_t)FS_T * 16);  // ~16 keys per thread
+  int64_t nb = (n_host + (int64_t)FS_T * 4 - 1) / ((int64_t)FS_T * 4);  // 4 keys (one 16-byte load) per thread ...
   if (nb < 1) nb = 1;
-  if (nb > 512) nb = 512;
+  if (nb > 128) nb = 128;  // ... then a grid-stride loop: every block ends with one global atomic per non-empty bin,
+                           // and same-address atomics serialise (~10-20 ns each), so few, fat blocks
   sort_hist_kernel<<<(int)nb, FS_T, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0);
 }
 
@@ -380,7 +505,7 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
 // zeroed and hist filled by launch_sort_hist.  Returns 0 if the result ends in (key_a, val_a), 1 if in (key_b, val_b).
 int launch_sort_fused(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
                       const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
-                      hipStream_t st) {
+                      const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st) {
   if (n_host <= 0) return 0;
   int passes;
   const int db = fused_sort_digit_bits(bits, &passes);
@@ -391,18 +516,19 @@ int launch_sort_fused(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
   for (int p = 0; p < passes; ++p) {
     int fsf = 0;
     if (p == 0 && vals_in_identity) fsf |= FSF_IDENTITY;
-    if (p == passes - 1) fsf |= FSF_NO_KEYS | (ranges ? FSF_RANGES : 0);
-    u32* stat = status + (size_t)p * plan.nblk * NB;
-#define OLSR_PASS(DBV)                                                                                                \
-  case DBV:                                                                                                           \
-    launch_pass_k<DBV>(plan.kpt, kin, vin, n_host, n_dev, db * p, hist + 256 * p, stat, tickets + p, kout, vout, fsf, \
-                       flags_clear, ranges, plan.nblk, st);                                                           \
-    break;
+    if (p == passes - 1) fsf |= FSF_NO_KEYS | (ranges ? FSF_RANGES : 0) | (emit_totals ? FSF_EMIT_TOTALS : 0);
+    if (plan.nblk <= FS_ALWAYS_RESIDENT_BLOCKS) fsf |= FSF_NO_TICKET;
+    PassArgs a{kin, vin, n_host, n_dev, db * p, hist + 256 * p,
+               reinterpret_cast<u16*>(status) + (size_t)p * plan.nblk * NB, tickets + p, kout, vout, fsf, flags_clear,
+               ranges, inst_count, emit_totals, plan.nblk};
     switch (db) {
-      OLSR_PASS(4) OLSR_PASS(5) OLSR_PASS(6) OLSR_PASS(7) OLSR_PASS(8)
+      case 4: launch_pass_k<4>(plan.kpt, a, st); break;
+      case 5: launch_pass_k<5>(plan.kpt, a, st); break;
+      case 6: launch_pass_k<6>(plan.kpt, a, st); break;
+      case 7: launch_pass_k<7>(plan.kpt, a, st); break;
+      case 8: launch_pass_k<8>(plan.kpt, a, st); break;
       default: break;
     }
-#undef OLSR_PASS
     u32* t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
     where ^= 1;

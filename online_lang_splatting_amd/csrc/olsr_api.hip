@@ -191,10 +191,14 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       HIP_TRY(hipEventRecord(g_pinned.ev, st));
     }
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
-    if (!legacy && fused_sort_applicable(s.P, 32))
-      launch_sort_fused(sb, s.P, nullptr, 32, false, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr, st);
-    else
+    // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
+    if (!legacy && fused_sort_applicable(s.P, 32)) {
+      launch_sort_fused(sb, s.P, nullptr, 32, false, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
+                        g.tiles_touched, g.emit_status, st);
+    } else {
       launch_radix_sort(sb, s.P, nullptr, 32, false, st);
+      launch_emit_totals(g.depth_order, s.P, g.emit_rec, g.emit_status, st);
+    }
     STAGE("depth_sort");
   }
 
@@ -228,7 +232,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     // synchronisation words of the binning buffer that this frame uses (zeroed by the emission kernel)
     const int64_t bin_sync_words =
         (b.tile_status - b.sync_words) +
-        (fused_tiles ? (int64_t)tpasses * sort_plan(n_host).nblk * ((int64_t)1 << tdb) : 0);
+        (fused_tiles ? ((int64_t)tpasses * sort_plan(n_host).nblk * ((int64_t)1 << tdb) + 1) / 2 : 0);  // 16-bit words
     launch_emit(s, d, g, b, bin_sync_words, st);
     STAGE("emit");
     if (n_host > 0) {
@@ -238,7 +242,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       if (fused_tiles) {
         launch_sort_hist(b.key_a, n_host, n_dev, tbits, b.tile_hist, nullptr, st);
         // the first pass also clears the liveness flags, the last one derives the tile ranges
-        launch_sort_fused(sb, n_host, n_dev, tbits, true, b.tile_hist, b.tile_status, b.tickets, b.flags, im.ranges, st);
+        launch_sort_fused(sb, n_host, n_dev, tbits, true, b.tile_hist, b.tile_status, b.tickets, b.flags, im.ranges,
+                          nullptr, nullptr, st);
       } else {
         const int where = launch_radix_sort(sb, n_host, n_dev, tbits, true, st);
         launch_tile_ranges(where ? b.key_b : b.key_a, n_host, n_dev, im.ranges, b.flags, st);
@@ -510,6 +515,8 @@ const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t 
   if (!std::strcmp(name, "tiles_touched")) return g.tiles_touched;
   if (!std::strcmp(name, "depth_order")) return g.depth_order;
   if (!std::strcmp(name, "counters")) return g.counters;
+  if (!std::strcmp(name, "emit_totals")) return g.emit_status;
+  if (!std::strcmp(name, "inst_start")) return g.inst_start;
   return nullptr;
 }
 
@@ -556,6 +563,10 @@ int olsr_get_stage_times(const char** names, float* ms, int max) {
     ++n;
   }
   return n;
+}
+
+void olsr_debug_sort_timing(unsigned long long* device_buffer, int max_blocks, int max_launches) {
+  debug_set_sort_timing(device_buffer, max_blocks, max_launches);
 }
 
 const char* olsr_last_error(void) { return g_err.c_str(); }

@@ -44,7 +44,7 @@ inline SortPlan sort_plan(long long n) {
 }
 inline size_t fused_status_words(long long n, int passes) {
   const SortPlan p = sort_plan(n);
-  return (p.nblk <= FUSED_SORT_MAX_BLOCKS) ? (size_t)passes * (size_t)p.nblk * 256 : 0;
+  return (p.nblk <= FUSED_SORT_MAX_BLOCKS) ? (size_t)passes * (size_t)p.nblk * 128 : 0;  // 256 16-bit counts per row
 }
 // single-pass scans (emission offsets, row compaction): elements per 1024-thread block
 constexpr int EMIT_CHUNK = 1024;

@@ -35,9 +35,9 @@ def test_single_process_line():
     assert cpu["checked_against_gpu"]["ok"], cpu["checked_against_gpu"]   # the CPU timed the frame the GPU rendered
     assert cpu["single_thread"]["cores"] == 1 and cpu["single_thread"]["value"] > 0
     assert d["isolated"]["frames_in_flight_per_gpu"] == 1
-    for leg in (d["latency_ms"], d["isolated"]["latency_ms"]):
-        q = leg["step_completion_interval_ms"]
-        assert q["p10"] <= q["median"] <= q["p90"] and q["n"] >= 1
+    q = d["isolated"]["latency_ms"]["step_completion_interval_ms"]
+    assert q["p10"] <= q["median"] <= q["p90"] and q["n"] >= 1
+    assert d["isolated"]["stage_ms"]["render_backward"] > 0
 
 
 def test_two_ranks_frame_sharded_over_gloo():
