@@ -22,6 +22,9 @@
 //     consecutive lanes -> coalesced stores.
 // The last tile-sort pass also derives the per-tile ranges (identifyTileRanges, CR/rasterizer_impl.cu:116-138) and
 // skips the sorted keys nobody reads; the first one clears the liveness flags of the frame's instances.
+#include <cstdio>
+#include <cstdlib>
+
 #include "olsr_device.h"
 #include "olsr_kernels.h"
 
@@ -100,29 +103,38 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
   const int64_t n = fs_bounded_n(n_host, n_dev);
   const u32 mask = (1u << db) - 1u;
   const int64_t stride = (int64_t)gridDim.x * FS_T * 4;
-  for (int64_t i0 = ((int64_t)blockIdx.x * FS_T + tid) * 4; i0 < n; i0 += stride) {
-    u32 k[4];
-    if (i0 + 4 <= n) {
-      const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
-      k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
-    } else {
+  constexpr int HU = 4;  // independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
+  for (int64_t i00 = ((int64_t)blockIdx.x * FS_T + tid) * 4; i00 < n; i00 += stride * HU) {
+    u32 k[HU][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k[j] = (i0 + j < n) ? keys[i0 + j] : 0u;
+    for (int u = 0; u < HU; ++u) {
+      const int64_t i0 = i00 + (int64_t)u * stride;
+      if (i0 + 4 <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
+        k[u][0] = q.x; k[u][1] = q.y; k[u][2] = q.z; k[u][3] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[u][j] = (i0 + j < n) ? keys[i0 + j] : 0u;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool valid = i0 + j < n;
-      for (int p = 0; p < passes; ++p) {
-        const u32 dg = (k[j] >> (db * p)) & mask;
-        // the high digits of depth keys (sign, exponent) and of tile ids are nearly constant across a wave: 64 lanes
-        // on one LDS counter serialise, so a wave whose valid lanes all agree adds its population with one lane
-        const u64 vm = ballot(valid);
-        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)(valid ? dg : 0xFFFFu));
-        const bool uniform = vm != 0ull && ballot(valid && dg == d0) == vm;  // (d0 of an invalid lane matches nothing)
-        if (uniform) {
-          if (lane_id() == 0) atomicAdd(&h[p][d0], (u32)__popcll(vm));
-        } else if (valid) {
-          atomicAdd(&h[p][dg], 1u);
+    for (int u = 0; u < HU; ++u) {
+      const int64_t i0 = i00 + (int64_t)u * stride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool valid = i0 + j < n;
+        for (int p = 0; p < passes; ++p) {
+          const u32 dg = (k[u][j] >> (db * p)) & mask;
+          // the high digits of depth keys (sign, exponent) and of tile ids are nearly constant across a wave: 64
+          // lanes on one LDS counter serialise, so a wave whose valid lanes all agree adds its population with one lane
+          const u64 vm = ballot(valid);
+          const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)(valid ? dg : 0xFFFFu));
+          const bool uniform = vm != 0ull && ballot(valid && dg == d0) == vm;  // (d0 of an invalid lane matches nothing)
+          if (uniform) {
+            if (lane_id() == (int)__builtin_ctzll(vm)) atomicAdd(&h[p][d0], (u32)__popcll(vm));
+          } else if (valid) {
+            atomicAdd(&h[p][dg], 1u);
+          }
         }
       }
     }
@@ -393,20 +405,29 @@ __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__
         // lane of every piece adds its piece's sum: one to three atomics per wave instead of 64.
         const u32 cntg = inst_count[vv];  // (P x 4 bytes: stays in L2, unlike the 32-byte emission records)
         const u32 bucket = pos / (u32)EMIT_CHUNK;
-        u32 run = cntg;
+        const u64 act = ballot(true);  // (evaluated by every active lane)
+        const u32 b0 = (u32)__builtin_amdgcn_readfirstlane((int)bucket);
+        if (act == ~0ull && ballot(bucket != b0) == 0ull) {
+          // the common case: a full wave inside one emission block — a plain wave sum
+          u32 t = cntg;
 #pragma unroll
-        for (int sft = 1; sft < 64; sft <<= 1) {
-          const u32 o = __shfl_up(run, sft);
-          const u32 ob = __shfl_up(bucket, sft);
-          if (lane >= sft && ob == bucket) run += o;
+          for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+          if (lane == 0 && t) atomicAdd(&emit_totals[b0], t);
+        } else {
+          u32 run = cntg;
+#pragma unroll
+          for (int sft = 1; sft < 64; sft <<= 1) {
+            const u32 o = __shfl_up(run, sft);
+            const u32 ob = __shfl_up(bucket, sft);
+            if (lane >= sft && ob == bucket) run += o;
+          }
+          // (a piece longer than the shift distance is covered because pieces are contiguous: equality with the lane
+          //  sft below implies equality with every lane in between)
+          const u32 nb_ = __shfl_down(bucket, 1);
+          const bool next_active = (act >> ((lane + 1) & 63)) & 1ull;
+          const bool last = (lane == 63) || !next_active || nb_ != bucket;
+          if (last && run) atomicAdd(&emit_totals[bucket], run);
         }
-        // (a piece longer than the shift distance is covered because pieces are contiguous: equality with the lane
-        //  sft below implies equality with every lane in between)
-        const u32 nb_ = __shfl_down(bucket, 1);
-        const u64 act = ballot(true);  // (evaluated by every active lane: NOT inside the short-circuit below)
-        const bool next_active = (act >> ((lane + 1) & 63)) & 1ull;
-        const bool last = (lane == 63) || !next_active || nb_ != bucket;
-        if (last && run) atomicAdd(&emit_totals[bucket], run);
       }
       if (fsf & FSF_RANGES) {
         // After the last pass equal keys (tile ids) are contiguous, and inside one digit's run of this block the
@@ -449,6 +470,14 @@ static void launch_pass_t(const PassArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_pass_kernel<DB, KPT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
+  }
+  static bool printed = false;
+  if (!printed && std::getenv("OLSR_SORT_DEBUG")) {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sort_pass_kernel<DB, KPT>, FS_T, smem);
+    std::fprintf(stderr, "[olsr] sort_pass_kernel<%d,%d>: %zu B dynamic LDS, occupancy API: %d blocks/CU, grid %d\n", DB, KPT,
+                 smem, nb, a.nblk);
+    printed = true;
   }
   unsigned long long* timing = nullptr;
   if (g_timing.buf && g_timing.launch < g_timing.max_launches && a.nblk <= g_timing.max_blocks)

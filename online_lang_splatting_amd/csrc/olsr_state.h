@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <cstdlib>
 
 namespace olsr {
 
@@ -37,9 +38,17 @@ struct SortPlan {
 };
 constexpr int FUSED_SORT_THREADS = 1024;
 constexpr int FUSED_SORT_MAX_BLOCKS = 4096;  // beyond: the multi-kernel passes (histogram, device-wide scan, scatter)
+inline int sort_plan_max_blocks() {  // (OLSR_SORT_MAX_BLOCKS: tuning experiments only)
+  static const int v = [] {
+    const char* e = std::getenv("OLSR_SORT_MAX_BLOCKS");
+    const int x = e ? std::atoi(e) : 0;
+    return x > 0 ? x : 512;
+  }();
+  return v;
+}
 inline SortPlan sort_plan(long long n) {
   int kpt = 2;
-  while (kpt < 8 && (n + 1024LL * kpt - 1) / (1024LL * kpt) > 512) kpt *= 2;
+  while (kpt < 8 && (n + 1024LL * kpt - 1) / (1024LL * kpt) > sort_plan_max_blocks()) kpt *= 2;
   return SortPlan{kpt, (int)((n + 1024LL * kpt - 1) / (1024LL * kpt))};
 }
 inline size_t fused_status_words(long long n, int passes) {

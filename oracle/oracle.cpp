@@ -95,6 +95,10 @@ const float SH_C3[] = {-0.5900435899266435f, 2.890611442640554f, -0.457045799464
 static inline float bits2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline uint32_t f2bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static float oracle_expf(float x) {
+#ifdef ORACLE_LIBM_EXP
+  // sensitivity variant (scripts/cuda_sensitivity.py): the host libm instead of the pinned routine
+  return std::exp(x);
+#endif
   x = (x < -87.0f) ? -87.0f : x;
   x = (x > 88.0f) ? 88.0f : x;
   float n = std::nearbyintf(x * 1.44269504088896341f);  // round-half-even
@@ -156,6 +160,8 @@ struct State {
   std::vector<uint32_t> n_contrib;
   // backward internals (kept for inspection)
   std::vector<float> dL_dconic, dL_ddepths;
+  // optional (oracle_set_record): per sorted list position, which thread ranks of its tile blended it (256 bits)
+  std::vector<uint32_t> contrib_mask;
 };
 
 // ------------------------------------------------------------------ forward: preprocess
@@ -365,8 +371,10 @@ static void bin_and_sort(const olsr_scene& s, State& st, const int* radii) {
 // One tile at a time; each "thread" is a pixel of the tile.  The batch structure of the
 // reference (collective fetch of BLOCK_SIZE entries, tile-wide early exit) does not
 // change any per-pixel value, so pixels simply walk the tile's list.
+static bool g_record_contrib = false;
 static void render_forward(const olsr_scene& s, State& st, float* out_color, float* out_lang,
                            float* out_depth, float* out_opacity, int* n_touched) {
+  if (g_record_contrib) st.contrib_mask.assign((size_t)st.R * 8, 0u); else st.contrib_mask.clear();
   const int W = s.width, H = s.height, F = s.F, tile = s.tile;
   const float* features = s.colors_precomp ? s.colors_precomp : st.rgb.data();
   const float* lang = s.language_precomp;
@@ -406,6 +414,10 @@ static void render_forward(const olsr_scene& s, State& st, float* out_color, flo
           for (int ch = 0; ch < 3; ch++) C[ch] = std::fmaf(features[(size_t)id * 3 + ch] * alpha, T, C[ch]);
           for (int ch = 0; ch < F; ch++) L[ch] = std::fmaf(lang[(size_t)id * F + ch] * alpha, T, L[ch]);
           D = std::fmaf(st.depths[id] * alpha, T, D);
+          if (g_record_contrib) {  // (each list position belongs to one tile, each tile to one OpenMP thread)
+            const int rank = ty * tile + tx;
+            st.contrib_mask[(size_t)k * 8 + (rank >> 5)] |= 1u << (rank & 31);
+          }
           if (test_T > 0.5f) {
 #pragma omp atomic
             n_touched[id] += 1;
@@ -1049,12 +1061,24 @@ int64_t oracle_get_field(void* h, const char* name, void* dst) {
   if (!std::strcmp(name, "ranges")) return cp(st.ranges.data(), st.ranges.size(), 4);
   if (!std::strcmp(name, "final_T")) return cp(st.final_T.data(), st.final_T.size(), 4);
   if (!std::strcmp(name, "n_contrib")) return cp(st.n_contrib.data(), st.n_contrib.size(), 4);
+  if (!std::strcmp(name, "contrib_mask")) return cp(st.contrib_mask.data(), st.contrib_mask.size(), 4);
   return -1;
 }
 
 float oracle_expf_probe(float x) { return oracle_expf(x); }
 
 // OpenMP team size of the following calls (bench.py's cpu_baseline: all host cores, and one thread)
+// record, per sorted list position, the 256-bit mask of tile thread ranks that blended it (sensitivity studies)
+void oracle_set_record(int on) { g_record_contrib = on != 0; }
+const char* oracle_variant() {
+#if defined(ORACLE_LIBM_EXP)
+  return "libm_exp";
+#elif defined(ORACLE_CONTRACT_FAST)
+  return "contract_fast";
+#else
+  return "default";
+#endif
+}
 void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 int oracle_get_threads() { return omp_get_max_threads(); }
 

@@ -38,11 +38,29 @@ def build(force=False):
     return so
 
 
+_variant = "default"
+
+
+def use_variant(name):
+    """Switch the library behind this module: "default" (the parity oracle), "libm_exp" or "contract_fast"
+    (sensitivity variants built by `make -C oracle variants`; scripts/cuda_sensitivity.py only)."""
+    global _lib, _variant
+    assert name in ("default", "libm_exp", "contract_fast"), name
+    if name != _variant:
+        _states.clear()
+        _lib, _variant = None, name
+
+
 def lib():
     global _lib
     if _lib is None:
         so = build()
+        if _variant != "default":
+            subprocess.check_call(["make", "-C", _HERE, "-s", "variants"])
+            so = os.path.join(_HERE, {"libm_exp": "liboracle_libmexp.so", "contract_fast": "liboracle_contract.so"}[_variant])
         L = C.CDLL(so)
+        L.oracle_set_record.argtypes = [C.c_int]
+        L.oracle_variant.restype = C.c_char_p
         L.oracle_create.restype = C.c_void_p
         L.oracle_destroy.argtypes = [C.c_void_p]
         vp = C.c_void_p
@@ -142,7 +160,8 @@ def release(geomBuffer):
 
 
 _FIELD_DT = {"clamped": torch.uint8, "tiles_touched": torch.int32, "point_offsets": torch.int32,
-             "point_list": torch.int32, "keys": torch.int64, "ranges": torch.int32, "n_contrib": torch.int32}
+             "point_list": torch.int32, "keys": torch.int64, "ranges": torch.int32, "n_contrib": torch.int32,
+             "contrib_mask": torch.int32}
 
 
 def get_field(geomBuffer, name):

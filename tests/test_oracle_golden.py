@@ -129,3 +129,58 @@ def test_oracle_sort_order_and_ranges(oracle):
     counts = torch.bincount(tiles, minlength=rg.shape[0])
     assert torch.equal(counts, lens)
     oracle.release(geom)
+
+
+GEO = np.load(os.path.join(os.path.dirname(__file__), "golden", "geometry.npz"))
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_oracle_cov3d_matches_reference_build_scaling_rotation(oracle, k):
+    """computeCov3D (CR/forward.cu:121-155) as restated by the oracle == strip_symmetric(L L^T) with
+    L = build_scaling_rotation(modifier * scaling, rotation) of the reference's general_utils.py:97-149 (the
+    composition of GaussianModel.build_covariance_from_scaling_rotation), for three scale modifiers."""
+    scales, rot = torch.tensor(GEO["cov_scales"]), torch.tensor(GEO["cov_rotations"])
+    P = scales.shape[0]
+    sc = S.make_scene(P, 96, 96, 0, seed=3)
+    # every Gaussian in front of the camera, inside the frustum, so preprocess reaches computeCov3D for all of them
+    g = torch.Generator().manual_seed(1)
+    z = torch.rand(P, generator=g) * 3.0 + 1.0
+    sc.means3D = torch.stack([(torch.rand(P, generator=g) - 0.5) * z, (torch.rand(P, generator=g) - 0.5) * z, z], 1).contiguous()
+    sc.scales, sc.rotations = scales.contiguous(), rot.contiguous()
+    oracle.TILE = 15
+    r = oracle.rasterize_gaussians(*fwd_args(sc, scale_modifier=float(GEO[f"cov3D_modifier{k}"])))
+    radii, geom = r[2], r[3]
+    cov = oracle.get_field(geom, "cov3D").view(P, 6)
+    oracle.release(geom)
+    vis = radii > 0
+    assert int(vis.sum()) > P // 2
+    ref = torch.tensor(GEO[f"cov3D_mod{k}"])
+    # off-diagonal entries cancel: compare relative to the covariance's own scale (its largest entry)
+    scale = ref[vis].abs().max(dim=1, keepdim=True).values
+    assert float(((cov[vis] - ref[vis]).abs() / scale).max()) <= 2e-6
+
+
+def test_oracle_projection_matches_reference_camera_matrices(oracle):
+    """means2D / depths of the oracle's preprocess (CR/forward.cu:300-303,343; ndc2Pix CR/auxiliary.h:41-44) == the
+    points multiplied, in float64, with the matrices the reference's Camera hands to the rasterizer."""
+    for i in range(int(GEO["num_proj"])):
+        W, H, fx, fy, cx, cy = GEO[f"proj{i}_spec"]
+        cam = S.Camera(int(W), int(H), fx, fy, cx, cy, torch.tensor(GEO[f"proj{i}_R"]), torch.tensor(GEO[f"proj{i}_T"]))
+        np.testing.assert_allclose(cam.world_view_transform.numpy(), GEO[f"proj{i}_viewmatrix"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(cam.full_proj_transform.numpy(), GEO[f"proj{i}_projmatrix"], rtol=1e-5, atol=1e-6)
+        pts = torch.tensor(GEO[f"proj{i}_points"])
+        N = pts.shape[0]
+        sc = S.make_scene(N, int(W), int(H), 0, seed=4, camera=cam)
+        sc.means3D = pts.contiguous()
+        sc.scales = torch.full((N, 3), 0.02)
+        oracle.TILE = 15
+        r = oracle.rasterize_gaussians(*fwd_args(sc))
+        radii, geom = r[2], r[3]
+        m2d = oracle.get_field(geom, "means2D").view(N, 2).double()
+        dep = oracle.get_field(geom, "depths").double()
+        oracle.release(geom)
+        vis = radii > 0
+        assert int(vis.sum()) > N // 2
+        # fp32 matrix products against float64: a few ulp of the largest term (pixels up to ~2000, depths up to ~6)
+        np.testing.assert_allclose(m2d[vis].numpy(), GEO[f"proj{i}_pix"][vis.numpy()], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(dep[vis].numpy(), GEO[f"proj{i}_depth"][vis.numpy()], rtol=2e-6, atol=2e-6)
