@@ -170,6 +170,59 @@ def cpu_baseline(sc, seed, gpu=None, budget_s=12.0, max_frames=6, single_thread=
     return res
 
 
+def dropin_leg(sc, dev, steps, warmup):
+    """The reference's own Python API on the same workload: diff_gaussian_rasterization.LanguageGaussianRasterizer
+    (GaussianRasterizer for F == 0), autograd forward + backward with the image cotangents fed straight to
+    torch.autograd.backward (no loss kernels), fresh output / gradient / state tensors per call and the one host
+    synchronisation the API implies (num_rendered is a Python int).  One frame in flight."""
+    from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer,
+                                             LanguageGaussianRasterizer)
+    cam = sc.camera
+    rs = GaussianRasterizationSettings(
+        image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=sc.bg.to(dev),
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+        projmatrix_raw=cam.projection_matrix.to(dev), sh_degree=sc.sh_degree, campos=cam.camera_center.to(dev),
+        prefiltered=False, debug=False)
+    lang = sc.F > 0
+    rast = (LanguageGaussianRasterizer if lang else GaussianRasterizer)(raster_settings=rs)
+    names = ("means3D", "opacities", "scales", "rotations", "shs") + (("language",) if lang else ())
+    p = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in names}
+    means2D = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    dc, dl, dd = [None if t is None else t.to(dev) for t in sc.cotangents(3)]
+    leaves = list(p.values()) + [means2D, theta, rho]
+
+    def step():
+        kw = dict(means3D=p["means3D"], means2D=means2D, opacities=p["opacities"], shs=p["shs"], scales=p["scales"],
+                  rotations=p["rotations"], theta=theta, rho=rho)
+        if lang:
+            color, language, radii, depth, opacity, n_touched = rast(language_precomp=p["language"], **kw)
+            outs, cots = [color, language, depth], [dc, dl, dd]
+        else:
+            color, radii, depth, opacity, n_touched = rast(**kw)
+            outs, cots = [color, depth], [dc, dd]
+        for t in leaves:
+            t.grad = None
+        torch.autograd.backward(outs, cots)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    gaps = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return {"path": "diff_gaussian_rasterization autograd API (forward + backward, torch allocations, 1 host sync)",
+            "value": round(steps / dt, 3), "unit": "frames/s", "ms_per_frame": round(1e3 * dt / steps, 4), "steps": steps,
+            "frame_interval_ms": percentiles(gaps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +431,8 @@ def main():
                                "latency_ms": iso_lat,
                                "stage_ms": {k: round(v, 4) for k, v in prof[1].items()},
                                "stage_ms_note": "from a separate profiled leg (HIP events between the stages, ~6 us each)"}
+        if world == 1 and a.isolated_steps > 0:
+            out["dropin"] = dropin_leg(sc, dev, max(a.isolated_steps, 10), 10)
         if world == 1 and not a.no_cpu_baseline:
             lane0 = lanes.lanes[0]
             sl = lane0[1].layout.slices()

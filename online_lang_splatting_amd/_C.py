@@ -13,6 +13,7 @@ Knobs the reference fixes at compile time (CR/config.h:15-18) are module attribu
 The number of language channels is taken from language.shape[1] (supported: 3, 15, 16, 32).
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -44,16 +45,30 @@ def _require_gpu(t, what):
 
 
 class _Resizer:
-    """resizeFunctional, DGR/rasterize_points.cu:27-33: the C side asks for bytes, we resize a
-    uint8 tensor and hand back its data pointer."""
+    """resizeFunctional, DGR/rasterize_points.cu:27-33: the C side asks for bytes, we allocate a uint8 tensor and
+    hand back its data pointer.  ONE ctypes trampoline serves every call (building a CFUNCTYPE object per buffer per
+    call costs more than the allocation): the `user` word the library passes back selects the slot."""
+
+    _tls = threading.local()
 
     def __init__(self, device):
-        self.t = torch.empty(0, dtype=torch.uint8, device=device)
-        self.cb = _abi.ALLOC_FN(self._alloc)
+        self.device = device
+        self.t = None
 
-    def _alloc(self, _user, nbytes):
-        self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.t.device)
-        return self.t.data_ptr()
+    @staticmethod
+    def _dispatch(user, nbytes):
+        r = _Resizer._tls.slots[int(user or 0)]
+        r.t = torch.empty(int(nbytes), dtype=torch.uint8, device=r.device)
+        return r.t.data_ptr()
+
+    @classmethod
+    def bind(cls, *resizers):
+        """Make `resizers` the targets of user words 0, 1, ... for the next library call of this thread."""
+        cls._tls.slots = resizers
+        return [C.c_void_p(i) for i in range(len(resizers))]
+
+
+_Resizer.cb = _abi.ALLOC_FN(_Resizer._dispatch)
 
 
 def current_config():
@@ -101,8 +116,9 @@ def _forward(F, bg, means3D, colors, language, opacity, scales, rotations, scale
         radii = torch.empty(P, **i32)
         n_touched = torch.empty(P, **i32)
         geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
+        u_geom, u_bin, u_img = _Resizer.bind(geom, binning, img)
         R = C.c_int32(0)
-        check(lib().olsr_forward(C.byref(s), geom.cb, None, binning.cb, None, img.cb, None, out_color.data_ptr(),
+        check(lib().olsr_forward(C.byref(s), _Resizer.cb, u_geom, _Resizer.cb, u_bin, _Resizer.cb, u_img, out_color.data_ptr(),
                                  out_lang.data_ptr() if F > 0 else None, out_depth.data_ptr(),
                                  out_opacity.data_ptr(), radii.data_ptr() if P else None,
                                  n_touched.data_ptr() if P else None, C.byref(R), _stream(dev)))
@@ -160,10 +176,18 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
         def p(name):
             t = g.get(name)
             return t.data_ptr() if t is not None and t.numel() > 0 else None
-        scratch = _Resizer(dev)  # sized exactly for the live (instance, slot) rows: one host sync
+        # Row scratch: one partial-gradient row per live (instance, 64-pixel slot) pair.  Their number L is only known
+        # on the device; instead of a host sync for it, the scratch is sized by the bound L <= slots * R (two packed
+        # survivor waves per instance in the reference mode of 15x15 tiles, else four slots).  The caching allocator
+        # hands the same block back call after call, and a backward without a sync keeps the GPU fed.
+        tile, bwd_mode, _binning = cfg if cfg is not None else current_config()
+        slots = 2 if (bwd_mode == _abi.BWD_REFERENCE and tile == 15) else 4
+        rows = max(int(R), 0) * slots
+        scratch = torch.empty(lib().olsr_backward_scratch_bytes(rows, F), dtype=torch.uint8, device=dev)
         check(lib().olsr_backward(
             C.byref(s), rad.data_ptr() if P else None, geomBuffer.data_ptr(), int(R), binningBuffer.data_ptr(),
-            imageBuffer.data_ptr(), scratch.cb, None, None, 0, dc.data_ptr() if dc is not None else None,
+            imageBuffer.data_ptr(), _abi.ALLOC_FN(0), None, scratch.data_ptr(), rows,
+            dc.data_ptr() if dc is not None else None,
             dl.data_ptr() if dl is not None else None, dd.data_ptr() if dd is not None else None,
             p("dL_dmeans2D"), p("dL_dconic"), p("dL_dopacity"), p("dL_dcolors"), p("dL_dlanguage"), p("dL_ddepths"),
             p("dL_dmeans3D"), p("dL_dcov3D"), p("dL_dsh"), p("dL_dscales"), p("dL_drotations"), p("dL_dtau"),

@@ -11,7 +11,9 @@ from ._abi import BINNING_ELLIPSE, BINNING_RECT, BWD_EXACT, BWD_REFERENCE  # noq
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
                          LanguageGaussianRasterizer, rasterize_gaussians, rasterize_language_gaussians)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "LanguageGaussianRasterizer",
+from .renderer import render  # noqa: F401,E402  (the caller-side façade: gaussian_renderer.render)
+
+__all__ = ["render", "GaussianRasterizationSettings", "GaussianRasterizer", "LanguageGaussianRasterizer",
            "rasterize_gaussians", "rasterize_language_gaussians", "BWD_REFERENCE", "BWD_EXACT", "set_backward_mode",
            "set_tile", "BINNING_RECT", "BINNING_ELLIPSE", "set_binning"]
 

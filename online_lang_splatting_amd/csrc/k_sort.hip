@@ -120,6 +120,8 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       const int64_t i0 = i00 + (int64_t)u * stride;
+      // (block-uniform: nothing of this block's u-th slice lies below n)
+      if ((int64_t)blockIdx.x * FS_T * 4 + (i00 - ((int64_t)blockIdx.x * FS_T + tid) * 4) + (int64_t)u * stride >= n) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool valid = i0 + j < n;

@@ -56,6 +56,78 @@ def test_language_rasterizer_autograd_matches_c_level(hip, oracle):
     oracle.release(fo["geom"])
 
 
+class _Model:
+    """The attributes of GaussianModel that gaussian_renderer.render touches."""
+
+    def __init__(self, sc, dev, language=True, isotropic=False):
+        leaf = lambda t: t.to(dev).clone().requires_grad_(True)  # noqa: E731
+        self.get_xyz, self.get_opacity, self.get_rotation = leaf(sc.means3D), leaf(sc.opacities), leaf(sc.rotations)
+        self.get_scaling = leaf(sc.scales[:, :1] if isotropic else sc.scales)
+        self.get_features = leaf(sc.shs)
+        self.get_language_features = leaf(sc.language) if language else None
+        self.active_sh_degree = sc.sh_degree
+        self.max_sh_degree = int(math.isqrt(sc.shs.shape[1])) - 1
+        self.is_language = language
+
+
+def _view(sc, dev):
+    from types import SimpleNamespace
+    cam = sc.camera
+    return SimpleNamespace(FoVx=2 * math.atan(cam.tanfovx), FoVy=2 * math.atan(cam.tanfovy), image_height=cam.height,
+                           image_width=cam.width, world_view_transform=cam.world_view_transform.to(dev),
+                           full_proj_transform=cam.full_proj_transform.to(dev), projection_matrix=cam.projection_matrix.to(dev),
+                           camera_center=cam.camera_center.to(dev), cam_rot_delta=torch.zeros(3, device=dev, requires_grad=True),
+                           cam_trans_delta=torch.zeros(3, device=dev, requires_grad=True))
+
+
+def test_render_harness_returns_the_callers_dict(hip, oracle):
+    """online_lang_splatting_amd.render — the counterpart of gaussian_renderer.render / _language_render
+    (GS/gaussian_renderer/__init__.py:25-58, 195-347): settings from a Camera, the dict keys the SLAM code reads
+    (:338-347), gradients into the model's leaves, viewspace_points.grad and the pose deltas; the SH-in-Python
+    branch, the isotropic-scaling branch, the empty model and the mask path."""
+    from types import SimpleNamespace
+    from online_lang_splatting_amd import render
+    dev = torch.device(DEV)
+    sc = make_scene(3000, 160, 120, 15, seed=5, max_sh_degree=1, sh_degree=1)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
+    bg = sc.bg.to(dev)
+    pc, view = _Model(sc, dev), _view(sc, dev)
+    pkg = render(view, pc, pipe, bg)
+    assert list(pkg) == ["render", "language", "viewspace_points", "visibility_filter", "radii", "depth", "opacity", "n_touched"]
+    fo, go = run_backend(oracle, sc, None, 3, 15, _abi.BWD_REFERENCE)
+    assert torch.equal(pkg["render"].detach().cpu(), fo["color"]) and torch.equal(pkg["language"].detach().cpu(), fo["language"])
+    assert torch.equal(pkg["depth"].detach().cpu(), fo["depth"]) and torch.equal(pkg["radii"].cpu(), fo["radii"])
+    assert torch.equal(pkg["visibility_filter"].cpu(), fo["radii"] > 0) and torch.equal(pkg["n_touched"].cpu(), fo["n_touched"])
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(3))
+    ((pkg["render"] * dc).sum() + (pkg["language"] * dl).sum() + (pkg["depth"] * dd).sum()).backward()
+    assert rel_err(pc.get_xyz.grad, go["dL_dmeans3D"])[0] <= 1e-4
+    assert rel_err(pkg["viewspace_points"].grad, go["dL_dmeans2D"])[0] <= 1e-4
+    tau = go["dL_dtau"].double().sum(0).float()
+    assert rel_err(view.cam_trans_delta.grad.reshape(-1), tau[:3])[0] <= 1e-4   # rho
+    assert rel_err(view.cam_rot_delta.grad.reshape(-1), tau[3:])[0] <= 1e-4     # theta
+    oracle.release(fo["geom"])
+    # SH evaluated in Python (convert_SHs_python): same image up to the fp32 order of the SH sum
+    pkg2 = render(view, _Model(sc, dev), SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=False), bg)
+    assert rel_err(pkg2["render"], pkg["render"].detach())[0] <= 1e-5
+    # RGB-only model: no "language" key; isotropic scaling is repeated to three axes
+    sc0 = make_scene(1500, 96, 64, 0, seed=6)
+    pkg3 = render(_view(sc0, dev), _Model(sc0, dev, language=False, isotropic=True), pipe, sc0.bg.to(dev))
+    assert list(pkg3) == ["render", "viewspace_points", "visibility_filter", "radii", "depth", "opacity", "n_touched"]
+    sc_iso = make_scene(1500, 96, 64, 0, seed=6)
+    sc_iso.scales = sc_iso.scales[:, :1].repeat(1, 3).contiguous()
+    fo3, _ = run_backend(oracle, sc_iso, None, 0, 15, 0)
+    assert torch.equal(pkg3["render"].detach().cpu(), fo3["color"])
+    oracle.release(fo3["geom"])
+    # mask: a subset is rendered, per-Gaussian outputs come back for all P
+    mask = torch.zeros(sc.P, dtype=torch.bool, device=dev)
+    mask[::2] = True
+    pkg4 = render(view, _Model(sc, dev), pipe, bg, mask=mask)
+    assert pkg4["radii"].shape[0] == sc.P and int(pkg4["radii"][~mask].abs().sum()) == 0 and int(pkg4["radii"][mask].sum()) > 0
+    # empty model
+    empty = _Model(make_scene(0, 96, 64, 0, seed=1), dev, language=False)
+    assert render(_view(sc0, dev), empty, pipe, sc0.bg.to(dev)) is None
+
+
 def test_rgb_rasterizer_autograd_and_mark_visible(hip, oracle):
     from diff_gaussian_rasterization import GaussianRasterizer
     dev = torch.device(DEV)

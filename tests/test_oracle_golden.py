@@ -184,3 +184,13 @@ def test_oracle_projection_matches_reference_camera_matrices(oracle):
         # fp32 matrix products against float64: a few ulp of the largest term (pixels up to ~2000, depths up to ~6)
         np.testing.assert_allclose(m2d[vis].numpy(), GEO[f"proj{i}_pix"][vis.numpy()], rtol=0, atol=2e-3)
         np.testing.assert_allclose(dep[vis].numpy(), GEO[f"proj{i}_depth"][vis.numpy()], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_renderer_eval_sh_matches_reference(deg):
+    """online_lang_splatting_amd.renderer.eval_sh (the convert_SHs_python branch of render()) == the reference's
+    gaussian_splatting/utils/sh_utils.eval_sh on the golden directions / coefficients."""
+    from online_lang_splatting_amd.renderer import eval_sh
+    dirs, sh = torch.tensor(GOLD["sh_dirs"]), torch.tensor(GOLD["sh_coeffs"])
+    got = eval_sh(deg, sh.transpose(1, 2), dirs)
+    torch.testing.assert_close(got, torch.tensor(GOLD[f"sh_raw_deg{deg}"]), rtol=1e-5, atol=1e-6)
