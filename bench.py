@@ -223,6 +223,70 @@ def dropin_leg(sc, dev, steps, warmup):
             "frame_interval_ms": percentiles(gaps)}
 
 
+def views_mode(a, sc, dev, rank, world, dist):
+    """--views V: one step = one mapping iteration (utils/slam_backend.py:510-760 without the language front end):
+    V viewpoints of the same Gaussians, view v rendered forward + backward by rank v mod N straight into the flat
+    gradient bucket, ONE exchange of the bucket per step (--exchange), the fused Adam step, and — owner-applies —
+    the all-gather of the updated parameter rows.  Total work is fixed as N grows: strong scaling."""
+    from online_lang_splatting_amd import _C
+    from online_lang_splatting_amd.frame_shard import (FrameShardedStep, FusedAdam, GradLayout, RasterWorkspace,
+                                                       views_of_rank)
+    cfg = CONFIGS[a.config]
+    P, W, H, F = cfg["P"], cfg["W"], cfg["H"], cfg["F"]
+    M = sc.shs.shape[1]
+    cams = arc_cameras(W, H, n=a.views)
+    g_dev, _ = device_inputs(sc, cams[0], dev)
+    cam_dev = [device_inputs(sc, c, dev)[1] for c in cams]
+    cot = [None if t is None else t.to(dev) for t in sc.cotangents(a.config)]
+    mine = views_of_rank(a.views, rank, world)
+    need = 0
+    for v in mine:  # instance capacity: the largest of this rank's views, measured once
+        c = cam_dev[v]
+        args = [g_dev["bg"], g_dev["means3D"], torch.empty(0, device=dev)] + ([g_dev["language"]] if F > 0 else []) + [
+            g_dev["opacities"], g_dev["scales"], g_dev["rotations"], 1.0, torch.empty(0, device=dev), c["viewmatrix"],
+            c["projmatrix"], c["projmatrix_raw"], c["tanfovx"], c["tanfovy"], H, W, g_dev["shs"], sc.sh_degree,
+            c["campos"], False, False]
+        need = max(need, int((_C.rasterize_language_gaussians if F > 0 else _C.rasterize_gaussians)(*args)[0]))
+    ws = RasterWorkspace(P, W, H, F, M, int(need * 1.3) + (1 << 16), dev)
+    step = FrameShardedStep(ws, rank, world, exchange=a.exchange)
+    adam = FusedAdam(P, GradLayout(M, F), dev)
+    params = dict(means3D=g_dev["means3D"], shs=g_dev["shs"], opacities=g_dev["opacities"], scales=g_dev["scales"],
+                  rotations=g_dev["rotations"], language=g_dev["language"])
+    lrs = dict(xyz=1.6e-5, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.01, scale=1e-4, rotation=1e-4, language=2.5e-3)
+
+    def one():
+        step.run(g_dev, cam_dev, lambda v, out: cot, sh_degree=sc.sh_degree)
+        step.optimizer_step(adam, params, lrs)
+    for _ in range(a.warmup):
+        one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    if rank == 0:
+        width = 11 + 3 * M + F
+        print(json.dumps({
+            "metric": f"mapping iteration: {a.views} views rasterizer fwd+bwd + gradient exchange + Adam, frames/sec",
+            "value": round(a.views * a.steps / el, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{a.config - 1}] Gaussians, {a.views} arc viewpoints per step, "
+                                   f"view v on rank v mod {world}, exchange {a.exchange}, fused Adam",
+                       "P": P, "width": W, "height": H, "F": F, "views_per_step": a.views,
+                       "views_of_rank0": len(views_of_rank(a.views, 0, world)), "parallelism": f"frame-shard x{world}",
+                       "exchange": a.exchange, "bucket_bytes": P * width * 4,
+                       "wire": step.wire}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +298,12 @@ def main():
     ap.add_argument("--binning", default="ellipse", choices=["ellipse", "rect"],
                     help="ellipse: exact tile lists (default); rect: the reference's bounding-square lists")
     ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (workspaces on separate HIP streams)")
+    ap.add_argument("--views", type=int, default=0,
+                    help="mapping-iteration mode: every step renders this many viewpoints in total, view v on rank v mod N "
+                         "(BackEnd.map renders 12, utils/slam_backend.py:510-670), then ONE exchange of the bucket; "
+                         "0 (default): one view per rank per step, weak scaling")
+    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter", "sparse"],
+                    help="--views mode: how the shared-Gaussian gradients travel (frame_shard.FrameShardedStep)")
     ap.add_argument("--isolated-steps", type=int, default=30, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
 
@@ -259,6 +329,12 @@ def main():
     P, W, H, F = cfg["P"], cfg["W"], cfg["H"], cfg["F"]
     sc = make_scene(P, W, H, F, seed=a.config, max_sh_degree=cfg["max_sh_degree"])
     M = sc.shs.shape[1]
+    if a.views > 0:
+        views_mode(a, sc, dev, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     cams = arc_cameras(W, H, n=max(world, 1))  # n == 1 -> the identity pose of config 3
     g_dev, _ = device_inputs(sc, cams[0], dev)
     cam_dev = [device_inputs(sc, c, dev)[1] for c in cams]

@@ -121,6 +121,73 @@ class GradientBucket:
                  dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group, async_op=async_op)]
         return works if async_op else []
 
+    # ---- owner-applies exchange: rank r owns the Gaussians [r0, r1) ---------------------
+    @staticmethod
+    def owned_rows(P, rank, world):
+        """Contiguous, equal-sized (up to padding) row ranges: rank r owns [r * ceil(P / world), ...) clipped to P."""
+        per = (P + world - 1) // world
+        return min(rank * per, P), min((rank + 1) * per, P)
+
+    def reduce_scatter(self, rank, world, group=None):
+        """Sum over ranks of the gradient rows this rank owns, left in self.flat[r0:r1] (other rows keep this rank's
+        own partial sums).  On xGMI every GPU has a direct link to each of its 7 peers: a reduce-scatter moves
+        (G-1)/G of the buffer once over all links concurrently, where a ring all-reduce moves 2 (G-1)/G of it around
+        one ring.  RCCL: reduce_scatter_tensor; gloo (CPU tests) has no reduce-scatter: all-reduce + slice."""
+        import torch.distributed as dist
+        P, width = self.flat.shape
+        r0, r1 = self.owned_rows(P, rank, world)
+        if world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return r0, r1
+        if dist.get_backend(group) == "nccl":
+            per = (P + world - 1) // world
+            pad = per * world - P
+            src = self.flat if pad == 0 else torch.cat([self.flat, self.flat.new_zeros(pad, width)])
+            out = torch.empty(per, width, dtype=self.flat.dtype, device=self.flat.device)
+            dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=group)
+            self.flat[r0:r1].copy_(out[: r1 - r0])
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        # the densification statistics and radii are small: plain all-reduces
+        dist.all_reduce(self.densify, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
+        return r0, r1
+
+    # ---- sparse exchange (SURVEY.md section 8(f) row 2, the parity-preserving half) ------------------------------
+    def sparse_all_reduce(self, group=None):
+        """Exchange only the rows of Gaussians that at least one rank saw (densify[:, 1] > 0 somewhere): every other
+        row is zero on every rank, so its sum is the zero it already holds.  Step 1: all-reduce (MAX) of the per-rank
+        visibility BITMASKS (P / 8 bytes); step 2: all-reduce (SUM) of the packed [n_active, width + 2] rows
+        (gradients + the two densification statistics); step 3: unpack.  Same values as all_reduce().
+        Returns dict(active_rows, bytes_dense, bytes_sparse) — the bytes each rank contributes to the wire."""
+        import torch.distributed as dist
+        P, width = self.flat.shape
+        dense_bytes = self.sum_storage.numel() * 4 + self.max_radii.numel() * 4
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return dict(active_rows=int((self.densify[:, 1] > 0).sum()), bytes_dense=dense_bytes, bytes_sparse=0)
+        world = dist.get_world_size(group)
+        seen = self.densify[:, 1] > 0
+        nb = (P + 7) // 8
+        bits = torch.zeros(nb * 8, dtype=torch.uint8, device=seen.device)
+        bits[:P] = seen
+        weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=seen.device)
+        mine = (bits.view(nb, 8).to(torch.int32) * weights).sum(dim=1).to(torch.uint8)       # P / 8 bytes
+        every = torch.empty(world * nb, dtype=torch.uint8, device=seen.device)
+        dist.all_gather_into_tensor(every, mine, group=group)                                 # bitmasks of all ranks
+        union = every.view(world, nb)[0].clone()
+        for r in range(1, world):
+            union |= every.view(world, nb)[r]
+        anyseen = ((union.view(nb, 1).to(torch.int32) // weights) % 2).reshape(-1)[:P]
+        idx = torch.nonzero(anyseen, as_tuple=False).reshape(-1)           # identical on every rank, ascending
+        packed = torch.cat([self.flat.index_select(0, idx), self.densify.index_select(0, idx)], dim=1)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        self.flat.index_copy_(0, idx, packed[:, :width])
+        self.densify.index_copy_(0, idx, packed[:, width:])
+        radii = self.max_radii.index_select(0, idx)
+        dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
+        self.max_radii.index_copy_(0, idx, radii)
+        return dict(active_rows=int(idx.numel()), bytes_dense=dense_bytes,
+                    bytes_sparse=int(nb + idx.numel() * ((width + 2) * 4 + 4)))
+
 
 class FusedAdam:
     """torch.optim.Adam(param_groups, lr=0.0, eps=1e-15) of the reference's GaussianModel
@@ -133,9 +200,11 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
         self.step_count = 0
 
-    def step(self, bucket: GradientBucket, params: Dict[str, torch.Tensor], lrs: Dict[str, float]):
+    def step(self, bucket: GradientBucket, params: Dict[str, torch.Tensor], lrs: Dict[str, float], rows=None):
         """params: means3D [P,3], shs [P,M,3], opacities [P(,1)], scales [P,3], rotations [P,4], language [P,F]
-        (contiguous fp32 on the GPU, updated in place); lrs: xyz, sh_dc, sh_rest, opacity, scale, rotation, language."""
+        (contiguous fp32 on the GPU, updated in place); lrs: xyz, sh_dc, sh_rest, opacity, scale, rotation, language.
+        rows = (r0, r1): update only that contiguous range of Gaussians (the rows a rank owns after a
+        reduce-scatter); the moments of the other rows are left alone."""
         self.step_count += 1
         hp = _abi.OlsrAdamParams(lr_xyz=lrs["xyz"], lr_sh_dc=lrs["sh_dc"], lr_sh_rest=lrs["sh_rest"], lr_opacity=lrs["opacity"],
                                  lr_scale=lrs["scale"], lr_rotation=lrs["rotation"], lr_language=lrs.get("language", 0.0),
@@ -143,14 +212,19 @@ class FusedAdam:
         for k, t in params.items():
             if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
                 raise RuntimeError(f"FusedAdam: {k} must be a contiguous fp32 tensor on the GPU")
+        P = bucket.flat.shape[0]
+        r0, r1 = (0, P) if rows is None else rows
+        if r1 <= r0:
+            return
+        M, F, W = self.layout.M, self.layout.F, self.layout.width
+        per_row = dict(means3D=3, shs=3 * M, opacities=1, scales=3, rotations=4, language=F)
 
         def p(name):
             t = params.get(name)
-            return t.data_ptr() if t is not None and t.numel() > 0 else None
-        P = bucket.flat.shape[0]
-        check(lib().olsr_adam_step(P, self.layout.M, self.layout.F, C.byref(hp), bucket.flat.data_ptr(), p("means3D"),
+            return t.data_ptr() + 4 * r0 * per_row[name] if t is not None and t.numel() > 0 else None
+        check(lib().olsr_adam_step(r1 - r0, M, F, C.byref(hp), bucket.flat.data_ptr() + 4 * r0 * W, p("means3D"),
                                    p("shs"), p("opacities"), p("scales"), p("rotations"), p("language"),
-                                   self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                   self.exp_avg.data_ptr() + 4 * r0 * W, self.exp_avg_sq.data_ptr() + 4 * r0 * W,
                                    C.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)))
 
 
@@ -302,20 +376,40 @@ class FrameLanes:
 class FrameShardedStep:
     """One optimisation step's worth of rasterization, sharded by viewpoint over the ranks of a
     torch.distributed group (one process per GPU).  `cameras` is the full list of views of the step
-    (identical on every rank); this rank renders views_of_rank(...)."""
+    (identical on every rank); this rank renders views_of_rank(...).
 
-    def __init__(self, workspace: RasterWorkspace, rank=0, world=1, group=None):
+    exchange:
+      "all_reduce"      one SUM all-reduce of the flat bucket (+ the statistics); every rank then holds the total
+                        and applies the identical update — what north_star names;
+      "reduce_scatter"  owner-applies: rank r receives the summed rows of the Gaussians it
+                        owns, steps Adam on those rows only (`optimizer_step`), and the updated parameter rows are
+                        all-gathered — 2 x (G-1)/G of the PARAMETER bytes + (G-1)/G of the gradient bytes per GPU,
+                        all of it spread over the G-1 direct xGMI links;
+      "sparse"          all-reduce of the rows of Gaussians some rank saw (GradientBucket.sparse_all_reduce).
+    A capacity overflow on ANY rank (instances or gradient rows: that view contributed zeros) is surfaced: the
+    per-rank flag travels with the MAX all-reduce and `run` raises OverflowError on every rank, with the capacity
+    that would have sufficed, so the caller can regrow its workspace and repeat the step."""
+
+    def __init__(self, workspace: RasterWorkspace, rank=0, world=1, group=None, exchange="all_reduce"):
+        assert exchange in ("all_reduce", "reduce_scatter", "sparse")
         self.ws = workspace
-        self.rank, self.world, self.group = rank, world, group
+        self.rank, self.world, self.group, self.exchange = rank, world, group, exchange
         self.bucket = GradientBucket(workspace.P, GradLayout(workspace.M, workspace.F), workspace.device)
         self.pose_grads: Dict[int, torch.Tensor] = {}
+        self.owned = GradientBucket.owned_rows(workspace.P, rank, world)
+        self.wire = None  # dict from the sparse exchange
+        self._need = torch.zeros(2, dtype=torch.int32, device=workspace.device)  # max over views {R, live rows}
+        self._ovf = torch.zeros(1, dtype=torch.int32, device=workspace.device)
 
     def run(self, gaussians: Dict[str, torch.Tensor], cameras: Sequence[Dict], cotangents, sh_degree=0):
         """gaussians: bg, means3D, opacities, scales, rotations, shs, language.
         cameras[v]: viewmatrix, projmatrix, projmatrix_raw, campos (device tensors), tanfovx, tanfovy.
         cotangents(v, outputs) -> (dL_dcolor, dL_dlanguage, dL_ddepth): the caller's loss gradient."""
+        import torch.distributed as dist
         ws = self.ws
         self.pose_grads.clear()
+        self._need.zero_()
+        self._ovf.zero_()
         mine = views_of_rank(len(cameras), self.rank, self.world)
         if not mine:
             self.bucket.zero_()
@@ -329,5 +423,48 @@ class FrameShardedStep:
             # the per-Gaussian backward kernel writes / adds straight into the bucket (fused accumulate)
             g = ws.backward(dc, dl, dd, bucket=self.bucket, first=(n_done == 0), bucket_only=True)
             self.pose_grads[v] = g["dL_dtau_sum"].clone()  # [rho | theta], stays on the owning rank
-        self.bucket.all_reduce(self.group)
+            # overflow bookkeeping stays on the device (no sync inside the loop)
+            torch.maximum(self._need[0:1], ws.num_rendered[0:1], out=self._need[0:1])
+            torch.maximum(self._need[1:2], ws.bwd_status[0:1], out=self._need[1:2])
+            torch.maximum(self._ovf, torch.maximum(ws.num_rendered[1:2], ws.bwd_status[1:2]), out=self._ovf)
+        multi = self.world > 1 and dist.is_available() and dist.is_initialized()
+        if self.exchange == "reduce_scatter":
+            self.owned = self.bucket.reduce_scatter(self.rank, self.world, self.group)
+        elif self.exchange == "sparse":
+            self.wire = self.bucket.sparse_all_reduce(self.group)
+        else:
+            self.bucket.all_reduce(self.group)
+        flags = torch.cat([self._ovf, self._need])
+        if multi:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        ovf, need_R, need_L = (int(x) for x in flags.cpu())  # the step's one host synchronisation
+        if ovf:
+            raise OverflowError(f"a view overflowed the workspace on some rank: it needs capacity >= {need_R} instances "
+                                f"and row_capacity >= {need_L} gradient rows (has {ws.capacity} / {ws.row_capacity}); "
+                                "regrow the RasterWorkspace and repeat the step")
         return self.bucket
+
+    def optimizer_step(self, adam: "FusedAdam", params: Dict[str, torch.Tensor], lrs: Dict[str, float]):
+        """Apply the step to the raw parameters.  all_reduce / sparse: every rank updates every row (identical
+        results everywhere).  reduce_scatter: this rank updates the rows it owns, then the parameter rows are
+        all-gathered so that every rank renders the next step from identical Gaussians."""
+        import torch.distributed as dist
+        if self.exchange != "reduce_scatter" or self.world == 1:
+            adam.step(self.bucket, params, lrs)
+            return
+        adam.step(self.bucket, params, lrs, rows=self.owned)
+        P = self.bucket.flat.shape[0]
+        per = (P + self.world - 1) // self.world
+        for name, t in params.items():
+            if t is None or t.numel() == 0:
+                continue
+            rows = t.reshape(P, -1)
+            w = rows.shape[1]
+            if per * self.world == P:
+                dist.all_gather_into_tensor(rows, rows[self.owned[0]:self.owned[1]].clone(), group=self.group)
+            else:  # ragged tail: gather into a padded staging buffer
+                mine = rows.new_zeros(per, w)
+                mine[: self.owned[1] - self.owned[0]] = rows[self.owned[0]:self.owned[1]]
+                full = rows.new_empty(per * self.world, w)
+                dist.all_gather_into_tensor(full, mine, group=self.group)
+                rows.copy_(full[:P])

@@ -91,3 +91,61 @@ def test_sharding_and_layout_properties():
 
     partition()
     layout()
+
+
+def _exchange_worker(rank, world, port, P, M, F, V, mode, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = GradientBucket(P, GradLayout(M, F), "cpu")
+    for v in views_of_rank(V, rank, world):
+        g, radii = _fake_view_grads(P, M, F, v)
+        # Gaussians a view does not see have zero gradients and zero radius, as the rasterizer writes them
+        hidden = torch.arange(P) % (3 + v) == 0
+        for k in g:
+            g[k][hidden] = 0
+        radii[hidden] = 0
+        radii[~hidden] += 1
+        b.accumulate(g, radii)
+    if mode == "sparse":
+        ret[f"wire{rank}"] = b.sparse_all_reduce()
+    elif mode == "reduce_scatter":
+        r0, r1 = b.reduce_scatter(rank, world)
+        ret[f"rows{rank}"] = (r0, r1, b.flat[r0:r1].clone())
+    else:
+        b.all_reduce()
+    if rank == 0:
+        ret["flat"], ret["densify"], ret["max_radii"] = b.flat.clone(), b.densify.clone(), b.max_radii.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_exchange(mode, P=301, M=1, F=15, V=5, world=2):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_exchange_worker, args=(world, port, P, M, F, V, mode, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+def test_sparse_exchange_equals_dense_all_reduce():
+    """Only the rows of Gaussians that some rank saw travel; the result equals the dense all-reduce bit for bit
+    (the same two partial sums are added in the same order) and fewer bytes are sent."""
+    dense, sparse = _run_exchange("all_reduce"), _run_exchange("sparse")
+    assert torch.equal(sparse["flat"], dense["flat"]) and torch.equal(sparse["densify"], dense["densify"])
+    assert torch.equal(sparse["max_radii"], dense["max_radii"])
+    w = sparse["wire0"]
+    assert 0 < w["active_rows"] <= 301 and w == sparse["wire1"]
+    assert w["active_rows"] == int((dense["densify"][:, 1] > 0).sum())
+
+
+def test_reduce_scatter_gives_every_rank_its_owned_rows():
+    dense, rs = _run_exchange("all_reduce"), _run_exchange("reduce_scatter")
+    covered = []
+    for rank in range(2):
+        r0, r1, rows = rs[f"rows{rank}"]
+        assert (r0, r1) == GradientBucket.owned_rows(301, rank, 2)
+        assert torch.equal(rows, dense["flat"][r0:r1])
+        covered += list(range(r0, r1))
+    assert covered == list(range(301))
+    assert torch.equal(rs["densify"], dense["densify"]) and torch.equal(rs["max_radii"], dense["max_radii"])

@@ -53,3 +53,20 @@ def test_two_ranks_frame_sharded_over_gloo():
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 2 and d["config"]["views_per_step"] == 2 and d["value"] > 0
     assert "cpu_baseline" not in d
+
+
+def test_mapping_iteration_mode_two_ranks_over_gloo():
+    """bench.py --views: V views sharded over the ranks, one exchange + fused Adam per step, in all three exchange modes."""
+    for exchange in ("all_reduce", "reduce_scatter", "sparse"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, OLSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--config",
+                            "1", "--views", "5", "--exchange", exchange, "--steps", "3", "--warmup", "1"], cwd=ROOT,
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (exchange, p.stdout[-1500:], p.stderr[-1500:])
+        d = _last_json(p.stdout)
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["views_per_step"] == 5 and d["value"] > 0
+        assert d["config"]["views_of_rank0"] == 3 and d["config"]["exchange"] == exchange

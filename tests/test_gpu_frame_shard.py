@@ -1,0 +1,122 @@
+"""FrameShardedStep on the GPU: two ranks (gloo, sharing the one device of the test box — on a multi-GPU node the same
+code runs one rank per GPU over RCCL) shard the views of one mapping step; the exchanged bucket must equal the
+single-process result of the same views bit for bit (fixed summation order: rank 0's views, then rank 1's), all three
+exchange modes must leave the same parameters after the optimiser step, and an overflow on one rank must surface on
+both."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+P, W, H, F, V = 6000, 200, 150, 15, 5
+LRS = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
+
+
+def _inputs(dev):
+    from online_lang_splatting_amd.scene import arc_cameras, make_scene
+    sc = make_scene(P, W, H, F, seed=17)
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    cams = [dict(viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev),
+                 projmatrix_raw=c.projection_matrix.to(dev), campos=c.camera_center.to(dev), tanfovx=c.tanfovx,
+                 tanfovy=c.tanfovy) for c in arc_cameras(W, H, V)]
+    cot = [tuple(t.to(dev) for t in sc.cotangents(100 + v)) for v in range(V)]
+    return sc, g, cams, cot
+
+
+def _step(rank, world, exchange, capacity, dev):
+    from online_lang_splatting_amd.frame_shard import FrameShardedStep, FusedAdam, GradLayout, RasterWorkspace
+    sc, g, cams, cot = _inputs(dev)
+    ws = RasterWorkspace(P, W, H, F, sc.shs.shape[1], capacity, dev)
+    st = FrameShardedStep(ws, rank, world, exchange=exchange)
+    bucket = st.run(g, cams, lambda v, out: cot[v], sh_degree=sc.sh_degree)
+    params = dict(means3D=g["means3D"].clone(), shs=g["shs"].clone(), opacities=g["opacities"].clone(),
+                  scales=g["scales"].clone(), rotations=g["rotations"].clone(), language=g["language"].clone())
+    adam = FusedAdam(P, GradLayout(sc.shs.shape[1], F), dev)
+    st.optimizer_step(adam, params, LRS)
+    torch.cuda.synchronize()
+    return st, bucket, params
+
+
+def _worker(rank, world, port, exchange, capacity, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    try:
+        st, bucket, params = _step(rank, world, exchange, capacity, dev)
+        ret[f"flat{rank}"] = bucket.flat.cpu()
+        ret[f"densify{rank}"], ret[f"radii{rank}"] = bucket.densify.cpu(), bucket.max_radii.cpu()
+        ret[f"params{rank}"] = {k: v.cpu() for k, v in params.items()}
+        ret[f"owned{rank}"] = st.owned
+        ret[f"poses{rank}"] = {v: t.cpu() for v, t in st.pose_grads.items()}
+        if st.wire is not None:
+            ret[f"wire{rank}"] = st.wire
+    except OverflowError as e:
+        ret[f"overflow{rank}"] = str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(exchange, capacity=400000):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, exchange, capacity, ret), nprocs=2, join=True)
+    return dict(ret)
+
+
+def _single_process_reference(dev):
+    """The same five views in one process, summed in the order the two ranks produce: (v0 + v2 + v4) + (v1 + v3)."""
+    from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket, RasterWorkspace
+    sc, g, cams, cot = _inputs(dev)
+    ws = RasterWorkspace(P, W, H, F, sc.shs.shape[1], 400000, dev)
+    parts, poses = [], {}
+    for rank in range(2):
+        b = GradientBucket(P, GradLayout(sc.shs.shape[1], F), dev)
+        for n, v in enumerate(range(rank, V, 2)):
+            ws.set_scene(sh_degree=sc.sh_degree, **cams[v], **g)
+            ws.forward()
+            gr = ws.backward(*cot[v], bucket=b, first=(n == 0), bucket_only=True)
+            poses[v] = gr["dL_dtau_sum"].clone().cpu()
+        parts.append(b)
+    torch.cuda.synchronize()
+    return (parts[0].flat + parts[1].flat).cpu(), (parts[0].densify + parts[1].densify).cpu(), \
+        torch.maximum(parts[0].max_radii, parts[1].max_radii).cpu(), poses
+
+
+def test_two_ranks_equal_the_single_process_sum(hip):
+    dev = torch.device("cuda:0")
+    flat, densify, radii, poses = _single_process_reference(dev)
+    assert float(flat.abs().max()) > 0 and int((densify[:, 1] == V).sum()) > 0
+    res = {m: _spawn(m) for m in ("all_reduce", "sparse", "reduce_scatter")}
+    for m in ("all_reduce", "sparse"):
+        for r in range(2):
+            assert torch.equal(res[m][f"flat{r}"], flat), (m, r)
+            assert torch.equal(res[m][f"densify{r}"], densify) and torch.equal(res[m][f"radii{r}"], radii), (m, r)
+    w = res["sparse"]["wire0"]
+    assert w["active_rows"] == int((densify[:, 1] > 0).sum()) and w["bytes_sparse"] < w["bytes_dense"]
+    for r in range(2):  # owner-applies: the rows a rank owns hold the total
+        r0, r1 = res["reduce_scatter"][f"owned{r}"]
+        assert torch.equal(res["reduce_scatter"][f"flat{r}"][r0:r1], flat[r0:r1])
+    # pose gradients stay with the rank that rendered the view
+    for r in range(2):
+        assert sorted(res["all_reduce"][f"poses{r}"]) == list(range(r, V, 2))
+        for v, t in res["all_reduce"][f"poses{r}"].items():
+            assert torch.equal(t, poses[v])
+    # one optimiser step later every rank holds the same parameters, whatever the exchange
+    ref = res["all_reduce"]["params0"]
+    for m in res:
+        for r in range(2):
+            for k in ref:
+                assert torch.equal(res[m][f"params{r}"][k], ref[k]), (m, r, k)
+    assert not torch.equal(ref["means3D"], _inputs(torch.device("cpu"))[1]["means3D"])  # ... and they did move
+
+
+def test_overflow_on_any_rank_surfaces_on_every_rank(hip):
+    res = _spawn("all_reduce", capacity=2000)
+    assert "overflow0" in res and "overflow1" in res and "capacity >=" in res["overflow0"]
