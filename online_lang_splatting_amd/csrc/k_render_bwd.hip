@@ -121,14 +121,19 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   float T = T_final;
   const int last_contributor = inside ? (int)n_contrib[pix] : 0;
   float last_alpha = 0.f;
-  float accum_c[3] = {0.f, 0.f, 0.f}, last_c[3] = {0.f, 0.f, 0.f}, dLc[3];
+  // Colour / depth "behind" a splat: the reference carries (last_alpha, last_color, accum_rec) and forms
+  // accum_rec <- last_alpha * last_color + (1 - last_alpha) * accum_rec when it reaches the next splat
+  // (CR/backward.cu:1110-1123).  The same quantity in running form: Z = colour composited from everything behind,
+  // used as accum_rec and then advanced, Z <- Z + alpha * (c - Z).  Algebraically identical, 4 state registers
+  // instead of 8, one operation less per channel (value path: no decision depends on it).
+  float Zc[3] = {0.f, 0.f, 0.f}, dLc[3];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) dLc[ch] = inside ? dL_dpixels[ch * HW + pix] : 0.f;
   float bg_dot = 0.f;
   bg_dot += bg0 * dLc[0];
   bg_dot += bg1 * dLc[1];
   bg_dot += bg2 * dLc[2];
-  float accum_d = 0.f, last_d = 0.f;
+  float Zd = 0.f;
   const float dLd = inside ? dL_dpixels_depth[pix] : 0.f;
   float A_f = 0.f, D_last = 0.f, dLf[FX];
 #pragma unroll
@@ -208,14 +213,29 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
     __syncthreads();
 
     // From here to the next batch the four waves run independently: no barrier per splat.
-    for (int i = 0; i < cnt; ++i) {
-      // (wave-uniform values are moved to scalar registers: the tests below become s_cmp / s_cbranch)
-      const u32 fl = (u32)__builtin_amdgcn_readfirstlane((int)s_flag[i]);
-      if ((fl & 15u) == 0) continue;  // whole tile skips this splat: no state changes (CR/backward.cu:1091-1093)
-      // did any pixel of THIS wave blend it in the forward?  (bits 0-3: the forward's slots; bits 4-5: the
-      // packed survivor waves)
-      const bool mine = (fl >> (PACKED ? 4 + w : w)) & 1u;
-      if (!REF && !mine) continue;
+    // The flags of the staged entries become wave-uniform 64-bit masks (one ballot per half batch): which entries the
+    // tile as a whole does not skip (bits 0-3: the forward's slots) and which ones THIS wave blended (bits 4-5: the
+    // packed survivor waves).  The loop then walks set bits with scalar instructions; an entry nobody blended — most
+    // of every list — costs nothing (it used to cost a dependent LDS read and a v_readfirstlane each).
+    static_assert(B == 128, "two 64-bit masks per batch");
+    u64 m_any[2], m_mine[2], m_w0[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = lane + 64 * h;
+      const u32 f = (e < cnt) ? s_flag[e] : 0u;
+      m_any[h] = ballot((f & 15u) != 0u);
+      m_mine[h] = ballot(((f >> (PACKED ? 4 + w : w)) & 1u) != 0u);
+      m_w0[h] = ballot(((f >> 4) & 1u) != 0u);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+    // reference mode with language channels: the recursion also advances on entries another wave blended
+    u64 todo = (REF && F > 0) ? m_any[h] : m_mine[h];
+    while (todo != 0ull) {
+      const int bit = (int)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const int i = 64 * h + bit;
+      const bool mine = (m_mine[h] >> bit) & 1ull;  // did any pixel of THIS wave blend it in the forward?
       const float* fr = &s_feat[i * FR];
       float D_cur = 0.f;
       if constexpr (F > 0) {
@@ -253,46 +273,50 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
       // -- value path: FMA contraction allowed (rounding differs from the oracle by ~1 ulp per
       //    operation; no decision depends on these values).  Everything a skipping pixel must not
       //    contribute hangs off three factors that are zero for it.
-      float f_dcd = 0.f;  // alpha * T        (dchannel_dcolor)
-      float f_dLa = 0.f;  // dL_dalpha
+      // The state update is branch-free: every lane evaluates it, a skipping lane keeps its old state through a
+      // select.  (An `if (!skip)` block cost ~28 register copies per visit around the exec-masked region, in a kernel
+      // that is bound by VALU issue.)
+      float f_dcd, f_dLa;  // alpha * T (dchannel_dcolor) and dL_dalpha; zero for a skipping pixel
       float sum[NVP];
       {
 #pragma clang fp contract(fast)
-        const float la = last_alpha, one_m_la = 1.f - last_alpha;
         if constexpr (REF && F > 0) {  // unguarded (CR/backward.cu:1132-1133)
-          A_f = la * D_last + one_m_la * A_f;
+          A_f = last_alpha * D_last + (1.f - last_alpha) * A_f;
           D_last = D_cur;
         }
-        if (!skip) {
-          const float one_m_alpha = 1.f - alpha;  // in [0.01, 1]
-          float inv = __builtin_amdgcn_rcpf(one_m_alpha);
-          inv = __builtin_fmaf(__builtin_fmaf(-one_m_alpha, inv, 1.0f), inv, inv);
-          T = T * inv;
-          float dL_dalpha = 0.0f;
+        const float one_m_alpha = 1.f - alpha;  // in [0.01, 1] for every pixel that does not skip
+        float inv = __builtin_amdgcn_rcpf(one_m_alpha);
+        inv = __builtin_fmaf(__builtin_fmaf(-one_m_alpha, inv, 1.0f), inv, inv);
+        const float T_new = T * inv;
+        float dL_dalpha = 0.0f;
+        float Zn[3];
 #pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const float c = fr[ch];
-            accum_c[ch] = la * last_c[ch] + one_m_la * accum_c[ch];
-            last_c[ch] = c;
-            dL_dalpha += (c - accum_c[ch]) * dLc[ch];
-          }
-          const float depth = fr[3];
-          accum_d = la * last_d + one_m_la * accum_d;
-          last_d = depth;
-          dL_dalpha += (depth - accum_d) * dLd;
-          if constexpr (F > 0) {
-            if constexpr (!REF) {
-              A_f = la * D_last + one_m_la * A_f;
-              D_last = D_cur;
-            }
-            dL_dalpha += D_cur - A_f;
-          }
-          dL_dalpha *= T;
-          last_alpha = alpha;
-          if (has_bg) dL_dalpha += (-T_final * inv) * bg_dot;
-          f_dcd = alpha * T;
-          f_dLa = dL_dalpha;
+        for (int ch = 0; ch < 3; ++ch) {
+          const float diff = fr[ch] - Zc[ch];
+          dL_dalpha += diff * dLc[ch];
+          Zn[ch] = Zc[ch] + alpha * diff;
         }
+        const float ddiff = fr[3] - Zd;
+        dL_dalpha += ddiff * dLd;
+        const float Zdn = Zd + alpha * ddiff;
+        float A_new = A_f;
+        if constexpr (F > 0) {
+          if constexpr (!REF) A_new = last_alpha * D_last + (1.f - last_alpha) * A_f;  // guarded like colour
+          dL_dalpha += D_cur - A_new;
+        }
+        dL_dalpha *= T_new;
+        if (has_bg) dL_dalpha += (-T_final * inv) * bg_dot;
+        T = skip ? T : T_new;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) Zc[ch] = skip ? Zc[ch] : Zn[ch];
+        Zd = skip ? Zd : Zdn;
+        if constexpr (!REF && F > 0) {
+          A_f = skip ? A_f : A_new;
+          D_last = skip ? D_last : D_cur;
+        }
+        last_alpha = skip ? last_alpha : alpha;
+        f_dcd = skip ? 0.f : alpha * T_new;
+        f_dLa = skip ? 0.f : dL_dalpha;
         // reference mode: only the ranks that survive its 225-lane tree contribute to these ten sums
         const float Gm = (skip || !surv) ? 0.f : G;  // (G of a skipping pixel may be huge: keep it out of products)
         const float s_dLa = surv ? f_dLa : 0.f;
@@ -343,9 +367,16 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
         rowval = lang_lane ? dcd0 * dLf0_lane : rowval;
       }
       // compact row index: rows of an instance are consecutive, one per set slot bit
-      const u32 before = PACKED ? ((fl >> 4) & (u32)w) : (u32)__popc(fl & ((1u << w) - 1u));  // rows of earlier waves
+      u32 before;  // rows of earlier waves
+      if constexpr (PACKED) {
+        before = (u32)w & (u32)((m_w0[h] >> bit) & 1ull);
+      } else {
+        const u32 fl = (u32)__builtin_amdgcn_readfirstlane((int)s_flag[i]);
+        before = (u32)__popc(fl & ((1u << w) - 1u));
+      }
       float* rowp = rows + ((size_t)(u32)__builtin_amdgcn_readfirstlane((int)s_row[i]) + before) * ROW;  // scalar
       if (role >= 0) rowp[role] = rowval;
+    }
     }
   }
 }

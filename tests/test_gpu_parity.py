@@ -198,7 +198,7 @@ def test_needles_and_faint_splats_exact_binning(hip, oracle):
     _check(hip, oracle, sc, seed=12, tile=16, grad_keys=COMPOSITE_GRADS)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("OLSR_STRESS_SEEDS", "48"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OLSR_STRESS_SEEDS", "256"))))
 def test_exact_binning_never_drops_a_blending_instance(hip, seed):
     """Randomised stress of the conservative interval arithmetic behind the exact tile lists (no oracle needed):
     random anisotropy up to 3000:1, scale, opacity around the alpha floor, off-screen and near-plane splats,
