@@ -126,15 +126,16 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   // (CR/backward.cu:1110-1123).  The same quantity in running form: Z = colour composited from everything behind,
   // used as accum_rec and then advanced, Z <- Z + alpha * (c - Z).  Algebraically identical, 4 state registers
   // instead of 8, one operation less per channel (value path: no decision depends on it).
-  float Zc[3] = {0.f, 0.f, 0.f}, dLc[3];
+  v2f Z01 = {0.f, 0.f}, Z23 = {0.f, 0.f};  // {r, g} and {b, depth} composited from everything behind
+  float dLc[3];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) dLc[ch] = inside ? dL_dpixels[ch * HW + pix] : 0.f;
   float bg_dot = 0.f;
   bg_dot += bg0 * dLc[0];
   bg_dot += bg1 * dLc[1];
   bg_dot += bg2 * dLc[2];
-  float Zd = 0.f;
   const float dLd = inside ? dL_dpixels_depth[pix] : 0.f;
+  const v2f dL01 = {dLc[0], dLc[1]}, dL23 = {dLc[2], dLd};  // the pixel's cotangents, in the same pairs
   float A_f = 0.f, D_last = 0.f, dLf[FX];
 #pragma unroll
   for (int ch = 0; ch < FX; ++ch) dLf[ch] = (F > 0 && inside) ? dL_dpixels_lang[ch * HW + pix] : 0.f;
@@ -284,58 +285,59 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
           A_f = last_alpha * D_last + (1.f - last_alpha) * A_f;
           D_last = D_cur;
         }
+        // Everything a skipping pixel must not do hangs off two masked factors: alpha_eff = 0 leaves Z unchanged and
+        // zeroes alpha * T, inv_eff = 1 leaves T unchanged.  Colour and depth run on packed fp32 pairs — an
+        // instruction holds the SIMD's issue for one quad-cycle whether it is packed or not.
         const float one_m_alpha = 1.f - alpha;  // in [0.01, 1] for every pixel that does not skip
         float inv = __builtin_amdgcn_rcpf(one_m_alpha);
         inv = __builtin_fmaf(__builtin_fmaf(-one_m_alpha, inv, 1.0f), inv, inv);
-        const float T_new = T * inv;
-        float dL_dalpha = 0.0f;
-        float Zn[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float diff = fr[ch] - Zc[ch];
-          dL_dalpha += diff * dLc[ch];
-          Zn[ch] = Zc[ch] + alpha * diff;
-        }
-        const float ddiff = fr[3] - Zd;
-        dL_dalpha += ddiff * dLd;
-        const float Zdn = Zd + alpha * ddiff;
-        float A_new = A_f;
+        const float alpha_eff = skip ? 0.f : alpha;
+        const float inv_eff = skip ? 1.f : inv;
+        T = T * inv_eff;
+        const float4 f4 = *reinterpret_cast<const float4*>(fr);  // r g b depth of the splat (wave-uniform LDS read)
+        const v2f d01 = v2f{f4.x, f4.y} - Z01, d23 = v2f{f4.z, f4.w} - Z23;
+        const v2f dd = d01 * dL01 + d23 * dL23;
+        float dL_dalpha = dd.x + dd.y;
+        const v2f a2 = {alpha_eff, alpha_eff};
+        Z01 = Z01 + a2 * d01;
+        Z23 = Z23 + a2 * d23;
         if constexpr (F > 0) {
-          if constexpr (!REF) A_new = last_alpha * D_last + (1.f - last_alpha) * A_f;  // guarded like colour
-          dL_dalpha += D_cur - A_new;
+          if constexpr (!REF) {  // guarded like colour
+            const float A_new = last_alpha * D_last + (1.f - last_alpha) * A_f;
+            dL_dalpha += D_cur - A_new;
+            A_f = skip ? A_f : A_new;
+            D_last = skip ? D_last : D_cur;
+          } else {
+            dL_dalpha += D_cur - A_f;
+          }
         }
-        dL_dalpha *= T_new;
+        dL_dalpha *= T;
         if (has_bg) dL_dalpha += (-T_final * inv) * bg_dot;
-        T = skip ? T : T_new;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) Zc[ch] = skip ? Zc[ch] : Zn[ch];
-        Zd = skip ? Zd : Zdn;
-        if constexpr (!REF && F > 0) {
-          A_f = skip ? A_f : A_new;
-          D_last = skip ? D_last : D_cur;
-        }
         last_alpha = skip ? last_alpha : alpha;
-        f_dcd = skip ? 0.f : alpha * T_new;
+        f_dcd = alpha_eff * T;
         f_dLa = skip ? 0.f : dL_dalpha;
         // reference mode: only the ranks that survive its 225-lane tree contribute to these ten sums
         const float Gm = (skip || !surv) ? 0.f : G;  // (G of a skipping pixel may be huge: keep it out of products)
         const float s_dLa = surv ? f_dLa : 0.f;
         const float s_dcd = surv ? f_dcd : 0.f;
         const float dL_dG = co.w * s_dLa;
-        const float gdx = Gm * dx;
-        const float gdy = Gm * dy;
-        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-        const float dG_ddely = -gdy * co.z - gdx * co.y;
-        sum[0] = dL_dG * dG_ddelx * ddelx_dx;
-        sum[1] = dL_dG * dG_ddely * ddely_dy;
-        sum[2] = -0.5f * gdx * dx * dL_dG;
-        sum[3] = -0.5f * gdx * dy * dL_dG;
-        sum[4] = -0.5f * gdy * dy * dL_dG;
+        const v2f dxy = {dx, dy};
+        const v2f gd = dxy * v2f{Gm, Gm};                                        // {gdx, gdy}
+        const v2f dGd = -(gd * v2f{co.x, co.z}) - v2f{gd.y, gd.x} * v2f{co.y, co.y};  // {dG_ddelx, dG_ddely}
+        const v2f s01 = (dGd * v2f{dL_dG, dL_dG}) * v2f{ddelx_dx, ddely_dy};
+        const float h = -0.5f * dL_dG;
+        const v2f s23 = dxy * v2f{gd.x * h, gd.x * h};                           // -0.5 gdx {dx, dy} dL_dG
+        const v2f s67 = dL01 * v2f{s_dcd, s_dcd}, s89 = dL23 * v2f{s_dcd, s_dcd};
+        sum[0] = s01.x;
+        sum[1] = s01.y;
+        sum[2] = s23.x;
+        sum[3] = s23.y;
+        sum[4] = (gd.y * h) * dy;
         sum[5] = Gm * s_dLa;
-        sum[6] = s_dcd * dLc[0];
-        sum[7] = s_dcd * dLc[1];
-        sum[8] = s_dcd * dLc[2];
-        sum[9] = s_dcd * dLd;
+        sum[6] = s67.x;
+        sum[7] = s67.y;
+        sum[8] = s89.x;
+        sum[9] = s89.y;
         if constexpr (!REF && F > 0) {
 #pragma unroll
           for (int k2 = 0; k2 < F2; ++k2) {

@@ -52,3 +52,23 @@ def hip():
     from online_lang_splatting_amd import _C, _lib
     _lib.lib()
     return _C
+
+
+@pytest.fixture(autouse=True)
+def _default_rasterizer_knobs():
+    """Tile edge / backward mode / binning are module-level knobs of the product `_C` (and of the oracle): every test
+    starts from the defaults, whatever an earlier test left behind."""
+    def reset():
+        try:
+            from online_lang_splatting_amd import _C, _abi
+            _C.TILE, _C.BWD_MODE, _C.BINNING = 15, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE
+        except Exception:
+            pass
+        try:
+            from oracle import oracle_C
+            oracle_C.TILE, oracle_C.BWD_MODE = 15, 0
+        except Exception:
+            pass
+    reset()
+    yield
+    reset()
