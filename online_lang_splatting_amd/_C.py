@@ -5,6 +5,12 @@ DGR/rasterize_points.h:17-152 — so the autograd layer (rasterizer.py) reads li
 reference's.  Tensors are allocated with torch (device memory and the current HIP stream are
 plumbing); all arithmetic happens behind the C-ABI of include/olsr.h in libolsr.so.
 
+Two bindings of the same library entry points live here.  The five `_C` functions go through the compiled torch
+extension `_olsr_torch` (csrc/olsr_torch.cpp, built in-tree by build.py) — argument checks, allocation and the call
+in C++, like the reference's ext.cpp; the ctypes binding below serves the same calls when that module has not been
+built (OLSR_BINDING=ctypes forces it) and everything outside the five functions (state introspection, losses, Adam,
+kNN, the benchmark's async entry).  Both end in libolsr.so; neither computes anything itself.
+
 Knobs the reference fixes at compile time (CR/config.h:15-18) are module attributes:
   TILE      logical tile edge, 15 (reference) or 16
   BWD_MODE  _abi.BWD_REFERENCE (bug-compatible, default) or _abi.BWD_EXACT (true gradient)
@@ -13,6 +19,7 @@ Knobs the reference fixes at compile time (CR/config.h:15-18) are module attribu
 The number of language channels is taken from language.shape[1] (supported: 3, 15, 16, 32).
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -23,6 +30,36 @@ from ._lib import check, lib
 TILE = 15
 BWD_MODE = _abi.BWD_REFERENCE
 BINNING = _abi.BINNING_ELLIPSE
+
+_EMPTY = torch.empty(0)
+_ext = None
+_ext_checked = False
+
+
+def compiled_binding():
+    """The `_olsr_torch` module, or None when it is absent (not built) or OLSR_BINDING=ctypes.  OLSR_BINDING=torch
+    makes its absence an error."""
+    global _ext, _ext_checked
+    want = os.environ.get("OLSR_BINDING", "")
+    if want == "ctypes":
+        return None
+    if not _ext_checked:
+        _ext_checked = True
+        lib()  # libolsr.so first: a missing library must raise its own message, not a loader error
+        try:
+            from . import _olsr_torch
+            _ext = _olsr_torch
+        except ImportError as e:
+            _ext = None
+            compiled_binding.error = e
+    if _ext is None and want == "torch":
+        raise ImportError(f"OLSR_BINDING=torch but _olsr_torch is not importable: {getattr(compiled_binding, 'error', None)}; "
+                          "build it with `python -m online_lang_splatting_amd.build`")
+    return _ext
+
+
+def _t(x):
+    return _EMPTY if x is None else x
 
 
 def _stream(device):
@@ -99,6 +136,13 @@ def _forward(F, bg, means3D, colors, language, opacity, scales, rotations, scale
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # DGR/rasterize_points.cu:159-161
     _require_gpu(means3D, "means3D")
+    ext = compiled_binding()
+    if ext is not None:
+        tile, bwd_mode, binning = current_config()
+        return ext.forward(F, _t(bg), means3D, _t(colors), _t(language), _t(opacity), _t(scales), _t(rotations),
+                           float(scale_modifier), _t(cov3D_precomp), _t(viewmatrix), _t(projmatrix), _t(projmatrix_raw),
+                           float(tan_fovx), float(tan_fovy), int(image_height), int(image_width), _t(sh), int(degree),
+                           _t(campos), bool(prefiltered), bool(debug), tile, bwd_mode, binning)
     dev = means3D.device
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     with torch.cuda.device(dev):
@@ -147,10 +191,26 @@ def rasterize_language_gaussians(bg, means3D, colors, language, opacity, scales,
                     image_width, sh, degree, campos, prefiltered, debug)
 
 
+_GRAD_NAMES = ("dL_dmeans2D", "dL_dcolors", "dL_dlanguage", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
+               "dL_dscales", "dL_drotations", "dL_dtau", "dL_dtau_sum", "dL_dconic", "dL_ddepths")
+
+
 def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
               projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language, dL_dout_depth, sh,
               degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, want_internal=False, cfg=None):
     _require_gpu(means3D, "means3D")
+    ext = compiled_binding()
+    if ext is not None:
+        tile, bwd_mode, binning = cfg if cfg is not None else current_config()
+        g = ext.backward(F, _t(bg), means3D, radii, _t(colors), _t(language), _t(scales), _t(rotations),
+                         float(scale_modifier), _t(cov3D_precomp), _t(viewmatrix), _t(projmatrix), _t(projmatrix_raw),
+                         float(tan_fovx), float(tan_fovy), dL_dout_color, _t(dL_dout_language), _t(dL_dout_depth), _t(sh),
+                         int(degree), _t(campos), geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
+                         bool(want_internal), tile, bwd_mode, binning)
+        out = dict(zip(_GRAD_NAMES, g))
+        if not want_internal:
+            del out["dL_dconic"], out["dL_ddepths"]
+        return out
     dev = means3D.device
     P = means3D.shape[0]
     H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
@@ -231,6 +291,9 @@ def backward_all(F, *args, **kw):
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible, DGR/rasterize_points.cu:457-476."""
     _require_gpu(means3D, "means3D")
+    ext = compiled_binding()
+    if ext is not None:
+        return ext.mark_visible(means3D, _t(viewmatrix), _t(projmatrix))
     dev = means3D.device
     P = means3D.shape[0]
     present = torch.zeros(P, dtype=torch.bool, device=dev)

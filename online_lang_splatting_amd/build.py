@@ -106,9 +106,41 @@ def build(force=False, keep_temps=False, verbose=False, jobs=None):
     return LIB
 
 
+TORCH_EXT = os.path.join(HERE, "_olsr_torch.so")
+
+
+def build_torch_ext(force=False, verbose=False):
+    """g++ build of csrc/olsr_torch.cpp, the compiled torch binding of the `_C` surface (host-only C++ against the
+    torch headers; it links libolsr.so through an $ORIGIN rpath).  In-tree, like libolsr.so, so that it travels
+    with the snapshot.  Takes about a minute the first time (torch's headers)."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "olsr_torch.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "olsr.h"), os.path.abspath(__file__)]
+    if not force and not _stale(TORCH_EXT, deps):
+        return TORCH_EXT
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    tlib = ce.library_paths()[0]
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_olsr_torch",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += [f"-I{d}" for d in ce.include_paths()] + [f"-I{rocm}/include", f"-I{sysconfig.get_paths()['include']}"]
+    cmd += [src, "-o", TORCH_EXT, f"-L{tlib}", f"-L{HERE}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
+            "-ltorch", "-ltorch_python", "-l:libolsr.so", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError(f"g++ failed for olsr_torch.cpp:\n{p.stdout}\n{p.stderr[-6000:]}")
+    if verbose:
+        print(f"[olsr build] built {TORCH_EXT}", file=sys.stderr)
+    return TORCH_EXT
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--keep-temps", action="store_true")
     a = ap.parse_args()
     print(build(force=a.force, keep_temps=a.keep_temps, verbose=True))
+    print(build_torch_ext(force=a.force, verbose=True))

@@ -125,3 +125,32 @@ def test_scene_generator_is_deterministic():
     assert c.shs.shape == (500, 16, 3) and c.F == 0 and c.sh_degree == 3
     assert torch.allclose(a.language.norm(dim=1), torch.ones(1000), atol=1e-5)
     assert torch.allclose(a.rotations.norm(dim=1), torch.ones(1000), atol=1e-5)
+
+
+def test_compiled_torch_binding_loads_and_rejects_cpu_tensors():
+    """The `_C` functions of DGR/ext.cpp:15-21 as a compiled torch extension (csrc/olsr_torch.cpp): it imports, holds
+    the three entry points, reports the library's version, and — without a GPU — refuses a CPU tensor like the ctypes
+    binding does."""
+    from online_lang_splatting_amd import _C
+    ext = _C.compiled_binding()
+    assert ext is not None, getattr(_C.compiled_binding, "error", None)
+    for name in ("forward", "backward", "mark_visible", "version"):
+        assert callable(getattr(ext, name))
+    assert ext.version() == _C.lib().olsr_version().decode()
+    e = torch.empty(0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.forward(15, e, torch.zeros(4, 3), e, e, e, e, e, 1.0, e, e, e, e, 1.0, 1.0, 10, 10, e, 0, e, False, False,
+                    15, 0, 1)
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        ext.forward(15, e, torch.zeros(4, 2), e, e, e, e, e, 1.0, e, e, e, e, 1.0, 1.0, 10, 10, e, 0, e, False, False,
+                    15, 0, 1)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.mark_visible(torch.zeros(4, 3), e, e)
+
+
+def test_binding_selector(monkeypatch):
+    from online_lang_splatting_amd import _C
+    monkeypatch.setenv("OLSR_BINDING", "ctypes")
+    assert _C.compiled_binding() is None
+    monkeypatch.setenv("OLSR_BINDING", "torch")
+    assert _C.compiled_binding() is not None

@@ -56,6 +56,29 @@ def test_language_rasterizer_autograd_matches_c_level(hip, oracle):
     oracle.release(fo["geom"])
 
 
+@pytest.mark.parametrize("F", [0, 15])
+def test_compiled_and_ctypes_bindings_agree_bit_for_bit(hip, F, monkeypatch):
+    """The five `_C` functions through csrc/olsr_torch.cpp and through ctypes reach the same library calls: every
+    output, state-dependent gradient and mark_visible mask must be identical."""
+    dev = torch.device(DEV)
+    sc = make_scene(5000, 200, 150, F, seed=21)
+    out = {}
+    for binding in ("torch", "ctypes"):
+        monkeypatch.setenv("OLSR_BINDING", binding)
+        assert (hip.compiled_binding() is not None) == (binding == "torch")
+        fw, gr = run_backend(hip, sc, dev, 9, 15, _abi.BWD_REFERENCE)
+        vis = hip.mark_visible(sc.means3D.to(dev), sc.camera.world_view_transform.to(dev),
+                               sc.camera.full_proj_transform.to(dev))
+        out[binding] = (fw, gr, vis)
+    (fa, ga, va), (fb, gb, vb) = out["torch"], out["ctypes"]
+    assert fa["R"] == fb["R"] and torch.equal(va, vb) and va.dtype == torch.bool
+    for k in ("color", "language", "depth", "opacity", "radii", "n_touched"):
+        assert (fa[k] is None and fb[k] is None) or torch.equal(fa[k], fb[k]), k
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+
+
 class _Model:
     """The attributes of GaussianModel that gaussian_renderer.render touches."""
 
