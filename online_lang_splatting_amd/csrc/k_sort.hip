@@ -217,7 +217,7 @@ constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4, FSF_EMIT_TOTALS
 constexpr int FS_ALWAYS_RESIDENT_BLOCKS = 256;  // one 1024-thread block per CU fits whatever its LDS size
 
 template <int DB, int KPT>
-__global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__ keys_in,
+__global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num_sgpr(80))) void sort_pass_kernel(const u32* __restrict__ keys_in,
                                                          const u32* __restrict__ vals_in, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int shift,
                                                          const u32* __restrict__ ghist, u16* status, u32* ticket,
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(FS_T) void sort_pass_kernel(const u32* __restrict__
   constexpr int CHUNK = FS_T * KPT;
   constexpr int C = (int)NB / 8;   // 16-byte status granules per block row
   constexpr int RPB = FS_T / C;    // predecessor rows read per batch (one granule per thread)
-  constexpr int U = 8;             // batches in flight per thread: one round covers 8 * RPB >= 256 predecessors
+  constexpr int U = (DB <= 6) ? 4 : 8;  // batches in flight per thread: one round covers U * RPB >= 256 predecessors
   extern __shared__ __attribute__((aligned(16))) u32 fs_smem[];
   u32* cnt = fs_smem;              // [16][NB] per-wave digit counts -> per-wave local starts; later the look-back partials
   u32* dstart = cnt + FS_W * NB;   // [NB + 1] local start of digit d inside the block (+ sentinel)
@@ -494,7 +494,9 @@ static void launch_pass_k(int kpt, const PassArgs& a, hipStream_t st) {
   switch (kpt) {
     case 2: launch_pass_t<DB, 2>(a, st); break;
     case 4: launch_pass_t<DB, 4>(a, st); break;
-    default: launch_pass_t<DB, 8>(a, st); break;
+    case 8: launch_pass_t<DB, 8>(a, st); break;
+    case 12: launch_pass_t<DB, 12>(a, st); break;
+    default: launch_pass_t<DB, 16>(a, st); break;
   }
 }
 
@@ -507,7 +509,7 @@ int fused_sort_digit_bits(int bits, int* passes_out) {
 }
 
 bool fused_sort_applicable(int64_t n_host, int bits) {
-  return n_host > 0 && bits <= 32 && sort_plan(n_host).nblk <= FUSED_SORT_MAX_BLOCKS;
+  return n_host > 0 && bits <= 32 && fused_sort_fits(n_host);
 }
 
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
@@ -534,13 +536,12 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
 
 // Sorts (key, val) pairs on the low `bits` bits of key, ceil(bits / 8) passes.  hist / status / tickets must have been
 // zeroed and hist filled by launch_sort_hist.  Returns 0 if the result ends in (key_a, val_a), 1 if in (key_b, val_b).
-int launch_sort_fused(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
-                      const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
+int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host, const int32_t* n_dev, int bits,
+                      bool vals_in_identity, const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
                       const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st) {
   if (n_host <= 0) return 0;
   int passes;
   const int db = fused_sort_digit_bits(bits, &passes);
-  const SortPlan plan = sort_plan(n_host);
   const size_t NB = (size_t)1 << db;
   u32 *kin = b.key_a, *kout = b.key_b, *vin = b.val_a, *vout = b.val_b;
   int where = 0;

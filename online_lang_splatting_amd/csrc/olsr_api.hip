@@ -193,7 +193,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
     // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
     if (!legacy && fused_sort_applicable(s.P, 32)) {
-      launch_sort_fused(sb, s.P, nullptr, 32, false, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
+      launch_sort_fused(sb, sort_plan(s.P), s.P, nullptr, 32, false, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
                         g.tiles_touched, g.emit_status, st);
     } else {
       launch_radix_sort(sb, s.P, nullptr, 32, false, st);
@@ -229,10 +229,11 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     int tpasses = 0;
     const int tdb = fused_sort_digit_bits(tbits, &tpasses);
     const bool fused_tiles = !legacy && fused_sort_applicable(n_host, tbits);
+    const SortPlan tile_plan = sort_plan(n_host, /*n_is_capacity=*/!sync_mode);
     // synchronisation words of the binning buffer that this frame uses (zeroed by the emission kernel)
     const int64_t bin_sync_words =
         (b.tile_status - b.sync_words) +
-        (fused_tiles ? ((int64_t)tpasses * sort_plan(n_host).nblk * ((int64_t)1 << tdb) + 1) / 2 : 0);  // 16-bit words
+        (fused_tiles ? ((int64_t)tpasses * tile_plan.nblk * ((int64_t)1 << tdb) + 1) / 2 : 0);  // 16-bit words
     launch_emit(s, d, g, b, bin_sync_words, st);
     STAGE("emit");
     if (n_host > 0) {
@@ -242,7 +243,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       if (fused_tiles) {
         launch_sort_hist(b.key_a, n_host, n_dev, tbits, b.tile_hist, nullptr, st);
         // the first pass also clears the liveness flags, the last one derives the tile ranges
-        launch_sort_fused(sb, n_host, n_dev, tbits, true, b.tile_hist, b.tile_status, b.tickets, b.flags, im.ranges,
+        launch_sort_fused(sb, tile_plan, n_host, n_dev, tbits, true, b.tile_hist, b.tile_status, b.tickets, b.flags, im.ranges,
                           nullptr, nullptr, st);
       } else {
         const int where = launch_radix_sort(sb, n_host, n_dev, tbits, true, st);

@@ -68,13 +68,13 @@ int fused_sort_digit_bits(int bits, int* passes_out);
 // digit totals of all passes (hist[pass][256], zeroed beforehand); optionally the frame's bookkeeping
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
                       const FusedHouse* house, hipStream_t st);
-// stable sort on the low `bits` bits; status: [passes][sort_plan(n_host).nblk][1 << digit bits] zeroed 16-bit words, tickets:
+// stable sort on the low `bits` bits; status: [passes][plan.nblk][1 << digit bits] zeroed 16-bit words (plan = sort_plan(n_host, ...)), tickets:
 // one zeroed word per pass.  flags_clear (with vals_in_identity): byte i is cleared for every element; ranges: the
 // last pass derives per-key [start, end) (keys must then be tile ids).  Returns where the result ends (0: a, 1: b);
 // the sorted keys of the LAST pass are not written.  emit_totals (depth sort): the last pass adds every value's
 // instance count (inst_count[v]) to emit_totals[final position / EMIT_CHUNK] (zeroed beforehand).
-int launch_sort_fused(const SortBuffers& b, int64_t n_host, const int32_t* n_dev, int bits, bool vals_in_identity,
-                      const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
+int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host, const int32_t* n_dev, int bits,
+                      bool vals_in_identity, const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
                       const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
 void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_launches);
 // the same totals for a depth order produced by the multi-kernel passes

@@ -30,30 +30,59 @@ constexpr int SCAN_CHUNK = 4096;
 inline int sort_blocks(long long n) { return (int)((n + SORT_CHUNK - 1) / SORT_CHUNK); }
 inline int scan_blocks(long long n) { return (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK); }
 
-// Fused sort passes (k_sort.hip): one 1024-thread block per chunk of 1024 * kpt keys, kpt in {2, 4, 8} chosen so that
-// a P- or R-sized sort has a few hundred blocks (every block reads the digit counts of all its predecessors).
+// Fused sort passes (k_sort.hip): one 1024-thread block per chunk of 1024 * kpt keys.  The runtime keeps ONE such block
+// per CU, so a pass runs in ceil(nblk / 256) rounds and a round costs about (kpt + 1.5) x 2 us (measured on
+// the 2.7 M-instance frame: 24 us at kpt = 12, 29 us at kpt = 16, i.e. about kpt + 11 us); kpt is the candidate that minimises rounds x (kpt + 11) — for the 2.7 M instances of the
+// headline frame one round of 220 blocks at kpt = 12 instead of 1.3 rounds at kpt = 8.
 struct SortPlan {
   int kpt;
   int nblk;
 };
 constexpr int FUSED_SORT_THREADS = 1024;
 constexpr int FUSED_SORT_MAX_BLOCKS = 4096;  // beyond: the multi-kernel passes (histogram, device-wide scan, scatter)
-inline int sort_plan_max_blocks() {  // (OLSR_SORT_MAX_BLOCKS: tuning experiments only)
-  static const int v = [] {
-    const char* e = std::getenv("OLSR_SORT_MAX_BLOCKS");
-    const int x = e ? std::atoi(e) : 0;
-    return x > 0 ? x : 512;
-  }();
-  return v;
+// (the two environment knobs exist for tuning experiments and for the tests that walk every kernel instantiation and
+//  the multi-round ticket order on small inputs; they are read at every call, a forward and its backward see the same)
+inline int sort_plan_resident_blocks() {
+  const char* e = std::getenv("OLSR_SORT_RESIDENT");
+  const int x = e ? std::atoi(e) : 0;
+  return x > 0 ? x : 256;
 }
-inline SortPlan sort_plan(long long n) {
-  int kpt = 2;
-  while (kpt < 8 && (n + 1024LL * kpt - 1) / (1024LL * kpt) > sort_plan_max_blocks()) kpt *= 2;
-  return SortPlan{kpt, (int)((n + 1024LL * kpt - 1) / (1024LL * kpt))};
+inline int sort_plan_forced_kpt() {
+  const char* e = std::getenv("OLSR_SORT_KPT");
+  const int x = e ? std::atoi(e) : 0;
+  return (x == 2 || x == 4 || x == 8 || x == 12 || x == 16) ? x : 0;
 }
+// n_is_capacity: n bounds a count that is only known on the device (olsr_forward_async); the rounds are then estimated
+// for 85 % of it — callers size a capacity with headroom, blocks past the real count exit at once, and the choice only
+// moves time, never the result.
+inline SortPlan sort_plan(long long n, bool n_is_capacity = false) {
+  static const int cand[5] = {2, 4, 8, 12, 16};
+  const long long res = sort_plan_resident_blocks();
+  const long long n_est = n_is_capacity ? (n * 85 + 99) / 100 : n;
+  int best = sort_plan_forced_kpt();
+  if (best == 0) {
+    double best_cost = 0.0;
+    for (int i = 0; i < 5; ++i) {
+      const long long chunk = 1024LL * cand[i];
+      if ((n + chunk - 1) / chunk > FUSED_SORT_MAX_BLOCKS && i < 4) continue;
+      const long long nb = (n_est + chunk - 1) / chunk;
+      const double cost = (double)((nb + res - 1) / res) * (cand[i] + 11.0);
+      if (best == 0 || cost < best_cost) {
+        best = cand[i];
+        best_cost = cost;
+      }
+    }
+  }
+  return SortPlan{best, (int)((n + 1024LL * best - 1) / (1024LL * best))};
+}
+inline bool fused_sort_fits(long long n) { return (n + 16383) / 16384 <= FUSED_SORT_MAX_BLOCKS; }
+// status words reserved for a sort of n keys: whatever kpt the plan picks (it may differ between a sized and a
+// capacity-bounded launch of the same n), the rows of the smallest chunk cover it
 inline size_t fused_status_words(long long n, int passes) {
-  const SortPlan p = sort_plan(n);
-  return (p.nblk <= FUSED_SORT_MAX_BLOCKS) ? (size_t)passes * (size_t)p.nblk * 128 : 0;  // 256 16-bit counts per row
+  if (!fused_sort_fits(n)) return 0;
+  long long nb = (n + 2047) / 2048;
+  if (nb > FUSED_SORT_MAX_BLOCKS) nb = FUSED_SORT_MAX_BLOCKS;
+  return (size_t)passes * (size_t)nb * 128;  // 256 16-bit counts per row
 }
 // single-pass scans (emission offsets, row compaction): elements per 1024-thread block
 constexpr int EMIT_CHUNK = 1024;

@@ -273,6 +273,18 @@ def test_multi_kernel_sort_fallback(hip, oracle, monkeypatch):
     _check(hip, oracle, make_scene(6000, 200, 150, 15, seed=73), seed=4)
 
 
+@pytest.mark.parametrize("kpt", [2, 4, 8, 12, 16])
+def test_every_sort_pass_instantiation(hip, oracle, monkeypatch, kpt):
+    """The radix passes pick their keys-per-thread from the input size (olsr_state.h: sort_plan); OLSR_SORT_KPT pins it,
+    so that every instantiation sorts the same frame — at kpt = 2 its 0.6 M instances need more than 256 blocks, which
+    also exercises the ticket order of a pass that is not resident at once."""
+    monkeypatch.setenv("OLSR_SORT_KPT", str(kpt))
+    sc = make_scene(60000, 640, 480, 15, seed=76)
+    _check(hip, oracle, sc, seed=6)
+    if kpt in (2, 16):
+        _check(hip, oracle, make_scene(2500, 160, 120, 0, seed=77), seed=7, tile=16)
+
+
 def test_repeated_backward_on_one_forward(hip):
     """The row compaction's look-back state is re-armed by the kernel itself: a backward may be repeated on the same
     forward (autograd's retain_graph, or the test above) and must give the same bits every time."""
