@@ -8,7 +8,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libolsr.so")
+# (OLSR_LIB: another build of the same library, for kernel experiments; the compiled torch binding always links libolsr.so)
+LIB_PATH = os.environ.get("OLSR_LIB") or os.path.join(_HERE, "libolsr.so")
 
 # every symbol include/olsr.h declares
 EXPORTS = (

@@ -311,19 +311,12 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 }
 
 // ------------------------------------------------------------------------------- emission
-// cub::DeviceScan::InclusiveSum + duplicateWithKeys (CR/rasterizer_impl.cu:451, 70-111) in ONE kernel.  The depth
-// half of the reference's key is implied by the emission order; only the tile id is written.
-//   scan_emit_kernel  one thread per depth rank.  The instance count of the Gaussian comes with its emission record
-//                    (one 16-byte gather in depth order); the block scans its 1024 counts and adds the totals of all
-//                    earlier blocks, which the last pass of the depth sort accumulated while it scattered the
-//                    Gaussians to their depth ranks — no separate scan launches, no offsets array, no waiting.  A Gaussian with <= EMIT_BIG instances is then written by its lane
-//                    (consecutive ranks own adjacent output runs), larger ones go to a work list (one aggregated
-//                    atomic per block; the list order influences no result);
-//   emit_big_kernel  persistent grid, one wave per listed Gaussian: near splats cover hundreds to
-//                    thousands of tiles and cluster at the front of the depth order, so they are dealt
-//                    to all waves of the chip and written with coalesced stores.
+// cub::DeviceScan::InclusiveSum + duplicateWithKeys (CR/rasterizer_impl.cu:451, 70-111) in two kernels (below:
+// "output-balanced emission").  The depth half of the reference's key is implied by the emission order; only the
+// tile id is written.  A first formulation gave every Gaussian to one lane (up to 32 instances) or one wave (more):
+// a wave waited for its largest member (5.4 instances on average) and the wave-per-Gaussian kernel paid a latency
+// chain per item — 62 us for the 2.7 M instances of the headline frame, 41 us now.
 constexpr u32 EMIT_BIG = OLSR_BIG_FOOTPRINT;
-constexpr int EMIT_BIG_BLOCKS = 512;
 constexpr int EMIT_THREADS = EMIT_CHUNK;  // 1024: one list atomic per 1024 Gaussians
 
 // Block totals of a single-pass scan: two 32-bit words per block, {READY | total, READY | inclusive prefix}, zeroed
@@ -369,12 +362,34 @@ __device__ __forceinline__ u32 lb_block_exclusive(u32* status, u32 b, u32 total,
   return excl;
 }
 
-template <int TILE>
-__global__ __launch_bounds__(EMIT_THREADS) void scan_emit_kernel(
-    int P, const u32* __restrict__ order, const float4* __restrict__ emit_rec, int ellipse, int W, int H, int gx, int gy,
-    int32_t* __restrict__ counters, const u32* __restrict__ block_totals, uint4* __restrict__ bin_sync,
-    int bin_sync_quads,
-    u32* __restrict__ keys, u32* __restrict__ inst_gid, u32* __restrict__ inst_start, uint4* __restrict__ big_list) {
+// ---- output-balanced emission ------------------------------------------------------------------------------
+//   emit_offsets_kernel   one thread per depth rank: first instance of every rank (rank_off), of every block of 1024
+//                         ranks (blk_base), inst_start, the big / mid lists for the backward's row sums, and the
+//                         binning buffer's synchronisation words.  The block totals come from the depth sort's last
+//                         pass, so no block waits for another one;
+//   emit_balanced_kernel  block b writes instances [b * EB_OUT, (b + 1) * EB_OUT): it finds the depth ranks that own
+//                         them (two counting searches over the monotone blk_base / rank_off), expands Gaussians to
+//                         tile rows (a table in LDS), evaluates one row span per thread, and writes keys / inst_gid
+//                         in output order — a thread its own short row, a wave together a long one.  Every block has
+//                         the same amount of output whatever the footprint mix (near splats cover hundreds to
+//                         thousands of tiles and cluster at the front of the depth order); a Gaussian that straddles
+//                         two blocks has its row spans evaluated by both.
+#ifndef OLSR_EB_OUT
+#define OLSR_EB_OUT 2048
+#endif
+#ifndef OLSR_EB_T
+#define OLSR_EB_T 256
+#endif
+constexpr int EB_T = OLSR_EB_T;
+constexpr int EB_OUT = OLSR_EB_OUT;
+constexpr int EB_ROWCAP = 16 * EB_T;   // rows per fill of the row -> Gaussian table
+constexpr u32 EB_SHORT_ROW = 8;   // rows up to this many tiles are written by their own thread
+
+__global__ __launch_bounds__(EMIT_THREADS) void emit_offsets_kernel(
+    int P, const u32* __restrict__ order, const u32* __restrict__ inst_count, int32_t* __restrict__ counters,
+    const u32* __restrict__ block_totals, uint4* __restrict__ bin_sync, int bin_sync_quads,
+    u32* __restrict__ rank_off, u32* __restrict__ win_start, u32* __restrict__ inst_start,
+    uint4* __restrict__ big_list) {
   __shared__ u32 s_wsum[EMIT_THREADS / 64 + 1];
   // the words the tile sort and the row compaction synchronise through live in the binning buffer, which exists only
   // from here on (the drop-in entry allocates it after the instance count is known)
@@ -385,13 +400,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void scan_emit_kernel(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = (int)(b * EMIT_THREADS + threadIdx.x);
   u32 g = 0, n = 0;
-  float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r < P) {
     g = order[r];
-    r1 = emit_rec[2 * (size_t)g + 1];
-    n = __float_as_uint(r1.w);  // instances of the Gaussian; 0 when culled
+    n = inst_count[g];  // 0 when culled
   }
-  // block-wide exclusive scan of n
   u32 incl = n;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -400,16 +412,11 @@ __global__ __launch_bounds__(EMIT_THREADS) void scan_emit_kernel(
   }
   if (lane == 63) s_wsum[w] = incl;
   __syncthreads();
-  u32 wbase = 0, total = 0;
+  u32 wbase = 0;
 #pragma unroll
-  for (int i = 0; i < EMIT_THREADS / 64; ++i) {
-    const u32 c = s_wsum[i];
-    wbase += (i < w) ? c : 0u;
-    total += c;
-  }
+  for (int i = 0; i < EMIT_THREADS / 64; ++i) wbase += (i < w) ? s_wsum[i] : 0u;
   __syncthreads();
-  // first instance of this block = instances of all earlier blocks: the last depth-sort pass left every block's
-  // total behind (emit_totals), so no block waits for another one here
+  // first instance of this block = instances of all earlier blocks (left behind by the depth sort's last pass)
   u32 pre = 0;
   for (u32 j = threadIdx.x; j < b; j += EMIT_THREADS) pre += block_totals[j];
 #pragma unroll
@@ -419,121 +426,196 @@ __global__ __launch_bounds__(EMIT_THREADS) void scan_emit_kernel(
   u32 base = 0;
 #pragma unroll
   for (int i = 0; i < EMIT_THREADS / 64; ++i) base += s_wsum[i];
-  (void)total;
   const u32 off = base + wbase + incl - n;
+  if (r < P) rank_off[r] = off;
   if (n > 0) {
     inst_start[g] = off;
-    if (n <= EMIT_BIG) {
-      const float4 r0 = emit_rec[2 * (size_t)g];
-      const int rad = __float_as_int(r1.z);
-      const Rect rc = get_rect<TILE>(r0.x, r0.y, rad, gx, gy);
-      u32 o = off;
-      if (!ellipse) {
-        for (int y = rc.y0; y < rc.y1; y++)
-          for (int x = rc.x0; x < rc.x1; x++) {
-            keys[o] = (u32)(y * gx + x);
-            inst_gid[o] = g;
-            o++;
-          }
-      } else {
-        // exact binning: the same row spans preprocess counted (same function, same inputs)
-        const CullEllipse e = cull_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, rad);
-        int ya, yb;
-        cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
-        for (int y = ya; y < yb; y++) {
-          int xa, xb;
-          cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
-          for (int x = xa; x < xb; x++) {
-            keys[o] = (u32)(y * gx + x);
-            inst_gid[o] = g;
-            o++;
-          }
-        }
-      }
-    }
+    // this rank owns the first instance of every output window [k * EB_OUT, ...) that starts inside its run
+    for (u32 k = (off + (u32)EB_OUT - 1u) / (u32)EB_OUT; k * (u32)EB_OUT < off + n; ++k) win_start[k] = (u32)r;
   }
   const bool is_big = n > EMIT_BIG;
   const u32 slot = block_list_slot(is_big, &counters[5]);
   if (is_big) big_list[slot] = make_uint4(g, off, n, 0u);
-  // second list, from the back of the same array: medium footprints, for the backward's row sums
+  // second list, from the back of the same array: medium footprints
   const bool is_mid = n > OLSR_MID_FOOTPRINT && n <= EMIT_BIG;
   const u32 mslot = block_list_slot(is_mid, &counters[4]);
   if (is_mid) big_list[(u32)P - 1u - mslot] = make_uint4(g, off, n, 0u);
 }
 
-template <int TILE>
-__global__ __launch_bounds__(256) void emit_big_kernel(const uint4* __restrict__ big_list,
-                                                       const float4* __restrict__ emit_rec, int ellipse, int W, int H,
-                                                       int gx, int gy, const int32_t* __restrict__ counters,
-                                                       u32* __restrict__ keys, u32* __restrict__ inst_gid) {
-  if (counters[2] != 0) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-  const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-  const int count = counters[5];
-  if (wave >= count) return;
-  // the next item's descriptor and record are fetched while the current one is written
-  uint4 it = big_list[wave];
-  float4 r0 = emit_rec[2 * (size_t)it.x], r1 = emit_rec[2 * (size_t)it.x + 1];
-  for (int item = wave; item < count; item += nwaves) {
-    const u32 g = it.x, off = it.y, n = it.z;
-    const float4 c0 = r0, c1 = r1;
-    {
-      const int nxt = item + nwaves;
-      it = big_list[nxt < count ? nxt : item];
-      r0 = emit_rec[2 * (size_t)it.x];
-      r1 = emit_rec[2 * (size_t)it.x + 1];
-    }
-    const int rad = __float_as_int(c1.z);
-    const Rect rc = get_rect<TILE>(c0.x, c0.y, rad, gx, gy);
-    if (!ellipse) {
-      const u32 wrect = (u32)(rc.x1 - rc.x0);
-      for (u32 t = (u32)lane; t < n; t += 64) {
-        const u32 yy = t / wrect, xx = t - yy * wrect;
-        keys[off + t] = (u32)((rc.y0 + (int)yy) * gx + (rc.x0 + (int)xx));
-        inst_gid[off + t] = g;
-      }
-      continue;
-    }
-    const CullEllipse e = cull_setup(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, rad);
-    int y0, y1;
-    cull_rows<TILE>(e, rc.y0, rc.y1, y0, y1);
-    // lane l evaluates rows y0 + l, y0 + l + 64, ...; a wave scan turns the spans into offsets
-    u32 run = 0;
-    for (int yb = y0; yb < y1; yb += 64) {
-      const int y = yb + lane;
-      int xa = 0, xb = 0;
-      if (y < y1) cull_row_span<TILE>(e, rc.x0, rc.x1, y, W, H, xa, xb);
-      const u32 cnt = (u32)(xb - xa);
-      u32 incl = cnt;
+// exclusive scan of v over the EB_T threads of the block; *total = the sum (two barriers; s_w: [EB_T / 64])
+__device__ __forceinline__ u32 eb_scan(u32 v, u32* s_w, u32* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u32 incl = v;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const u32 v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  __syncthreads();  // (s_w may still be read from the previous use)
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  u32 wb = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < EB_T / 64; ++i) {
+    const u32 c = s_w[i];
+    wb += (i < w) ? c : 0u;
+    tot += c;
+  }
+  *total = tot;
+  return wb + incl - v;
+}
+
+// what a row's thread needs about its Gaussian: the ellipse of cull_setup, the rect's columns, where the rows start
+struct EbGauss {
+  float4 e0;  // px py b inv_a
+  float4 e1;  // A det_lo xstar ystar
+  uint4 m;    // exact, x0 | x1 << 16, first row, first instance
+};
+
+template <int TILE>
+__global__ __launch_bounds__(EB_T) void emit_balanced_kernel(
+    int P, const u32* __restrict__ order, const u32* __restrict__ rank_off, const u32* __restrict__ win_start,
+    const float4* __restrict__ emit_rec, int ellipse, int W, int H, int gx, const int32_t* __restrict__ counters,
+    u32* __restrict__ keys, u32* __restrict__ inst_gid) {
+  __shared__ EbGauss s_gs[EB_T];
+  __shared__ u32 s_g[EB_T], s_first[EB_T], s_rowoff[EB_T];
+  __shared__ uint8_t s_owner[EB_ROWCAP];
+  __shared__ u32 s_w[EB_T / 64];
+  __shared__ u32 s_flag;
+  if (counters[2] != 0) return;
+  const u32 R = (u32)counters[1];
+  const u32 o0 = blockIdx.x * (u32)EB_OUT;
+  if (o0 >= R) return;
+  const u32 o1 = min(o0 + (u32)EB_OUT, R);
+  const int tid = threadIdx.x, lane = tid & 63;
+
+  // the rank that owns instance o0 (left behind by emit_offsets_kernel)
+  const int r_lo = (int)win_start[blockIdx.x];
+  auto load_rank = [&](int r, u32& off, u32& end, u32& g) {
+    off = 0; end = 0; g = 0;
+    if (r < P) {
+      off = rank_off[r];
+      end = (r + 1 < P) ? rank_off[r + 1] : R;
+      g = order[r];
+    }
+  };
+  u32 off, end, g;
+  load_rank(r_lo + tid, off, end, g);
+
+  for (int rb0 = r_lo;; rb0 += EB_T) {
+    // ---- one batch of EB_T depth ranks
+    const int r = rb0 + tid;
+    const bool use = end > off && off < o1 && end > o0;
+    u32 nrows = 0;
+    if (use) {
+      const float4 r0 = emit_rec[2 * (size_t)g], r1 = emit_rec[2 * (size_t)g + 1];
+      const u32 yw = __float_as_uint(r1.z), xw = __float_as_uint(r1.w);
+      nrows = yw >> 16;
+      EbGauss q;
+      q.m = make_uint4(0u, xw, yw & 0xFFFFu, off);
+      q.e0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      q.e1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ellipse) {
+        const CullEllipse e = cull_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, 0);
+        q.e0 = make_float4(e.px, e.py, e.b, e.inv_a);
+        q.e1 = make_float4(e.A, e.det_lo, e.xstar, e.ystar);
+        q.m.x = e.exact ? 1u : 0u;
       }
-      const u32 total = __shfl(incl, 63);
-      const u32 excl = incl - cnt;
-      const int rows = min(64, y1 - yb);
-      for (int rr = 0; rr < rows; ++rr) {  // the wave writes row rr's span together
-        const u32 c_r = __shfl(cnt, rr), e_r = __shfl(excl, rr);
-        const int xa_r = __shfl(xa, rr);
-        for (u32 t = (u32)lane; t < c_r; t += 64) {
-          keys[off + run + e_r + t] = (u32)((yb + rr) * gx + xa_r + (int)t);
-          inst_gid[off + run + e_r + t] = g;
+      s_gs[tid] = q;
+    }
+    s_g[tid] = g;
+    if (tid == EB_T - 1) s_flag = (r < P && end < o1) ? 1u : 0u;  // ranks beyond this batch still own instances
+    // the next batch's ranks are fetched while this one is expanded
+    u32 off_n, end_n, g_n;
+    load_rank(r + EB_T, off_n, end_n, g_n);
+    u32 total_rows;
+    const u32 rowoff = eb_scan(nrows, s_w, &total_rows);
+    s_rowoff[tid] = rowoff;
+    __syncthreads();
+    const bool more = s_flag != 0u;
+
+    u32 carry = 0;
+    for (u32 sbase = 0; sbase < total_rows; sbase += EB_ROWCAP) {
+      // row -> Gaussian table for rows [sbase, sbase + EB_ROWCAP) of the batch
+      {
+        const u32 k0 = max(rowoff, sbase), k1 = min(rowoff + nrows, sbase + (u32)EB_ROWCAP);
+        for (u32 k = k0; k < k1; ++k) s_owner[k - sbase] = (uint8_t)tid;
+      }
+      __syncthreads();
+      const u32 send = min(total_rows, sbase + (u32)EB_ROWCAP);
+      for (u32 rbase = sbase; rbase < send; rbase += EB_T) {
+        // ---- one row per thread
+        const u32 idx = rbase + (u32)tid;
+        const bool live = idx < send;
+        int owner = 0;
+        u32 cnt = 0, key0 = 0;
+        if (live) {
+          owner = (int)s_owner[idx - sbase];
+          const EbGauss q = s_gs[owner];
+          const int y = (int)q.m.z + (int)(idx - s_rowoff[owner]);
+          int xa = (int)(q.m.y & 0xFFFFu), xb = (int)(q.m.y >> 16);
+          if (ellipse) {
+            // exact binning: the same row spans preprocess counted (same function, same inputs)
+            CullEllipse e;
+            e.px = q.e0.x; e.py = q.e0.y; e.b = q.e0.z; e.inv_a = q.e0.w;
+            e.A = q.e1.x; e.det_lo = q.e1.y; e.xstar = q.e1.z; e.ystar = q.e1.w;
+            e.ymax = 0.f;
+            e.exact = q.m.x != 0u;
+            cull_row_span<TILE>(e, xa, xb, y, W, H, xa, xb);
+          }
+          cnt = (u32)(xb - xa);
+          key0 = (u32)(y * gx + xa);
+        }
+        u32 chunk_total;
+        const u32 S = carry + eb_scan(cnt, s_w, &chunk_total);
+        carry += chunk_total;
+        // a row's first instance = its Gaussian's first instance + the instances of the Gaussian's earlier rows
+        if (live && idx == s_rowoff[owner]) s_first[owner] = S;
+        __syncthreads();
+        u32 out = 0, gid = 0;
+        if (live) {
+          out = s_gs[owner].m.w + (S - s_first[owner]);
+          gid = s_g[owner];
+        }
+        // the part of the row inside this block's window
+        const u32 jlo = max(out, o0), jhi = min(out + cnt, o1);
+        const bool inside = live && jlo < jhi;
+        if (inside && cnt <= EB_SHORT_ROW) {
+          for (u32 j = jlo; j < jhi; ++j) {
+            keys[j] = key0 + (j - out);
+            inst_gid[j] = gid;
+          }
+        }
+        u64 longrows = ballot(inside && cnt > EB_SHORT_ROW);
+        while (longrows) {  // the wave writes a long row together
+          const int src = (int)__builtin_ctzll(longrows);
+          longrows &= longrows - 1;
+          const u32 lo_s = (u32)__shfl((int)jlo, src), hi_s = (u32)__shfl((int)jhi, src);
+          const u32 out_s = (u32)__shfl((int)out, src), key_s = (u32)__shfl((int)key0, src);
+          const u32 gid_s = (u32)__shfl((int)gid, src);
+          for (u32 j = lo_s + (u32)lane; j < hi_s; j += 64) {
+            keys[j] = key_s + (j - out_s);
+            inst_gid[j] = gid_s;
+          }
         }
       }
-      run += total;
+      __syncthreads();  // (s_owner is refilled)
     }
+    if (!more) break;
+    off = off_n;
+    end = end_n;
+    g = g_n;
+    __syncthreads();  // (s_gs / s_g / s_rowoff are rewritten by the next batch)
   }
 }
 
 // per-emission-block instance totals for a depth order that did not come from the fused sort (multi-kernel passes)
 __global__ __launch_bounds__(EMIT_THREADS) void emit_totals_kernel(int P, const u32* __restrict__ order,
-                                                                   const float4* __restrict__ emit_rec,
+                                                                   const u32* __restrict__ inst_count,
                                                                    u32* __restrict__ totals) {
   __shared__ u32 s_w[EMIT_THREADS / 64];
   const int r = (int)(blockIdx.x * EMIT_THREADS + threadIdx.x);
-  u32 n = (r < P) ? __float_as_uint(emit_rec[2 * (size_t)order[r] + 1].w) : 0u;
+  u32 n = (r < P) ? inst_count[order[r]] : 0u;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
@@ -544,32 +626,34 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_totals_kernel(int P, const 
     totals[blockIdx.x] = t;
   }
 }
-void launch_emit_totals(const uint32_t* order, int P, const float4* emit_rec, uint32_t* emit_totals, hipStream_t st) {
+void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st) {
   if (P <= 0) return;
-  emit_totals_kernel<<<(P + EMIT_THREADS - 1) / EMIT_THREADS, EMIT_THREADS, 0, st>>>(P, order, emit_rec, emit_totals);
+  emit_totals_kernel<<<(P + EMIT_THREADS - 1) / EMIT_THREADS, EMIT_THREADS, 0, st>>>(P, order, inst_count, emit_totals);
+}
+
+template <int TILE>
+static void launch_emit_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                          int64_t bin_sync_words, int64_t n_host, hipStream_t st) {
+  const int nb = (s.P + EMIT_THREADS - 1) / EMIT_THREADS;
+  const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
+  const u32* totals = g.emit_status;  // per-block instance totals, accumulated by the depth sort's last pass
+  uint4* bsync = reinterpret_cast<uint4*>(b.sync_words);
+  const int quads = (int)((bin_sync_words + 3) / 4);
+  u32* rank_off = g.key_b;   // the depth keys are dead once the order exists
+  u32* win_start = b.key_b;  // the tile sort's second key buffer is not in use yet
+  emit_offsets_kernel<<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.tiles_touched, g.counters, totals, bsync, quads,
+                                                   rank_off, win_start, g.inst_start, g.big_list);
+  const int64_t nblk = (n_host + EB_OUT - 1) / EB_OUT;
+  if (nblk > 0)
+    emit_balanced_kernel<TILE><<<(int)nblk, EB_T, 0, st>>>(s.P, g.depth_order, rank_off, win_start, g.emit_rec,
+                                                           ellipse, d.W, d.H, d.gx, g.counters, b.key_a, b.inst_gid);
 }
 
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                 int64_t bin_sync_words, hipStream_t st) {
+                 int64_t bin_sync_words, int64_t n_host, hipStream_t st) {
   if (s.P <= 0) return;
-  const int nb = (s.P + EMIT_THREADS - 1) / EMIT_THREADS;
-  const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
-  const u32* status = g.emit_status;  // per-block instance totals, accumulated by the depth sort's last pass
-  uint4* bsync = reinterpret_cast<uint4*>(b.sync_words);
-  const int quads = (int)((bin_sync_words + 3) / 4);
-  if (d.tile == 15) {
-    scan_emit_kernel<15><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
-                                                      g.counters, status, bsync, quads, b.key_a,
-                                                      b.inst_gid, g.inst_start, g.big_list);
-    emit_big_kernel<15><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
-                                                         g.counters, b.key_a, b.inst_gid);
-  } else {
-    scan_emit_kernel<16><<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
-                                                      g.counters, status, bsync, quads, b.key_a,
-                                                      b.inst_gid, g.inst_start, g.big_list);
-    emit_big_kernel<16><<<EMIT_BIG_BLOCKS, 256, 0, st>>>(g.big_list, g.emit_rec, ellipse, d.W, d.H, d.gx, d.gy,
-                                                         g.counters, b.key_a, b.inst_gid);
-  }
+  if (d.tile == 15) launch_emit_t<15>(s, d, g, b, bin_sync_words, n_host, st);
+  else launch_emit_t<16>(s, d, g, b, bin_sync_words, n_host, st);
 }
 
 // ------------------------------------------------------------------------------- row compaction

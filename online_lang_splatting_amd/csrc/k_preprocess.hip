@@ -158,25 +158,30 @@ __device__ __forceinline__ u32 preprocess_one(
 
   u32 count = area;
   float t2 = 0.f;
+  int ya = rc.y0, yb = rc.y1;  // tile rows that hold instances
   if (ellipse) {
     // exact binning: count, per tile row of the rect, the tile columns the alpha-floor ellipse reaches
     t2 = cull_threshold(conic.x, conic.y, conic.z, opacity, irad, TILE);
     count = 0;
     if (t2 >= 0.0f) {
       const CullEllipse e = cull_setup(pix_x, pix_y, conic.x, conic.y, conic.z, t2, irad);
-      int ya, yb;
       cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
       for (int ty = ya; ty < yb; ++ty) {
         int xa, xb;
         cull_row_span<TILE>(e, rc.x0, rc.x1, ty, W, H, xa, xb);
         count += (u32)(xb - xa);
       }
+      // the emission re-evaluates the row spans from this record without the radius: a radius beyond cull_setup's
+      // range (full spans) is handed on as a threshold beyond its range (full spans as well)
+      if (!(irad < (1 << 20))) t2 = 2e6f;
     }
   }
   tiles_touched[idx] = count;
   count_out = count;
+  // {mean x, mean y, conic a, conic b}, {conic c, cull t2, first row | rows << 16, first column | end column << 16}
   emit_rec[2 * (size_t)idx] = make_float4(pix_x, pix_y, conic.x, conic.y);
-  emit_rec[2 * (size_t)idx + 1] = make_float4(conic.z, t2, __int_as_float(irad), __uint_as_float(count));
+  emit_rec[2 * (size_t)idx + 1] = make_float4(conic.z, t2, __uint_as_float((u32)ya | ((u32)(yb - ya) << 16)),
+                                              __uint_as_float((u32)rc.x0 | ((u32)rc.x1 << 16)));
   return area;
 }
 

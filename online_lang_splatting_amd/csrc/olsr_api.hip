@@ -197,7 +197,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
                         g.tiles_touched, g.emit_status, st);
     } else {
       launch_radix_sort(sb, s.P, nullptr, 32, false, st);
-      launch_emit_totals(g.depth_order, s.P, g.emit_rec, g.emit_status, st);
+      launch_emit_totals(g.depth_order, s.P, g.tiles_touched, g.emit_status, st);
     }
     STAGE("depth_sort");
   }
@@ -234,7 +234,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     const int64_t bin_sync_words =
         (b.tile_status - b.sync_words) +
         (fused_tiles ? ((int64_t)tpasses * tile_plan.nblk * ((int64_t)1 << tdb) + 1) / 2 : 0);  // 16-bit words
-    launch_emit(s, d, g, b, bin_sync_words, st);
+    launch_emit(s, d, g, b, bin_sync_words, n_host, st);
     STAGE("emit");
     if (n_host > 0) {
       // arrange the value ping-pong so that the last pass always lands in b.src

@@ -36,8 +36,9 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
                       hipStream_t st);
 // fused scan of the per-Gaussian instance counts (depth order) + emission of the instances; also zeroes the first
 // bin_sync_words words of the binning buffer's synchronisation area
+// (n_host: the instance count, or the caller's capacity when the count is only known on the device)
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                 int64_t bin_sync_words, hipStream_t st);
+                 int64_t bin_sync_words, int64_t n_host, hipStream_t st);
 // exclusive scan of popcount(flags) over [0, n] -> rowbase[0..n] in one kernel; counters[6] = total live rows,
 // counters[7] = (total > row_capacity) or the forward's instance overflow
 // packed_ref15: rows per instance = packed survivor waves (flag bits 4-5) instead of forward slots (bits 0-3)
@@ -78,7 +79,7 @@ int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host
                       const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
 void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_launches);
 // the same totals for a depth order produced by the multi-kernel passes
-void launch_emit_totals(const uint32_t* order, int P, const float4* emit_rec, uint32_t* emit_totals, hipStream_t st);
+void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
 
 // k_render_fwd.hip
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
