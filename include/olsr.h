@@ -65,6 +65,15 @@ typedef void *(*olsr_alloc_fn)(void *user, size_t nbytes);
 #define OLSR_ACT_SCALE_EXP 2
 #define OLSR_ACT_ROTATION_NORMALIZE 4
 
+/* olsr_scene.flags.
+ *   OLSR_FLAG_SIGNED_EMPTY_RADII  (forward) a Gaussian inside the frustum whose bounding square covers no tile gets
+ *       radii[i] = -radius instead of 0 (it still emits nothing, and n_touched stays 0).  The disentangled rasterizer
+ *       (DGR-D = submodules/diff-gaussian-rasterization-disentangle-optim) needs it: its
+ *       preprocess writes BOTH radii of a Gaussian as soon as ONE of its two covariance sets covers a tile
+ *       (DGR-D/cuda_rasterizer/forward.cu:391-431), so the caller that composes the two passes must know the radius of
+ *       the set that covered none.  A backward must be given max(radii, 0). */
+#define OLSR_FLAG_SIGNED_EMPTY_RADII 1
+
 /* How Gaussians are binned into tiles.
  *   OLSR_BINNING_RECT     every tile of the reference's bounding square (getRect, CR/auxiliary.h:46-56):
  *                         instance lists, num_rendered and n_contrib equal the reference's bit for bit.
@@ -111,7 +120,7 @@ typedef struct olsr_scene {
   const float *cam_pos;          /* [3] */
   int32_t activations; /* OLSR_ACT_* bit mask: which parameter arrays are RAW (pre-activation); 0 = the
                         * reference's calling convention (already activated) */
-  int32_t _pad1;
+  int32_t flags;       /* OLSR_FLAG_* bit mask, 0 = the reference's behaviour */
 } olsr_scene;
 
 /* Sizes of the three opaque state buffers (bytes).  Replace

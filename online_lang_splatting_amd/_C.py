@@ -116,7 +116,8 @@ def current_config():
 
 
 def _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-           projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug, cfg=None):
+           projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug, cfg=None,
+           flags=0):
     tile, bwd_mode, binning = cfg if cfg is not None else current_config()
     keep = [_c(x) for x in (bg, means3D, sh, colors, language, opacity, scales, rotations, cov3D_precomp, viewmatrix,
                             projmatrix, projmatrix_raw, campos)]
@@ -124,7 +125,7 @@ def _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_m
     M = sh_.shape[1] if sh_ is not None else 0
     s = _abi.make_scene(P=means3D.shape[0], D=degree, M=M, F=F, width=W, height=H, tile=tile,
                         prefiltered=prefiltered, debug=debug, bwd_mode=bwd_mode, tan_fovx=tan_fovx, tan_fovy=tan_fovy,
-                        scale_modifier=scale_modifier, binning=binning, background=bg_, means3D=m_, shs=sh_, colors_precomp=col_,
+                        scale_modifier=scale_modifier, binning=binning, flags=flags, background=bg_, means3D=m_, shs=sh_, colors_precomp=col_,
                         language_precomp=lang_, opacities=op_, scales=sc_, rotations=rot_, cov3D_precomp=cov_,
                         viewmatrix=v_, projmatrix=p_, projmatrix_raw=pr_, cam_pos=cp_)
     return s, keep
@@ -132,23 +133,24 @@ def _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_m
 
 def _forward(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-             prefiltered, debug):
+             prefiltered, debug, cfg=None, flags=0):
+    """`cfg` (tile, bwd_mode, binning) overrides the module knobs for this call; `flags`: _abi.FLAG_*."""
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # DGR/rasterize_points.cu:159-161
     _require_gpu(means3D, "means3D")
     ext = compiled_binding()
     if ext is not None:
-        tile, bwd_mode, binning = current_config()
+        tile, bwd_mode, binning = cfg if cfg is not None else current_config()
         return ext.forward(F, _t(bg), means3D, _t(colors), _t(language), _t(opacity), _t(scales), _t(rotations),
                            float(scale_modifier), _t(cov3D_precomp), _t(viewmatrix), _t(projmatrix), _t(projmatrix_raw),
                            float(tan_fovx), float(tan_fovy), int(image_height), int(image_width), _t(sh), int(degree),
-                           _t(campos), bool(prefiltered), bool(debug), tile, bwd_mode, binning)
+                           _t(campos), bool(prefiltered), bool(debug), tile, bwd_mode, binning, int(flags))
     dev = means3D.device
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     with torch.cuda.device(dev):
         s, keep = _scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                          viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos,
-                         prefiltered, debug)
+                         prefiltered, debug, cfg=cfg, flags=flags)
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         # every output is fully written by the library (no torch::full zero-fill, unlike

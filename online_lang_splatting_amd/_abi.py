@@ -17,6 +17,7 @@ ACT_OPACITY_SIGMOID = 1      # OLSR_ACT_*: the array holds the raw parameter, th
 ACT_SCALE_EXP = 2
 ACT_ROTATION_NORMALIZE = 4
 ACT_ALL = 7
+FLAG_SIGNED_EMPTY_RADII = 1  # OLSR_FLAG_SIGNED_EMPTY_RADII: radii = -radius for a bounding square that covers no tile
 
 BINNING_RECT = 0     # every tile of the reference's bounding square (bit-identical instance lists)
 BINNING_ELLIPSE = 1  # only tiles the alpha >= 1/255 ellipse reaches (identical outputs, shorter lists)
@@ -61,7 +62,7 @@ class OlsrScene(C.Structure):
         ("projmatrix_raw", _fp),
         ("cam_pos", _fp),
         ("activations", C.c_int32),
-        ("_pad1", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -96,7 +97,7 @@ def _ptr(t):
 
 
 def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode, tan_fovx, tan_fovy,
-               scale_modifier, binning=BINNING_RECT, activations=0, background, means3D, shs, colors_precomp, language_precomp, opacities,
+               scale_modifier, binning=BINNING_RECT, activations=0, flags=0, background, means3D, shs, colors_precomp, language_precomp, opacities,
                scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos):
     s = OlsrScene()
     s.P, s.D, s.M, s.F = int(P), int(D), int(M), int(F)
@@ -105,6 +106,7 @@ def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode,
     s.tan_fovx, s.tan_fovy, s.scale_modifier = float(tan_fovx), float(tan_fovy), float(scale_modifier)
     s.binning = int(binning)
     s.activations = int(activations)
+    s.flags = int(flags)
     s.background = _ptr(background)
     s.means3D = _ptr(means3D)
     s.shs = _ptr(shs)

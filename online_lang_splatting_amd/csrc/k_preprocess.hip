@@ -139,7 +139,11 @@ __device__ __forceinline__ u32 preprocess_one(
   const int irad = f2i_sat(my_radius);
   const Rect rc = get_rect<TILE>(pix_x, pix_y, irad, gx, gy);
   const u32 area = (u32)((rc.y1 - rc.y0) * (rc.x1 - rc.x0));
-  if (area == 0) return 0;
+  if (area == 0) {
+    // (OLSR_FLAG_SIGNED_EMPTY_RADII, carried in the upper half of `act`: the radius of a square that covers no tile)
+    if (act & (OLSR_FLAG_SIGNED_EMPTY_RADII << 16)) radii[idx] = -irad;
+    return 0;
+  }
 
   if (colors_precomp == nullptr) {
     const f3 c = color_from_sh(idx, D, M, p_orig, cam_pos, shs, clamped);
@@ -237,7 +241,7 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
       s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
       g.emit_rec, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
-      s.activations, g.part_rect, g.part_count, reinterpret_cast<uint4*>(g.sync_words), sync_quads
+      s.activations | (s.flags << 16), g.part_rect, g.part_count, reinterpret_cast<uint4*>(g.sync_words), sync_quads
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

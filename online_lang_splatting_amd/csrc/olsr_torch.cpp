@@ -52,7 +52,7 @@ void fill_scene(Scene &sc, int F, const Tensor &bg, const Tensor &means3D, const
                 const Tensor &opacity, const Tensor &scales, const Tensor &rotations, float scale_modifier,
                 const Tensor &cov3D_precomp, const Tensor &viewmatrix, const Tensor &projmatrix,
                 const Tensor &projmatrix_raw, float tan_fovx, float tan_fovy, int H, int W, const Tensor &sh, int degree,
-                const Tensor &campos, bool prefiltered, bool debug, int tile, int bwd_mode, int binning) {
+                const Tensor &campos, bool prefiltered, bool debug, int tile, int bwd_mode, int binning, int flags) {
   const Tensor *in[13] = {&bg,        &means3D,       &sh,         &colors,     &language,       &opacity, &scales,
                           &rotations, &cov3D_precomp, &viewmatrix, &projmatrix, &projmatrix_raw, &campos};
   static const char *names[13] = {"bg",        "means3D",       "sh",         "colors_precomp", "language_precomp",
@@ -76,6 +76,7 @@ void fill_scene(Scene &sc, int F, const Tensor &bg, const Tensor &means3D, const
   s.tan_fovy = tan_fovy;
   s.scale_modifier = scale_modifier;
   s.binning = binning;
+  s.flags = flags;
   s.background = fp(sc.keep[0]);
   s.means3D = fp(sc.keep[1]);
   s.shs = fp(sc.keep[2]);
@@ -100,7 +101,7 @@ std::tuple<int, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, 
     const Tensor &scales, const Tensor &rotations, float scale_modifier, const Tensor &cov3D_precomp,
     const Tensor &viewmatrix, const Tensor &projmatrix, const Tensor &projmatrix_raw, float tan_fovx, float tan_fovy,
     int image_height, int image_width, const Tensor &sh, int degree, const Tensor &campos, bool prefiltered, bool debug,
-    int tile, int bwd_mode, int binning) {
+    int tile, int bwd_mode, int binning, int flags) {
   TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3,
               "means3D must have dimensions (num_points, 3)");  // DGR/rasterize_points.cu:159-161
   TORCH_CHECK(means3D.is_cuda(), "means3D must live on the GPU: this rasterizer has no CPU path");
@@ -109,7 +110,7 @@ std::tuple<int, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, 
   Scene sc;
   fill_scene(sc, F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
-             debug, tile, bwd_mode, binning);
+             debug, tile, bwd_mode, binning, flags);
   auto f32 = means3D.options().dtype(torch::kFloat32);
   auto i32 = means3D.options().dtype(torch::kInt32);
   auto u8 = means3D.options().dtype(torch::kUInt8);
@@ -146,7 +147,7 @@ std::vector<Tensor> backward(int F, const Tensor &bg, const Tensor &means3D, con
   Scene sc;
   fill_scene(sc, F, bg, means3D, colors, language, Tensor(), scales, rotations, scale_modifier, cov3D_precomp,
              viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, H, W, sh, degree, campos, false, debug, tile,
-             bwd_mode, binning);
+             bwd_mode, binning, 0);
   const int64_t M = sc.s.M;
   auto f32 = means3D.options().dtype(torch::kFloat32);
   // written exactly once per row by the library: no torch::zeros (DGR/rasterize_points.cu:386-398)

@@ -285,7 +285,12 @@ static void preprocess(const olsr_scene& s, State& st, int* radii_out) {
     f2 point_image = {ndc2Pix(p_proj.x, s.width), ndc2Pix(p_proj.y, s.height)};
     int x0, y0, x1, y1;
     getRect(point_image, f2i_sat(my_radius), s.tile, st.gx, st.gy, x0, y0, x1, y1);
-    if ((x1 - x0) * (y1 - y0) == 0) continue;
+    if ((x1 - x0) * (y1 - y0) == 0) {
+      // OLSR_FLAG_SIGNED_EMPTY_RADII (include/olsr.h): the radius DGR-D's preprocess would still report when the
+      // Gaussian's other covariance set covers a tile (DGR-D/cuda_rasterizer/forward.cu:391-431)
+      if (s.flags & OLSR_FLAG_SIGNED_EMPTY_RADII) radii_out[idx] = -f2i_sat(my_radius);
+      continue;
+    }
     if (s.colors_precomp == nullptr) {
       f3 c = computeColorFromSH(idx, s.D, s.M, s.means3D, s.cam_pos, s.shs, st.clamped.data());
       st.rgb[3 * (size_t)idx + 0] = c.x;

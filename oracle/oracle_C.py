@@ -21,6 +21,7 @@ from online_lang_splatting_amd import _abi  # noqa: E402  (struct declarations o
 
 TILE = 15
 BWD_MODE = _abi.BWD_REFERENCE
+FLAGS = 0  # _abi.FLAG_* for the forward
 
 _lib = None
 _states = {}
@@ -112,7 +113,7 @@ def _scene(bg, means3D, colors, language, opacity, scales, rotations, scale_modi
     M = sh_.shape[1] if sh_ is not None else 0
     s = _abi.make_scene(P=means3D.shape[0], D=degree, M=M, F=F, width=W, height=H, tile=TILE,
                         prefiltered=prefiltered, debug=debug, bwd_mode=BWD_MODE, tan_fovx=tan_fovx,
-                        tan_fovy=tan_fovy, scale_modifier=scale_modifier, background=bg_, means3D=m_, shs=sh_,
+                        tan_fovy=tan_fovy, scale_modifier=scale_modifier, flags=FLAGS, background=bg_, means3D=m_, shs=sh_,
                         colors_precomp=col_, language_precomp=lang_, opacities=op_, scales=sc_, rotations=rot_,
                         cov3D_precomp=cov_, viewmatrix=v_, projmatrix=p_, projmatrix_raw=pr_, cam_pos=cp_)
     return s, keep

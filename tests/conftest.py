@@ -66,7 +66,7 @@ def _default_rasterizer_knobs():
             pass
         try:
             from oracle import oracle_C
-            oracle_C.TILE, oracle_C.BWD_MODE = 15, 0
+            oracle_C.TILE, oracle_C.BWD_MODE, oracle_C.FLAGS = 15, 0, 0
         except Exception:
             pass
     reset()

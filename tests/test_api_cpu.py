@@ -140,10 +140,10 @@ def test_compiled_torch_binding_loads_and_rejects_cpu_tensors():
     e = torch.empty(0)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ext.forward(15, e, torch.zeros(4, 3), e, e, e, e, e, 1.0, e, e, e, e, 1.0, 1.0, 10, 10, e, 0, e, False, False,
-                    15, 0, 1)
+                    15, 0, 1, 0)
     with pytest.raises(RuntimeError, match="num_points, 3"):
         ext.forward(15, e, torch.zeros(4, 2), e, e, e, e, e, 1.0, e, e, e, e, 1.0, 1.0, 10, 10, e, 0, e, False, False,
-                    15, 0, 1)
+                    15, 0, 1, 0)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ext.mark_visible(torch.zeros(4, 3), e, e)
 
