@@ -66,13 +66,25 @@ def algorithmic_bytes(P, R, N, C=3, F=15, M=1):
     return per
 
 
+PROFILE_TAG = "r2"  # the committed counter summaries of the current kernels: profiles/<tag>_pmc_{traffic,valu}.json
+
+
+def _pmc_summary(kind):
+    """profiles/<PROFILE_TAG>_pmc_<kind>.json, else the alphabetically last summary (file times do not survive a copy)."""
+    import glob
+    tagged = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_{kind}.json")
+    if os.path.exists(tagged):
+        return tagged
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}.json")))
+    return files[-1] if files else None
+
+
 def measured_traffic(kernel_stage, F):
-    """HBM bytes per launch of the stage's kernel from the newest profiles/*_pmc_traffic.json (rocprofv3
+    """HBM bytes per launch of the stage's kernel from profiles/<PROFILE_TAG>_pmc_traffic.json (rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as MI355X_MICROARCH.md prescribes);
     None when no summary has been committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
-    if not files:
+    files = [_pmc_summary("traffic")]
+    if not files[-1]:
         return None, None
     d = json.load(open(files[-1]))
     prefix = {"render_forward": "render_fwd_kernel", "render_backward": "render_bwd_kernel"}[kernel_stage]
@@ -83,11 +95,10 @@ def measured_traffic(kernel_stage, F):
 
 
 def measured_valu(kernel_stage, F):
-    """VALU wave-instructions per launch of the stage's kernel from the newest profiles/*_pmc_valu.json
+    """VALU wave-instructions per launch of the stage's kernel from profiles/<PROFILE_TAG>_pmc_valu.json
     (rocprofv3 --pmc SQ_INSTS_VALU ... of this same command); None when no summary has been committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")), key=os.path.getmtime)
-    if not files:
+    files = [_pmc_summary("valu")]
+    if not files[-1]:
         return None, None
     d = json.load(open(files[-1]))
     prefix = {"render_forward": "render_fwd_kernel", "render_backward": "render_bwd_kernel"}[kernel_stage]
