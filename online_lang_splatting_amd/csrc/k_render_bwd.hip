@@ -137,6 +137,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   const float dLd = inside ? dL_dpixels_depth[pix] : 0.f;
   const v2f dL01 = {dLc[0], dLc[1]}, dL23 = {dLc[2], dLd};  // the pixel's cotangents, in the same pairs
   float A_f = 0.f, D_last = 0.f, dLf[FX];
+  bool seen_mine = false;  // wave-uniform: an entry of this wave's own has been visited
 #pragma unroll
   for (int ch = 0; ch < FX; ++ch) dLf[ch] = (F > 0 && inside) ? dL_dpixels_lang[ch * HW + pix] : 0.f;
   v2f dLf2[F2X];  // the same cotangents in pairs, for packed fp32 math
@@ -237,6 +238,12 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
       todo &= todo - 1ull;
       const int i = 64 * h + bit;
       const bool mine = (m_mine[h] >> bit) & 1ull;  // did any pixel of THIS wave blend it in the forward?
+      // Until this wave meets the first entry one of its pixels blended, every lane still has last_alpha = 0: the
+      // unguarded recursion A <- 0 * D_last + 1 * A leaves A where it is, and the D_last it records is overwritten by
+      // that first entry before anything reads it — such visits (entries only OTHER waves of the tile blended, behind
+      // this wave's last contributors) are skipped outright, bit for bit the same result.
+      if (REF && !mine && !seen_mine) continue;
+      seen_mine = true;
       const float* fr = &s_feat[i * FR];
       float D_cur = 0.f;
       if constexpr (F > 0) {
