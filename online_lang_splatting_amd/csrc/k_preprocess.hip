@@ -67,6 +67,73 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float m
 }
 
 // One Gaussian; returns the area of the reference's tile rectangle (0 when culled).
+// Exact binning counts, per tile row of a Gaussian's rect, the tile columns its alpha-floor ellipse reaches.  A lane that
+// walked its own rows made the wave wait for its tallest member (2.5 rows on average, ~10 for the tallest of 64, ~100
+// instructions per row): the rows of the wave's 64 Gaussians are instead dealt one per lane — a row -> owner table in
+// LDS, the owner's ellipse read back from LDS, one LDS atomic per row for the sum.  Same function, same inputs as the
+// emission (cull_row_span), so the counts and the emitted instances agree by construction.
+struct PendingRows {
+  CullEllipse e;
+  int ya, nrows, x0, x1;
+};
+constexpr int PRE_ROWCAP = 512;  // rows per fill of a wave's row -> owner table
+struct PreWaveLds {
+  float4 e0[64];  // px py b inv_a
+  float4 e1[64];  // A det_lo xstar ystar
+  int4 m[64];     // exact, x0 | x1 << 16, first row, first row's index among the wave's rows
+  u32 cnt[64];
+  uint8_t owner[PRE_ROWCAP];
+};
+
+template <int TILE>
+__device__ __forceinline__ u32 count_pending_rows(const PendingRows& pd, PreWaveLds& L, int W, int H) {
+  const int lane = threadIdx.x & 63;
+  const u32 nrows = (u32)pd.nrows;
+  u32 incl = nrows;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  const u32 total = (u32)__shfl((int)incl, 63);
+  if (total == 0) return 0;  // (wave-uniform)
+  const u32 rowoff = incl - nrows;
+  L.cnt[lane] = 0;
+  if (nrows) {
+    L.e0[lane] = make_float4(pd.e.px, pd.e.py, pd.e.b, pd.e.inv_a);
+    L.e1[lane] = make_float4(pd.e.A, pd.e.det_lo, pd.e.xstar, pd.e.ystar);
+    L.m[lane] = make_int4(pd.e.exact ? 1 : 0, pd.x0 | (pd.x1 << 16), pd.ya, (int)rowoff);
+  }
+  for (u32 sbase = 0; sbase < total; sbase += PRE_ROWCAP) {
+    const u32 k0 = max(rowoff, sbase), k1 = min(rowoff + nrows, sbase + (u32)PRE_ROWCAP);
+    for (u32 k = k0; k < k1; ++k) L.owner[k - sbase] = (uint8_t)lane;
+    // one wave, one LDS queue: its own writes are visible to its later reads; only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 send = min(total, sbase + (u32)PRE_ROWCAP);
+    for (u32 rbase = sbase; rbase < send; rbase += 64) {
+      const u32 idx = rbase + (u32)lane;
+      if (idx < send) {
+        const int o = (int)L.owner[idx - sbase];
+        const float4 q0 = L.e0[o], q1 = L.e1[o];
+        const int4 m = L.m[o];
+        CullEllipse e;
+        e.px = q0.x; e.py = q0.y; e.b = q0.z; e.inv_a = q0.w;
+        e.A = q1.x; e.det_lo = q1.y; e.xstar = q1.z; e.ystar = q1.w;
+        e.ymax = 0.f;
+        e.exact = m.x != 0;
+        const int y = m.z + (int)(idx - (u32)m.w);
+        int xa = m.y & 0xFFFF, xb = (int)((u32)m.y >> 16);
+        cull_row_span<TILE>(e, xa, xb, y, W, H, xa, xb);
+        if (xb > xa) atomicAdd(&L.cnt[o], (u32)(xb - xa));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return L.cnt[lane];
+}
+
 template <int TILE>
 __device__ __forceinline__ u32 preprocess_one(
     int idx, int D, int M, const float* __restrict__ orig_points, const float* __restrict__ scales, float scale_modifier,
@@ -77,11 +144,11 @@ __device__ __forceinline__ u32 preprocess_one(
     float* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds, float* __restrict__ rgb,
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
-    int ellipse, int act, u32& count_out) {
+    int ellipse, int act, u32& count_out, PendingRows& pend) {
   count_out = 0;
+  pend.nrows = 0;
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
-  tiles_touched[idx] = 0;
   sort_key[idx] = 0xFFFFFFFFu;
   sort_val[idx] = (u32)idx;
   // the emission reads the instance count from the record (one gather in depth order): zero for culled Gaussians
@@ -170,17 +237,17 @@ __device__ __forceinline__ u32 preprocess_one(
     if (t2 >= 0.0f) {
       const CullEllipse e = cull_setup(pix_x, pix_y, conic.x, conic.y, conic.z, t2, irad);
       cull_rows<TILE>(e, rc.y0, rc.y1, ya, yb);
-      for (int ty = ya; ty < yb; ++ty) {
-        int xa, xb;
-        cull_row_span<TILE>(e, rc.x0, rc.x1, ty, W, H, xa, xb);
-        count += (u32)(xb - xa);
-      }
+      // the row spans are evaluated by the whole wave, one row per lane (count_pending_rows): the caller adds them up
+      pend.e = e;
+      pend.ya = ya;
+      pend.nrows = yb - ya;
+      pend.x0 = rc.x0;
+      pend.x1 = rc.x1;
       // the emission re-evaluates the row spans from this record without the radius: a radius beyond cull_setup's
       // range (full spans) is handed on as a threshold beyond its range (full spans as well)
       if (!(irad < (1 << 20))) t2 = 2e6f;
     }
   }
-  tiles_touched[idx] = count;
   count_out = count;
   // {mean x, mean y, conic a, conic b}, {conic c, cull t2, first row | rows << 16, first column | end column << 16}
   emit_rec[2 * (size_t)idx] = make_float4(pix_x, pix_y, conic.x, conic.y);
@@ -202,17 +269,22 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     int ellipse, int act, u32* __restrict__ rect_partials, u32* __restrict__ count_partials,
     uint4* __restrict__ sync_words, int sync_quads) {
   __shared__ u32 s_area[4], s_cnt[4];
+  __shared__ PreWaveLds s_rows[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   // the words the frame's fused kernels synchronise through (tickets, digit histograms, published block counts):
   // zeroed here, at the head of the frame, by as many threads as there are 16-byte pieces
   if (idx < sync_quads) sync_words[idx] = make_uint4(0u, 0u, 0u, 0u);
   u32 area = 0, count = 0;
+  PendingRows pend;
+  pend.nrows = 0;
   if (idx < P)
     area = preprocess_one<TILE>(idx, D, M, orig_points, scales, scale_modifier, rotations, opacities, shs, clamped,
                                 cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, W, H, tan_fovx,
                                 tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy,
                                 tiles_touched, emit_rec, sort_key, sort_val, n_touched, prefiltered, ellipse, act,
-                                count);
+                                count, pend);
+  if (ellipse) count += count_pending_rows<TILE>(pend, s_rows[threadIdx.x >> 6], W, H);
+  if (idx < P) tiles_touched[idx] = count;
   // instances of the reference's rect binning (its num_rendered) and instances this frame emits: one partial per
   // block each, summed by the next kernel (7.8 k same-address atomics would cost more than the whole kernel)
 #pragma unroll
