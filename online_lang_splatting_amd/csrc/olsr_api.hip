@@ -77,6 +77,8 @@ int check_scene(const olsr_scene* s, bool backward) {
   if (!s) return fail(OLSR_ERR_ARG, "scene is NULL");
   if (s->P < 0) return fail(OLSR_ERR_ARG, "P must be >= 0");
   if (s->width <= 0 || s->height <= 0) return fail(OLSR_ERR_ARG, "image size must be positive");
+  // (tile coordinates travel as 16-bit fields of the emission record)
+  if (s->width > 65535 * 15 || s->height > 65535 * 15) return fail(OLSR_ERR_ARG, "image size beyond 65535 tiles");
   if (s->tile != 15 && s->tile != 16) return fail(OLSR_ERR_ARG, "tile must be 15 or 16");
   if (!backward && s->binning != OLSR_BINNING_RECT && s->binning != OLSR_BINNING_ELLIPSE)
     return fail(OLSR_ERR_ARG, "binning must be OLSR_BINNING_RECT or OLSR_BINNING_ELLIPSE");
