@@ -385,26 +385,68 @@ constexpr int EB_OUT = OLSR_EB_OUT;
 constexpr int EB_ROWCAP = 16 * EB_T;   // rows per fill of the row -> Gaussian table
 constexpr u32 EB_SHORT_ROW = 8;   // rows up to this many tiles are written by their own thread
 
-__global__ __launch_bounds__(EMIT_THREADS) void emit_offsets_kernel(
+// (4-wave workgroups, four consecutive depth ranks per thread: a block still covers the EMIT_CHUNK ranks whose total the
+//  depth sort accumulated, but it fits beside the resident blocks of a compositing kernel of another frame in flight —
+//  16-wave workgroups only run in the gaps between composites)
+constexpr int EO_T = 256;
+constexpr int EO_PER = EMIT_CHUNK / EO_T;  // 4
+static_assert(EO_PER == 4, "one 16-byte load of the depth order per thread");
+
+// base slot of this thread's `cnt` list entries: one aggregated atomic per block (the list order influences no result)
+__device__ __forceinline__ u32 block_list_base(u32 cnt, int32_t* counter, u32* s_cnt /* [EO_T / 64] */, u32* s_base) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u32 incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  __syncthreads();  // (scratch may still be read from the previous use)
+  if (lane == 63) s_cnt[w] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tot = 0;
+    for (int i = 0; i < EO_T / 64; ++i) {
+      const u32 c = s_cnt[i];
+      s_cnt[i] = tot;
+      tot += c;
+    }
+    *s_base = tot ? (u32)atomicAdd(counter, (int)tot) : 0u;
+  }
+  __syncthreads();
+  return *s_base + s_cnt[w] + incl - cnt;
+}
+
+__global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
     int P, const u32* __restrict__ order, const u32* __restrict__ inst_count, int32_t* __restrict__ counters,
     const u32* __restrict__ block_totals, uint4* __restrict__ bin_sync, int bin_sync_quads,
     u32* __restrict__ rank_off, u32* __restrict__ win_start, u32* __restrict__ inst_start,
     uint4* __restrict__ big_list) {
-  __shared__ u32 s_wsum[EMIT_THREADS / 64 + 1];
+  __shared__ u32 s_wsum[EO_T / 64 + 1];
+  __shared__ u32 s_lbase;
   // the words the tile sort and the row compaction synchronise through live in the binning buffer, which exists only
   // from here on (the drop-in entry allocates it after the instance count is known)
-  for (int q = (int)(blockIdx.x * EMIT_THREADS + threadIdx.x); q < bin_sync_quads; q += (int)(gridDim.x * EMIT_THREADS))
+  for (int q = (int)(blockIdx.x * EO_T + threadIdx.x); q < bin_sync_quads; q += (int)(gridDim.x * EO_T))
     bin_sync[q] = make_uint4(0u, 0u, 0u, 0u);
   if (counters[2] != 0) return;  // more instances than the caller's capacity: nothing is emitted (uniform)
   const u32 b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = (int)(b * EMIT_THREADS + threadIdx.x);
-  u32 g = 0, n = 0;
-  if (r < P) {
-    g = order[r];
-    n = inst_count[g];  // 0 when culled
+  const int r0 = (int)(b * EMIT_CHUNK + threadIdx.x * EO_PER);  // this thread's four consecutive depth ranks
+  u32 g[EO_PER], n[EO_PER];
+  if (r0 + EO_PER <= P) {
+    const uint4 q = *reinterpret_cast<const uint4*>(order + r0);  // (the order array is 256-byte aligned)
+    g[0] = q.x; g[1] = q.y; g[2] = q.z; g[3] = q.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < EO_PER; ++k) g[k] = (r0 + k < P) ? order[r0 + k] : 0u;
   }
-  u32 incl = n;
+  u32 mine = 0;
+#pragma unroll
+  for (int k = 0; k < EO_PER; ++k) {
+    n[k] = (r0 + k < P) ? inst_count[g[k]] : 0u;  // 0 when culled
+    mine += n[k];
+  }
+  u32 incl = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const u32 o = __shfl_up(incl, d);
@@ -414,32 +456,53 @@ __global__ __launch_bounds__(EMIT_THREADS) void emit_offsets_kernel(
   __syncthreads();
   u32 wbase = 0;
 #pragma unroll
-  for (int i = 0; i < EMIT_THREADS / 64; ++i) wbase += (i < w) ? s_wsum[i] : 0u;
+  for (int i = 0; i < EO_T / 64; ++i) wbase += (i < w) ? s_wsum[i] : 0u;
   __syncthreads();
   // first instance of this block = instances of all earlier blocks (left behind by the depth sort's last pass)
   u32 pre = 0;
-  for (u32 j = threadIdx.x; j < b; j += EMIT_THREADS) pre += block_totals[j];
+  for (u32 j = threadIdx.x; j < b; j += EO_T) pre += block_totals[j];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m);
   if (lane == 0) s_wsum[w] = pre;
   __syncthreads();
   u32 base = 0;
 #pragma unroll
-  for (int i = 0; i < EMIT_THREADS / 64; ++i) base += s_wsum[i];
-  const u32 off = base + wbase + incl - n;
-  if (r < P) rank_off[r] = off;
-  if (n > 0) {
-    inst_start[g] = off;
-    // this rank owns the first instance of every output window [k * EB_OUT, ...) that starts inside its run
-    for (u32 k = (off + (u32)EB_OUT - 1u) / (u32)EB_OUT; k * (u32)EB_OUT < off + n; ++k) win_start[k] = (u32)r;
+  for (int i = 0; i < EO_T / 64; ++i) base += s_wsum[i];
+  u32 off[EO_PER];
+  u32 run = base + wbase + incl - mine;
+  u32 nbig = 0, nmid = 0;
+#pragma unroll
+  for (int k = 0; k < EO_PER; ++k) {
+    off[k] = run;
+    run += n[k];
+    nbig += (n[k] > EMIT_BIG) ? 1u : 0u;
+    nmid += (n[k] > OLSR_MID_FOOTPRINT && n[k] <= EMIT_BIG) ? 1u : 0u;
   }
-  const bool is_big = n > EMIT_BIG;
-  const u32 slot = block_list_slot(is_big, &counters[5]);
-  if (is_big) big_list[slot] = make_uint4(g, off, n, 0u);
-  // second list, from the back of the same array: medium footprints
-  const bool is_mid = n > OLSR_MID_FOOTPRINT && n <= EMIT_BIG;
-  const u32 mslot = block_list_slot(is_mid, &counters[4]);
-  if (is_mid) big_list[(u32)P - 1u - mslot] = make_uint4(g, off, n, 0u);
+  if (r0 + EO_PER <= P) {
+    *reinterpret_cast<uint4*>(rank_off + r0) = make_uint4(off[0], off[1], off[2], off[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < EO_PER; ++k)
+      if (r0 + k < P) rank_off[r0 + k] = off[k];
+  }
+#pragma unroll
+  for (int k = 0; k < EO_PER; ++k) {
+    if (n[k] > 0) {
+      inst_start[g[k]] = off[k];
+      // this rank owns the first instance of every output window [j * EB_OUT, ...) that starts inside its run
+      for (u32 j = (off[k] + (u32)EB_OUT - 1u) / (u32)EB_OUT; j * (u32)EB_OUT < off[k] + n[k]; ++j)
+        win_start[j] = (u32)(r0 + k);
+    }
+  }
+  // the two work lists of the backward's row sums: big footprints from the front, medium ones from the back
+  u32 slot = block_list_base(nbig, &counters[5], s_wsum, &s_lbase);
+#pragma unroll
+  for (int k = 0; k < EO_PER; ++k)
+    if (n[k] > EMIT_BIG) big_list[slot++] = make_uint4(g[k], off[k], n[k], 0u);
+  u32 mslot = block_list_base(nmid, &counters[4], s_wsum, &s_lbase);
+#pragma unroll
+  for (int k = 0; k < EO_PER; ++k)
+    if (n[k] > OLSR_MID_FOOTPRINT && n[k] <= EMIT_BIG) big_list[(u32)P - 1u - (mslot++)] = make_uint4(g[k], off[k], n[k], 0u);
 }
 
 // exclusive scan of v over the EB_T threads of the block; *total = the sum (two barriers; s_w: [EB_T / 64])
@@ -641,7 +704,7 @@ static void launch_emit_t(const olsr_scene& s, const FrameDims& d, const Geometr
   const int quads = (int)((bin_sync_words + 3) / 4);
   u32* rank_off = g.key_b;   // the depth keys are dead once the order exists
   u32* win_start = b.key_b;  // the tile sort's second key buffer is not in use yet
-  emit_offsets_kernel<<<nb, EMIT_THREADS, 0, st>>>(s.P, g.depth_order, g.tiles_touched, g.counters, totals, bsync, quads,
+  emit_offsets_kernel<<<nb, EO_T, 0, st>>>(s.P, g.depth_order, g.tiles_touched, g.counters, totals, bsync, quads,
                                                    rank_off, win_start, g.inst_start, g.big_list);
   const int64_t nblk = (n_host + EB_OUT - 1) / EB_OUT;
   if (nblk > 0)

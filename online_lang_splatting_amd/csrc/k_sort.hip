@@ -76,6 +76,26 @@ __device__ __forceinline__ bool fs_granule_ready(const u32x4& v) {
   return ((v.x & v.y & v.z & v.w) & FS_READY_PAIR) == FS_READY_PAIR;
 }
 
+// two exclusive prefixes at once (the same two barriers); s_w2: 32 words of LDS scratch
+__device__ __forceinline__ void fs_block_excl_scan2(u32 a, u32 b, u32* s_w2, u32& out_a, u32& out_b) {
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const u32 ia = fs_wave_incl_scan(a), ib = fs_wave_incl_scan(b);
+  if (lane == 63) {
+    s_w2[w] = ia;
+    s_w2[FS_W + w] = ib;
+  }
+  __syncthreads();
+  u32 ba = 0, bb = 0;
+#pragma unroll
+  for (int i = 0; i < FS_W; ++i) {
+    ba += (i < w) ? s_w2[i] : 0u;
+    bb += (i < w) ? s_w2[FS_W + i] : 0u;
+  }
+  __syncthreads();
+  out_a = ba + ia - a;
+  out_b = bb + ib - b;
+}
+
 // ---- digit totals of every pass of a sort, one read of the keys ---------------------------------------------
 // hist[p][d] += #keys whose digit p is d (hist zeroed by an earlier kernel of the frame); digits are `db` bits wide.
 // `house` (block 0 only, may be null): the frame's bookkeeping that used to be finalize_counts_kernel.
@@ -239,7 +259,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   u32* ex_key = gbase + NB + NB / 2;  // [CHUNK]
   u32* ex_val = ex_key + CHUNK;       // [CHUNK]
   __shared__ u32 s_bid;
-  __shared__ u32 s_w[FS_W];
+  __shared__ u32 s_w[2 * FS_W];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // chunk index: the launch order (blockIdx) when the whole grid is resident at once (at most one block per CU: a
   // spinning block then never keeps a predecessor from starting), else a ticket
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   const int64_t bbase = (int64_t)b * CHUNK;
   if (bbase >= n) return;  // (an empty block has only empty successors: nobody waits for it)
   const int64_t wbase = bbase + (int64_t)w * (64 * KPT);
+  const u32 gh = ((u32)tid < NB) ? ghist[tid] : 0u;  // (needed after the count: its latency hides behind it)
 
   u32 key[KPT], val[KPT];
 #pragma unroll
@@ -282,14 +303,16 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
     }
     pub[d] = (u16)(FS_READY16 | tot);
   }
-  const u32 start = fs_block_excl_scan(d < NB ? tot : 0u, s_w);
+  // local start of every digit inside the block and global start of every digit (from the up-front totals), one pair
+  // of barriers for both prefixes
+  u32 start, gdig;
+  fs_block_excl_scan2(d < NB ? tot : 0u, gh, s_w, start, gdig);
   // publish this block's row: NB / 8 granules of eight 16-bit counts, write-through (sc1)
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)(gridDim.x * NB * 2u), 0x00020000);
   if (tid < C) {
     const u32x4 g4 = *reinterpret_cast<const u32x4*>(pub + 8 * tid);
     __builtin_amdgcn_raw_buffer_store_b128(g4, rsrc, (int)((b * NB + 8u * (u32)tid) * 2u), 0, /*sc1*/ 16);
   }
-  const u32 gdig = fs_block_excl_scan(d < NB ? ghist[d] : 0u, s_w);
   if (d < NB) {
     dstart[d] = start;
     u32 run = start;
