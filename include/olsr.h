@@ -357,6 +357,11 @@ int olsr_get_stage_times(const char **names, float *ms, int max);
  * NULL switches it off. */
 void olsr_debug_sort_timing(unsigned long long *device_buffer, int max_blocks, int max_launches);
 
+/* Host logic of the radix passes, exposed for tests: the keys-per-thread and the number of 1024-thread blocks a sort of
+ * n keys is launched with (n_is_capacity != 0: n bounds a count only known on the device, see olsr_forward_async), and
+ * whether n is sorted by the one-kernel passes at all (return value: 1) or by the multi-kernel fallback (0). */
+int olsr_debug_sort_plan(int64_t n, int n_is_capacity, int32_t *keys_per_thread, int32_t *blocks);
+
 const char *olsr_last_error(void);
 const char *olsr_version(void);
 

@@ -573,6 +573,13 @@ void olsr_debug_sort_timing(unsigned long long* device_buffer, int max_blocks, i
   debug_set_sort_timing(device_buffer, max_blocks, max_launches);
 }
 
+int olsr_debug_sort_plan(int64_t n, int n_is_capacity, int32_t* keys_per_thread, int32_t* blocks) {
+  const SortPlan p = sort_plan((long long)n, n_is_capacity != 0);
+  if (keys_per_thread) *keys_per_thread = p.kpt;
+  if (blocks) *blocks = p.nblk;
+  return fused_sort_applicable(n, 32) ? 1 : 0;
+}
+
 const char* olsr_last_error(void) { return g_err.c_str(); }
 const char* olsr_version(void) { return "olsr 0.1 (gfx950)"; }
 

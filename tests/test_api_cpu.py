@@ -154,3 +154,28 @@ def test_binding_selector(monkeypatch):
     assert _C.compiled_binding() is None
     monkeypatch.setenv("OLSR_BINDING", "torch")
     assert _C.compiled_binding() is not None
+
+
+def test_sort_plan_host_logic(L, monkeypatch):
+    """Keys per thread / block count of the one-kernel radix passes (csrc/olsr_state.h: sort_plan): a round of at most
+    256 resident blocks costs about (kpt + 11) us; status rows are reserved for the smallest chunk; 4096 blocks at
+    most, beyond that the multi-kernel fallback."""
+    monkeypatch.delenv("OLSR_SORT_KPT", raising=False)
+    monkeypatch.delenv("OLSR_SORT_RESIDENT", raising=False)
+    kpt, nblk = ctypes.c_int32(), ctypes.c_int32()
+
+    def plan(n, cap=0):
+        ok = L.olsr_debug_sort_plan(n, cap, ctypes.byref(kpt), ctypes.byref(nblk))
+        return ok, kpt.value, nblk.value
+    assert plan(500_000) == (1, 2, 245)            # the depth sort of the headline frame: one round at kpt 2
+    assert plan(2_700_146) == (1, 12, 220)         # its tile sort: one round of 220 fat blocks
+    ok, k, b = plan(3_440_000, 1)                  # the same sort launched against a capacity: planned for 85 % fill
+    assert (ok, k) == (1, 12) and b == -(-3_440_000 // (1024 * 12))
+    assert plan(3_440_000, 0)[1] == 16             # ... while an exact count of that size takes one round at kpt 16
+    assert plan(0)[2] == 0
+    for n in (1, 2047, 2048, 2049, 10_000_000, 60_000_000):
+        ok, k, b = plan(n)
+        assert ok == 1 and k in (2, 4, 8, 12, 16) and b == -(-n // (1024 * k)) and b <= 4096
+    assert plan(4096 * 16384 + 1)[0] == 0          # more than 4096 blocks even at kpt 16: the multi-kernel passes
+    monkeypatch.setenv("OLSR_SORT_KPT", "4")
+    assert plan(500_000)[1:] == (4, 123)
