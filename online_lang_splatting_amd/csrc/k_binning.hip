@@ -383,6 +383,7 @@ __device__ __forceinline__ u32 lb_block_exclusive(u32* status, u32 b, u32 total,
 constexpr int EB_T = OLSR_EB_T;
 constexpr int EB_OUT = OLSR_EB_OUT;
 constexpr int EB_ROWCAP = 16 * EB_T;   // rows per fill of the row -> Gaussian table
+static_assert(EB_T <= 256 && EB_T % 64 == 0, "the row -> Gaussian table holds thread indices in one byte");
 constexpr u32 EB_SHORT_ROW = 8;   // rows up to this many tiles are written by their own thread
 
 // (4-wave workgroups, four consecutive depth ranks per thread: a block still covers the EMIT_CHUNK ranks whose total the
