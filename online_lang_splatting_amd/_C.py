@@ -262,26 +262,31 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
 def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 cfg=None):
-    """RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:243-331.  `cfg`: see current_config()."""
+                                 cfg=None, with_tau_sum=False):
+    """RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:243-331.  `cfg`: see current_config().
+    with_tau_sum: append the device-reduced sum over P of dL_dtau ([6] = [rho | theta]) to the tuple — what the
+    reference's Python layer computes with torch.sum (DGR/diff_gaussian_rasterization/__init__.py:383-385)."""
     g = _backward(0, bg, means3D, radii, colors, None, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                   projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, None, dL_dout_depths, sh, degree,
                   campos, geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=cfg)
-    return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
-            g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+    out = (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
+           g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+    return out + (g["dL_dtau_sum"],) if with_tau_sum else out
 
 
 def rasterize_language_gaussians_backward(bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
                                           cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy,
                                           dL_dout_color, dL_dout_language, dL_dout_depth, sh, degree, campos,
-                                          geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=None):
-    """RasterizeLanguageGaussiansBackwardCUDA, DGR/rasterize_points.cu:333-455.  `cfg`: see current_config()."""
+                                          geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=None, with_tau_sum=False):
+    """RasterizeLanguageGaussiansBackwardCUDA, DGR/rasterize_points.cu:333-455.  `cfg`: see current_config();
+    `with_tau_sum`: see rasterize_gaussians_backward."""
     g = _backward(language.shape[1], bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
                   cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
                   dL_dout_language, dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
                   debug, cfg=cfg)
-    return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dlanguage"], g["dL_dopacity"], g["dL_dmeans3D"],
-            g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+    out = (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dlanguage"], g["dL_dopacity"], g["dL_dmeans3D"],
+           g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+    return out + (g["dL_dtau_sum"],) if with_tau_sum else out
 
 
 def backward_all(F, *args, **kw):

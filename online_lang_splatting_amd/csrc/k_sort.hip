@@ -108,6 +108,8 @@ struct FrameHousekeeping {
   int32_t* num_rendered_dev;
   u32* ranges;
   int nranges;  // 2 * tiles
+  int32_t* host_mailbox;
+  int32_t host_seq;
 };
 
 __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
@@ -205,6 +207,10 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
       if (house.num_rendered_dev) {
         house.num_rendered_dev[0] = (int32_t)cnt;
         house.num_rendered_dev[1] = ok ? 0 : 1;
+      }
+      if (house.host_mailbox) {  // the drop-in entry's host is polling for the count (olsr_api.hip: PinnedCount)
+        __hip_atomic_store(&house.host_mailbox[0], (int32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&house.host_mailbox[1], house.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
@@ -549,6 +555,8 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
     h.num_rendered_dev = house->num_rendered_dev;
     h.ranges = house->ranges;
     h.nranges = house->nranges;
+    h.host_mailbox = house->host_mailbox;
+    h.host_seq = house->host_seq;
   }
   int64_t nb = (n_host + (int64_t)FS_T * 4 - 1) / ((int64_t)FS_T * 4);  // 4 keys (one 16-byte load) per thread ...
   if (nb < 1) nb = 1;

@@ -14,6 +14,8 @@
 #include "../../include/olsr.h"
 #include "olsr_device.h"
 #include "olsr_kernels.h"
+
+#include <chrono>
 #include "olsr_state.h"
 
 using namespace olsr;
@@ -142,14 +144,17 @@ bool force_legacy_sort() {
   return e && e[0] == '1';
 }
 
-// a pinned word for the instance count of the drop-in (synchronising) entry: the copy is asynchronous and the host
-// waits on an event, so the GPU keeps sorting while the host allocates the binning buffer
+// The drop-in (synchronising) entry needs the instance count on the host (the reference's blocking D2H,
+// CR/rasterizer_impl.cu:454-455).  No copy, no event: block 0 of the histogram kernel stores the count and then a
+// sequence number into two words of mapped, coherent host memory with system-scope stores ("the data is the flag"),
+// and the host polls the second word — while the GPU goes straight on to the depth sort.  (A hipMemcpyAsync in the
+// stream cost a 4 us copy kernel and a 6 us bubble in front of the first radix pass.)
 struct PinnedCount {
-  int32_t* p = nullptr;
-  hipEvent_t ev = nullptr;
+  int32_t* p = nullptr;   // host view: {count, sequence}
+  int32_t* dp = nullptr;  // device view of the same two words
+  int32_t seq = 0;
   ~PinnedCount() {
     if (p) (void)hipHostFree(p);
-    if (ev) (void)hipEventDestroy(ev);
   }
 };
 thread_local PinnedCount g_pinned;
@@ -183,16 +188,19 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     // digit totals of the four depth passes in one read of the keys + the frame's counters (instances emitted,
     // the reference's num_rendered, overflow against the capacity), tile ranges reset to "empty"
     FusedHouse house{g.part_rect, g.part_count, (s.P + 255) / 256, sync_mode ? 0x7FFFFFFFLL : (long long)bp.capacity,
-                     g.counters, num_rendered_dev, im.ranges, 2 * d.ntiles};
-    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, st);
+                     g.counters, num_rendered_dev, im.ranges, 2 * d.ntiles, nullptr, 0};
     if (sync_mode) {
       if (!g_pinned.p) {
-        HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 2 * sizeof(int32_t), hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&g_pinned.ev, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 2 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void**)&g_pinned.dp, g_pinned.p, 0));
+        g_pinned.p[0] = 0;
+        g_pinned.p[1] = 0;
       }
-      HIP_TRY(hipMemcpyAsync(g_pinned.p, g.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipEventRecord(g_pinned.ev, st));
+      g_pinned.seq = (g_pinned.seq == 0x7FFFFFFF) ? 1 : g_pinned.seq + 1;
+      house.host_mailbox = g_pinned.dp;
+      house.host_seq = g_pinned.seq;
     }
+    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, st);
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
     // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
     if (!legacy && fused_sort_applicable(s.P, 32)) {
@@ -214,8 +222,18 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     if (s.P > 0) {
       // the reference's blocking D2H (CR/rasterizer_impl.cu:454-455) — but the count was ready before the depth sort,
       // which keeps running while the host waits here and allocates
-      HIP_TRY(hipEventSynchronize(g_pinned.ev));
-      R = g_pinned.p[0];
+      volatile int32_t* box = g_pinned.p;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (uint32_t spin = 0; __atomic_load_n(&box[1], __ATOMIC_ACQUIRE) != g_pinned.seq; ++spin) {
+        __builtin_ia32_pause();
+        if ((spin & 0xFFFFu) == 0xFFFFu) {  // every ~65 k polls: did the stream die, or is this taking seconds?
+          const hipError_t q = hipStreamQuery(st);
+          if (q != hipSuccess && q != hipErrorNotReady) return fail(OLSR_ERR_DEVICE, hipGetErrorString(q));
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+            return fail(OLSR_ERR_DEVICE, "the instance count never arrived from the device");
+        }
+      }
+      R = box[0];
       if (R < 0) return fail(OLSR_ERR_CAPACITY, "instance count exceeds 2^31-1");
     }
     n_host = R;

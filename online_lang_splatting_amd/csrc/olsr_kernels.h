@@ -63,6 +63,8 @@ struct FusedHouse {  // the frame's bookkeeping done by block 0 of the depth sor
   int32_t* num_rendered_dev;
   uint32_t* ranges;  // initialised to {UINT_MAX, 0} per tile (empty)
   int nranges;
+  int32_t* host_mailbox;  // (may be null) device view of two host words: receives {R, host_seq}, in this order
+  int32_t host_seq;
 };
 bool fused_sort_applicable(int64_t n_host, int bits);
 int fused_sort_digit_bits(int bits, int* passes_out);

@@ -39,8 +39,8 @@ import torch
 import torch.nn as nn
 
 from . import _C, _abi
-from .rasterizer import (GaussianRasterizationSettings, _check_exclusive, _or_empty, _RasterizerBase,  # noqa: F401
-                         _settings_args, _split_tau)
+from .rasterizer import (GaussianRasterizationSettings, _check_exclusive, _cotangent, _or_empty,  # noqa: F401
+                         _RasterizerBase, _settings_args, _split_tau)
 
 TILE = 16  # BLOCK_X = BLOCK_Y = 16, DGR-D/cuda_rasterizer/config.h:17-18
 LANGUAGE_CHANNELS = 3  # NUM_LANGUAGE_CHANNELS as shipped, DGR-D/cuda_rasterizer/config.h:16 (any supported F works here)
@@ -72,17 +72,21 @@ class _RasterizeGaussians16(torch.autograd.Function):
         ctx.rs, ctx.R, ctx.cfg = rs, R, cfg
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
+        ctx.set_materialize_grads(False)
         return color, radii, depth, opacity, n_touched
 
     @staticmethod
     def backward(ctx, g_color, g_radii, g_depth, g_opacity, g_n_touched):
         rs = ctx.rs
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
-        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_tau) = _C.rasterize_gaussians_backward(
+        H, W = rs.image_height, rs.image_width
+        g_color, g_depth = _cotangent(g_color, (3, H, W), means3D), _cotangent(g_depth, (1, H, W), means3D)
+        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot, _g_tau,
+         tau_sum) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             *_settings_args(rs), g_color, g_depth, sh, rs.sh_degree, rs.campos, geom, ctx.R, binning, img, rs.debug,
-            cfg=ctx.cfg)
-        g_theta, g_rho = _split_tau(g_tau)
+            cfg=ctx.cfg, with_tau_sum=True)
+        g_theta, g_rho = _split_tau(tau_sum)
         return g_means3D, g_means2D, g_sh, g_colors, g_opac, g_scales, g_rot, g_cov3D, g_theta, g_rho, None
 
 
@@ -111,6 +115,7 @@ class _RasterizeLanguageGaussiansDisentangled(torch.autograd.Function):
                               cov3Ds_precomp, cov3Ds_precomp_lang, r1.clamp(min=0), r2.clamp(min=0), sh, dummy_rgb,
                               geom1, bin1, img1, geom2, bin2, img2)
         ctx.mark_non_differentiable(radii, radii_lang, n_touched, n_touched_lang)
+        ctx.set_materialize_grads(False)
         return color, language, radii, radii_lang, depth, opacity, opacity_lang, n_touched, n_touched_lang
 
     @staticmethod
@@ -118,10 +123,14 @@ class _RasterizeLanguageGaussiansDisentangled(torch.autograd.Function):
         rs = ctx.rs
         (colors_precomp, language_precomp, means3D, scales, scales_lang, rotations, rotations_lang, cov3Ds_precomp,
          cov3Ds_precomp_lang, radii1, radii2, sh, dummy_rgb, geom1, bin1, img1, geom2, bin2, img2) = ctx.saved_tensors
-        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_tau) = _C.rasterize_gaussians_backward(
+        H, W = rs.image_height, rs.image_width
+        g_color, g_depth = _cotangent(g_color, (3, H, W), means3D), _cotangent(g_depth, (1, H, W), means3D)
+        g_language = _cotangent(g_language, (language_precomp.shape[1], H, W), means3D)
+        (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot, _g_tau,
+         tau_sum) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii1, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             *_settings_args(rs), g_color, g_depth, sh, rs.sh_degree, rs.campos, geom1, ctx.R1, bin1, img1, rs.debug,
-            cfg=ctx.cfg)
+            cfg=ctx.cfg, with_tau_sum=True)
         # the language loop sees no colour / depth cotangent (DGR-D backward.cu:1337-1428); its mean and pose
         # gradients do not exist in DGR-D (computeCov2DCUDA_no_tau, :354-436) and are dropped here
         (_m2, _c, g_language_precomp, g_opac_lang, _m3, g_cov3D_lang, _sh, g_scales_lang, g_rot_lang,
@@ -129,7 +138,7 @@ class _RasterizeLanguageGaussiansDisentangled(torch.autograd.Function):
             rs.bg, means3D, radii2, dummy_rgb, language_precomp, scales_lang, rotations_lang, rs.scale_modifier,
             cov3Ds_precomp_lang, *_settings_args(rs), torch.zeros_like(g_color), g_language, torch.zeros_like(g_depth),
             None, 0, rs.campos, geom2, ctx.R2, bin2, img2, rs.debug, cfg=ctx.cfg)
-        g_theta, g_rho = _split_tau(g_tau)
+        g_theta, g_rho = _split_tau(tau_sum)
         return (g_means3D, g_means2D, g_sh, g_colors, g_language_precomp, g_opac, g_opac_lang, g_scales, g_scales_lang,
                 g_rot, g_rot_lang, g_cov3D, g_cov3D_lang, g_theta, g_rho, None)
 

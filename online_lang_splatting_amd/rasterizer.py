@@ -38,10 +38,16 @@ def _settings_args(rs):
     return (rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, rs.tanfovx, rs.tanfovy)
 
 
-def _split_tau(grad_tau):
-    """[P,6] -> (grad_theta[1,3], grad_rho[1,3]); dL_dtau = [rho | theta] per Gaussian (:383-385)."""
-    tau = torch.sum(grad_tau.view(-1, 6), dim=0)
-    return tau[3:].view(1, -1), tau[:3].view(1, -1)
+def _split_tau(tau_sum):
+    """[6] -> (grad_theta[1,3], grad_rho[1,3]).  dL_dtau = [rho | theta] per Gaussian; the reference sums it over P with
+    torch.sum (:383-385), here the library's backward already left the sum behind (fixed order, one tiny kernel)."""
+    return tau_sum[3:].view(1, -1), tau_sum[:3].view(1, -1)
+
+
+def _cotangent(g, shape, like):
+    """Autograd hands None for an output the loss never touched (the Functions do not materialise zero gradients: three
+    memsets per backward for radii / opacity / n_touched, which are ignored anyway): the kernels want zeros."""
+    return g if g is not None else torch.zeros(shape, dtype=torch.float32, device=like.device)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -61,18 +67,22 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.olsr_cfg = cfg
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
+        ctx.set_materialize_grads(False)
         return color, radii, depth, opacity, n_touched
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_out_radii, grad_out_depth, grad_out_opacity, grad_n_touched):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        H, W = rs.image_height, rs.image_width
+        grad_out_color = _cotangent(grad_out_color, (3, H, W), means3D)
+        grad_out_depth = _cotangent(grad_out_depth, (1, H, W), means3D)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, grad_tau) = _C.rasterize_gaussians_backward(
+         grad_rotations, _grad_tau, tau_sum) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             *_settings_args(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-            binning, img, rs.debug, cfg=ctx.olsr_cfg)
-        grad_theta, grad_rho = _split_tau(grad_tau)
+            binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True)
+        grad_theta, grad_rho = _split_tau(tau_sum)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
 
@@ -96,6 +106,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, language_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
+        ctx.set_materialize_grads(False)
         return color, language, radii, depth, opacity, n_touched
 
     @staticmethod
@@ -104,12 +115,16 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, language_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
          img) = ctx.saved_tensors
+        H, W = rs.image_height, rs.image_width
+        grad_out_color = _cotangent(grad_out_color, (3, H, W), means3D)
+        grad_out_language = _cotangent(grad_out_language, (language_precomp.shape[1], H, W), means3D)
+        grad_out_depth = _cotangent(grad_out_depth, (1, H, W), means3D)
         (grad_means2D, grad_colors_precomp, grad_language_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
-         grad_sh, grad_scales, grad_rotations, grad_tau) = _C.rasterize_language_gaussians_backward(
+         grad_sh, grad_scales, grad_rotations, _grad_tau, tau_sum) = _C.rasterize_language_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, language_precomp, scales, rotations, rs.scale_modifier,
             cov3Ds_precomp, *_settings_args(rs), grad_out_color, grad_out_language, grad_out_depth, sh, rs.sh_degree,
-            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, cfg=ctx.olsr_cfg)
-        grad_theta, grad_rho = _split_tau(grad_tau)
+            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True)
+        grad_theta, grad_rho = _split_tau(tau_sum)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_language_precomp, grad_opacities,
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
 
