@@ -375,7 +375,7 @@ __device__ __forceinline__ u32 lb_block_exclusive(u32* status, u32 b, u32 total,
 //                         thousands of tiles and cluster at the front of the depth order); a Gaussian that straddles
 //                         two blocks has its row spans evaluated by both.
 #ifndef OLSR_EB_OUT
-#define OLSR_EB_OUT 2048
+#define OLSR_EB_OUT 1024
 #endif
 #ifndef OLSR_EB_T
 #define OLSR_EB_T 256

@@ -277,7 +277,7 @@ def test_emission_of_screen_filling_splats(hip, oracle):
     """The emission expands Gaussians -> tile rows -> tiles through tables in LDS (k_binning.hip:
     emit_balanced_kernel).  A few hundred splats that each cover most of a 640x480 frame give a batch of 256 depth ranks
     more tile rows than one fill of the row table holds (16 x 256), rows of 40 tiles that a wave writes together, and
-    Gaussians that straddle many 2048-instance output windows."""
+    Gaussians that straddle many 1024-instance output windows."""
     sc = make_scene(700, 640, 480, 3, seed=91, scale_mult=25.0)
     _check(hip, oracle, sc, seed=9)
     _check(hip, oracle, make_scene(300, 333, 257, 0, seed=92, scale_mult=40.0), seed=10, tile=16)
