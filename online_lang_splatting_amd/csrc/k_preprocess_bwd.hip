@@ -21,12 +21,17 @@
 // dL_dtau is additionally reduced on the device, deterministically: fixed-order block
 // partials, then a single-wave pass (replaces the torch.sum of
 // DGR/diff_gaussian_rasterization/__init__.py:383).
+#include <algorithm>
+
 #include "olsr_device.h"
 #include "olsr_kernels.h"
 
 namespace olsr {
 
-constexpr int PB_THREADS = 128;
+#ifndef OLSR_PB_THREADS
+#define OLSR_PB_THREADS 128
+#endif
+constexpr int PB_THREADS = OLSR_PB_THREADS;
 int tau_partial_blocks(int P) { return (P + PB_THREADS - 1) / PB_THREADS; }
 
 constexpr int next_pow2_(int v) {
@@ -53,7 +58,10 @@ __device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
 }
 
 constexpr int RR_THREADS = 256;
-constexpr int RR_BIG_BLOCKS = 2048;  // persistent grid of the wave-per-Gaussian kernel (8 waves/SIMD)
+#ifndef OLSR_RR_BLOCKS
+#define OLSR_RR_BLOCKS 8192  // (65 k listed Gaussians at config 3: 1024 / 2048 / 4096 / 8192 blocks: 30 / 29 / 24 / 23 us)
+#endif
+constexpr int RR_BIG_BLOCKS = OLSR_RR_BLOCKS;  // persistent grid of the wave-per-Gaussian kernel (8 waves/SIMD)
 
 template <int F, int N>
 __device__ __forceinline__ void add_row(const float* __restrict__ rows, u32 row, float (&acc)[N]) {
@@ -633,7 +641,9 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
                         hipStream_t st) {
   const int nb = tau_partial_blocks(s.P);
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
-  row_reduce_big_kernel<F><<<RR_BIG_BLOCKS, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, s.P, b.rowbase, g.counters);
+  // (persistent grid: at most one wave per 4 Gaussians — the lists never hold more than a fraction of them)
+  const int rr_blocks = std::min(RR_BIG_BLOCKS, std::max(256, s.P / 16));
+  row_reduce_big_kernel<F><<<rr_blocks, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, s.P, b.rowbase, g.counters);
   const size_t bucket_lds = o.bucket_flat ? sizeof(float) * PB_THREADS * (size_t)(11 + 3 * s.M + s.F) : 0;
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, bucket_lds, st>>>(
       s.P, s.D, s.M, g.gacc, g.tiles_touched, g.inst_start, b.rowbase, rows, g.counters, s.means3D, radii, s.shs,
