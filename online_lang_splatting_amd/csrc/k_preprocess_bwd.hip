@@ -408,11 +408,14 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
         const float det = a * c - b * b;
         const float inv_det2 = 1.0f / ((det * det) + 0.0000001f);
         const float gx = acc[2], gy = acc[3], gw = acc[4];
-        // adj G adj with adj = [[c, -b], [-b, a]]: first H = G adj, then adj H
-        const float h00 = gx * c - gy * b, h01 = gy * a - gx * b, h10 = gy * c - gw * b, h11 = gw * a - gy * b;
-        float S00 = -(c * h00 - b * h10) * inv_det2;
-        float S01 = -(c * h01 - b * h11) * inv_det2;
-        float S11 = -(a * h11 - b * h01) * inv_det2;
+        // The three entries of -adj G adj, adj = [[c, -b], [-b, a]].  For a large splat a c and b^2 agree to two digits
+        // and each entry is what is left after three terms of order 1e8 cancel: ANY association differs from any other by
+        // that amplified rounding (1e-5 .. 1e-4 relative, found by scripts/oracle_stress.py), so these three — and only
+        // these — keep the association of the reference's source (CR/backward.cu:220-228), with det - a c standing for
+        // -b^2 and S01 being half of its dL_db.
+        float S00 = inv_det2 * (-c * c * gx + 2 * b * c * gy + (det - a * c) * gw);
+        float S11 = inv_det2 * (-a * a * gw + 2 * a * b * gy + (det - a * c) * gx);
+        float S01 = inv_det2 * (b * c * gx - (det + 2 * b * b) * gy + a * b * gw);
         if (inv_det2 == 0.f) S00 = S01 = S11 = 0.f;  // (det^2 overflowed: the reference leaves these gradients zero)
         // dL/dV = M^T S M
         float SMx[3], SMy[3];  // rows of S M (2x3)

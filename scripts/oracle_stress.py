@@ -1,0 +1,50 @@
+"""Randomised oracle-vs-GPU campaign (one-off confidence run, not part of the test suite): N random scenes — Gaussian
+count, image size, tile edge, language width, footprint scale over two decades, camera yaw / offset, SH degree — each put
+through tests/test_gpu_parity.py::_check (forward bit-exact in both binning modes, instance lists, every gradient).
+
+    python scripts/oracle_stress.py [N=200] [seed0=0]"""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from online_lang_splatting_amd import _C as hip, _abi
+from online_lang_splatting_amd.scene import default_camera, make_scene
+from oracle import oracle_C as oracle
+import test_gpu_parity as T
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+t0 = time.time()
+fails = 0
+notes = 0
+for k in range(N):
+    g = torch.Generator().manual_seed(77_000 + seed0 + k)
+    r = lambda: float(torch.rand(1, generator=g))
+    P = int(300 + r() * 9000)
+    W, H = int(64 + r() * 400), int(48 + r() * 300)
+    tile = 16 if r() < 0.4 else 15
+    F = (0, 3, 15, 16, 32)[int(r() * 5) % 5]
+    deg = int(r() * 4) % 4
+    cam = default_camera(W, H, yaw_deg=r() * 50 - 25, tx=r() - 0.5)
+    sc = make_scene(P, W, H, F, seed=900_000 + seed0 + k, camera=cam, scale_mult=10 ** (r() * 2.2 - 1.2), max_sh_degree=deg)
+    mode = _abi.BWD_EXACT if r() < 0.3 else _abi.BWD_REFERENCE
+    try:
+        T._check(hip, oracle, sc, seed=k, tile=tile, mode=mode)
+    except AssertionError as e:
+        # the max-norm bound (1e-4 of the tensor's largest magnitude) is what the test suite asserts on its fixed scenes;
+        # a breach here is re-judged by the north-star criterion per element (>= 99.99 % within 1e-4, worst <= 2e-2)
+        note = f"scene {k}: P={P} {W}x{H} tile={tile} F={F} deg={deg} mode={mode}: {str(e)[:200]}"
+        try:
+            T._check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2)
+            notes += 1
+            print("NOTE (max-norm only) " + note, flush=True)
+        except AssertionError as e2:
+            fails += 1
+            print("FAIL " + note + " | per element: " + str(e2)[:200], flush=True)
+    finally:
+        hip.TILE, hip.BWD_MODE, hip.BINNING = 15, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE
+        oracle.TILE, oracle.BWD_MODE = 15, 0
+    if (k + 1) % 25 == 0:
+        print(f"{k + 1}/{N} scenes, {fails} failures, {notes} notes, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {N} scenes, {fails} failures, {notes} max-norm notes")
+sys.exit(1 if fails else 0)
