@@ -165,8 +165,11 @@ __device__ __forceinline__ Rect get_rect(float px, float py, int max_radius, int
   Rect r;
   r.x0 = min(gx, max(0, f2i_sat((px - (float)max_radius) / (float)TILE)));
   r.y0 = min(gy, max(0, f2i_sat((py - (float)max_radius) / (float)TILE)));
-  r.x1 = min(gx, max(0, f2i_sat((px + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
-  r.y1 = min(gy, max(0, f2i_sat((py + (float)max_radius + (float)(TILE - 1)) / (float)TILE)));
+  // `p.x + max_radius + BLOCK_X - 1` is three float operations in the reference's source order (+ radius, + BLOCK, - 1),
+  // not `+ (BLOCK - 1)`: the two differ in the last bit when the sum crosses a power of two, and a whole tile column
+  // hangs on that bit (found by scripts/oracle_stress.py: mean x = 58.999992, radius 54, 16-pixel tiles)
+  r.x1 = min(gx, max(0, f2i_sat((((px + (float)max_radius) + (float)TILE) - 1.0f) / (float)TILE)));
+  r.y1 = min(gy, max(0, f2i_sat((((py + (float)max_radius) + (float)TILE) - 1.0f) / (float)TILE)));
   return r;
 }
 

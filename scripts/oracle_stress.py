@@ -28,14 +28,23 @@ for k in range(N):
     cam = default_camera(W, H, yaw_deg=r() * 50 - 25, tx=r() - 0.5)
     sc = make_scene(P, W, H, F, seed=900_000 + seed0 + k, camera=cam, scale_mult=10 ** (r() * 2.2 - 1.2), max_sh_degree=deg)
     mode = _abi.BWD_EXACT if r() < 0.3 else _abi.BWD_REFERENCE
+    kw = {}
+    if r() < 0.25:
+        kw["colors_precomp"] = torch.rand(P, 3, generator=g)
+    if r() < 0.2:  # precomputed 3D covariance: Sigma = R S S^T R^T of the scene's own scales / rotations, perturbed
+        L = torch.randn(P, 3, 3, generator=g) * sc.scales.mean()
+        Sg = L @ L.transpose(1, 2)
+        kw["cov3D_precomp"] = torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).contiguous()
+    elif r() < 0.3:
+        kw["scale_modifier"] = 0.5 + r()
     try:
-        T._check(hip, oracle, sc, seed=k, tile=tile, mode=mode)
+        T._check(hip, oracle, sc, seed=k, tile=tile, mode=mode, **kw)
     except AssertionError as e:
         # the max-norm bound (1e-4 of the tensor's largest magnitude) is what the test suite asserts on its fixed scenes;
         # a breach here is re-judged by the north-star criterion per element (>= 99.99 % within 1e-4, worst <= 2e-2)
-        note = f"scene {k}: P={P} {W}x{H} tile={tile} F={F} deg={deg} mode={mode}: {str(e)[:200]}"
+        note = f"scene {k}: P={P} {W}x{H} tile={tile} F={F} deg={deg} mode={mode} {sorted(kw)}: {str(e)[:200]}"
         try:
-            T._check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2)
+            T._check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2, **kw)
             notes += 1
             print("NOTE (max-norm only) " + note, flush=True)
         except AssertionError as e2:

@@ -285,6 +285,30 @@ def test_emission_of_screen_filling_splats(hip, oracle):
     _check(hip, oracle, make_scene(300, 333, 257, 0, seed=92, scale_mult=40.0), seed=10, tile=16)
 
 
+def test_rect_upper_bound_in_the_references_operation_order(hip, oracle):
+    """getRect's upper bound is `p.x + max_radius + BLOCK_X - 1` — three float operations (CR/auxiliary.h:52-55).  Folding
+    `BLOCK_X - 1` into one constant changes the last bit when the sum crosses 128, and with it a whole tile column:
+    scene 5323 of scripts/oracle_stress.py (a Gaussian with mean x = 58.999992, radius 54, 16-pixel tiles: 64 tiles in
+    the reference, 56 with the folded constant)."""
+    from online_lang_splatting_amd.scene import default_camera
+    g = torch.Generator().manual_seed(77_000 + 5000 + 323)
+    r = lambda: float(torch.rand(1, generator=g))  # noqa: E731
+    P = int(300 + r() * 9000)
+    W, H = int(64 + r() * 400), int(48 + r() * 300)
+    tile = 16 if r() < 0.4 else 15
+    F = (0, 3, 15, 16, 32)[int(r() * 5) % 5]
+    deg = int(r() * 4) % 4
+    cam = default_camera(W, H, yaw_deg=r() * 50 - 25, tx=r() - 0.5)
+    sc = make_scene(P, W, H, F, seed=900_000 + 5000 + 323, camera=cam, scale_mult=10 ** (r() * 2.2 - 1.2), max_sh_degree=deg)
+    assert (P, W, H, tile, F) == (6312, 463, 250, 16, 15)
+    fo, _ = run_backend(oracle, sc, None, 1, tile, 0)
+    fr, _ = run_backend(hip, sc, torch.device(DEV), 1, tile, 0, binning=_abi.BINNING_RECT)
+    assert fr["R"] == fo["R"] == 314790
+    tt = hip.state_field("geometry", fr["geom"], "tiles_touched", P=sc.P, F=F, dtype=torch.int32, count=sc.P).cpu()
+    assert int(tt[4248]) == 64 and torch.equal(tt, oracle.get_field(fo["geom"], "tiles_touched"))
+    oracle.release(fo["geom"])
+
+
 @pytest.mark.parametrize("kpt", [2, 4, 8, 12, 16])
 def test_every_sort_pass_instantiation(hip, oracle, monkeypatch, kpt):
     """The radix passes pick their keys-per-thread from the input size (olsr_state.h: sort_plan); OLSR_SORT_KPT pins it,
