@@ -2,8 +2,8 @@
 count, image size, tile edge, language width, footprint scale over two decades, camera yaw / offset, SH degree — each put
 through tests/test_gpu_parity.py::_check (forward bit-exact in both binning modes, instance lists, every gradient).
 
-    python scripts/oracle_stress.py [N=200] [seed0=0]"""
-import os, sys, time
+    python scripts/oracle_stress.py [N=200] [seed0=0] [vary]"""
+import math, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,6 +14,7 @@ import test_gpu_parity as T
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+VARY = len(sys.argv) > 3 and sys.argv[3] == "vary"  # also randomise intrinsics, background, opacity range, pitch
 t0 = time.time()
 fails = 0
 notes = 0
@@ -27,6 +28,16 @@ for k in range(N):
     deg = int(r() * 4) % 4
     cam = default_camera(W, H, yaw_deg=r() * 50 - 25, tx=r() - 0.5)
     sc = make_scene(P, W, H, F, seed=900_000 + seed0 + k, camera=cam, scale_mult=10 ** (r() * 2.2 - 1.2), max_sh_degree=deg)
+    if VARY:  # (second-generation scenes: intrinsics, background, opacity range, a pitch on top of the yaw)
+        cam.fx, cam.fy = W * (0.3 + 0.9 * r()), W * (0.3 + 0.9 * r())
+        cam.cx, cam.cy = (W - 1) / 2 + (r() - 0.5) * 0.3 * W, (H - 1) / 2 + (r() - 0.5) * 0.3 * H
+        a_ = (r() - 0.5) * 0.5
+        Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, math.cos(a_), -math.sin(a_)], [0.0, math.sin(a_), math.cos(a_)]])
+        cam.R = (Rx @ cam.R).contiguous()
+        cam.T = cam.T + torch.tensor([0.0, (r() - 0.5) * 0.6, (r() - 0.5) * 0.6])
+        sc.bg = torch.rand(3, generator=g) if r() < 0.6 else sc.bg
+        if r() < 0.5:
+            sc.opacities[:] = torch.sigmoid(torch.randn(sc.opacities.shape, generator=g) * (1 + 4 * r()) + (r() - 0.5) * 4)
     mode = _abi.BWD_EXACT if r() < 0.3 else _abi.BWD_REFERENCE
     kw = {}
     if r() < 0.25:
