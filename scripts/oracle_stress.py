@@ -2,7 +2,7 @@
 count, image size, tile edge, language width, footprint scale over two decades, camera yaw / offset, SH degree — each put
 through tests/test_gpu_parity.py::_check (forward bit-exact in both binning modes, instance lists, every gradient).
 
-    python scripts/oracle_stress.py [N=200] [seed0=0] [vary]"""
+    python scripts/oracle_stress.py [N=200] [seed0=0] [vary|big]"""
 import math, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,8 @@ import test_gpu_parity as T
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-VARY = len(sys.argv) > 3 and sys.argv[3] == "vary"  # also randomise intrinsics, background, opacity range, pitch
+VARY = len(sys.argv) > 3 and sys.argv[3] in ("vary", "big")
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"  # also randomise intrinsics, background, opacity range, pitch
 t0 = time.time()
 fails = 0
 notes = 0
@@ -23,6 +24,9 @@ for k in range(N):
     r = lambda: float(torch.rand(1, generator=g))
     P = int(300 + r() * 9000)
     W, H = int(64 + r() * 400), int(48 + r() * 300)
+    if BIG:  # (third generation: up to 80 k Gaussians on up to 964 x 748 pixels — several staging batches per tile)
+        P = int(10_000 + r() * 70_000)
+        W, H = int(200 + r() * 764), int(150 + r() * 598)
     tile = 16 if r() < 0.4 else 15
     F = (0, 3, 15, 16, 32)[int(r() * 5) % 5]
     deg = int(r() * 4) % 4
