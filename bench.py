@@ -108,11 +108,26 @@ def measured_valu(kernel_stage, F):
     return None, None
 
 
-# wave64 VALU instructions / s the chip can issue: 256 CUs x 4 SIMDs, ONE instruction per quad-cycle (4 clocks) per SIMD.
-# Evidence (profiles/*_pmc_valu.json): SQ_ACTIVE_INST_VALU (quad-cycles) == SQ_INSTS_VALU for every kernel, packed-fp32
-# instructions included — an instruction holds the SIMD's issue for 4 clocks whether it is v_fma_f32 or v_pk_fma_f32
-# (which is why packed math pays), and at ~1 resident wave issuing per SIMD the composite kernels sit at 80-96 % of it.
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0
+# wave64 VALU instructions / s the chip can issue = 256 CUs x 4 SIMDs x clock / (cycles one instruction holds a SIMD).
+# MI355X_MICROARCH.md: `v_fma_f32 (wave64): 2 cyc (SIMD-32)`.  Measured here (scripts/probe/valu_ubench.hip ->
+# profiles/r3_valu_ubench.json): full-rate instructions (v_fma / v_mul / v_add / v_mov / v_and)
+# reach 2.3-2.6 cycles per instruction per SIMD from 4 resident waves on — the guide's figure, not the one instruction per
+# quad-cycle rounds 1-2 assumed; v_pk_*_f32, v_max / v_min, v_cvt, v_rndne, v_cndmask, DPP: ~4.2-5 cycles (half rate);
+# v_exp / v_rcp / v_sqrt, v_permlane*_swap: ~8.2; v_readlane ~10.  A single wave issues at most one instruction per
+# ~5 cycles (dependent: ~8.5), so fewer than ~3 waves per SIMD cannot saturate the pipe.  `peak` below is the guide's
+# 2 cycles; `peak_measured` the best full-rate row of the committed micro-benchmark.
+VALU_CYCLES_GUIDE = 2.0
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / VALU_CYCLES_GUIDE
+
+
+def measured_valu_cycles():
+    """Best cycles-per-instruction-per-SIMD of a full-rate VALU instruction in profiles/r3_valu_ubench.json."""
+    path = os.path.join(ROOT, "profiles", "r3_valu_ubench.json")
+    if not os.path.exists(path):
+        return None, None
+    rows = json.load(open(path))["rows"]
+    full = [r["cycles_per_inst_per_simd"] for r in rows if r["op"] in ("v_fma_f32", "v_mul_f32", "v_add_f32", "v_fmac_f32")]
+    return (min(full) if full else None), os.path.basename(path)
 
 
 def percentiles(xs):
@@ -234,6 +249,152 @@ def dropin_leg(sc, dev, steps, warmup):
             "frame_interval_ms": percentiles(gaps)}
 
 
+
+def _sized_capacity(F, g_dev, c0, H, W, sh_degree, dev, cfg):
+    """Instances of one synchronous forward under the knobs cfg = (tile, backward mode, binning)."""
+    from online_lang_splatting_amd import _C
+    e = torch.empty(0, device=dev)
+    r = _C._forward(F, g_dev["bg"], g_dev["means3D"], e, g_dev["language"] if F > 0 else None, g_dev["opacities"],
+                    g_dev["scales"], g_dev["rotations"], 1.0, e, c0["viewmatrix"], c0["projmatrix"], c0["projmatrix_raw"],
+                    c0["tanfovx"], c0["tanfovy"], H, W, g_dev["shs"], sh_degree, c0["campos"], False, False, cfg=cfg)
+    return int(r[0])
+
+
+def bracket_legs(sc, g_dev, c0, cots, dev, steps, dims):
+    """One frame in flight, un-profiled, through the same sync-free entry points as the headline, for the settings the
+    headline does NOT use (missing #3): the exact backward (all 225 pixels of a tile, four waves, no
+    survivor shortcut), 16x16 tiles (DGR-D/cuda_rasterizer/config.h:17-18; the reduction tree keeps every rank) and the
+    reference's bounding-square tile lists (OLSR_BINNING_RECT).  They bracket the reference-mode headline from below."""
+    from online_lang_splatting_amd.frame_shard import GradientBucket, GradLayout, RasterWorkspace
+    P, W, H, F, M = dims
+    dc, dl, dd = cots
+    legs = {}
+    for name, cfg in (("exact_mode", (15, _abi.BWD_EXACT, _abi.BINNING_ELLIPSE)),
+                      ("tile16", (16, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE)),
+                      ("rect_binning", (15, _abi.BWD_REFERENCE, _abi.BINNING_RECT))):
+        tile, mode, binning = cfg
+        R = _sized_capacity(F, g_dev, c0, H, W, sc.sh_degree, dev, cfg)
+        ws = RasterWorkspace(P, W, H, F, M, int(R * 1.1) + (1 << 16), dev, tile=tile, bwd_mode=mode, binning=binning)
+        bucket = GradientBucket(P, GradLayout(M, F), dev)
+
+        def one():
+            ws.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
+            ws.forward()
+            ws.backward(dc, dl, dd, bucket=bucket, first=True, bucket_only=True)
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        L_rows, row_ovf = ws.backward_status()
+        legs[name] = {"tile": tile, "backward_mode": "exact" if mode == _abi.BWD_EXACT else "reference",
+                      "binning": "rect" if binning == _abi.BINNING_RECT else "ellipse", "value": round(steps / el, 3),
+                      "unit": "frames/s", "ms_per_frame": round(1e3 * el / steps, 4), "steps": steps, "R_binned": R,
+                      "live_gradient_rows": L_rows, "capacity_overflow": bool(ws.rendered()[1] or row_ovf)}
+        del ws, bucket
+    return legs
+
+
+def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4, views=12):
+    """BASELINE.json configs[3] (Replica room0 `slam.py` loop) cannot run in this image (no data, no SED / auto-encoder
+    checkpoints, front-end dependencies absent: SURVEY.md section 8(d)); what it spends its rasterizer time in can:
+      tracking iteration  utils/slam_frontend.py:218-243 — render, get_loss_tracking, backward to the pose only, Adam on the
+                          pose increments, update_pose; iterations DEPEND on each other (latency, not throughput)
+      mapping iteration   utils/slam_backend.py:510-760 — 12 views of the same Gaussians, mapping + language loss, summed
+                          gradients, one Adam step
+    on synthetic data of config 3's shape, entirely on this library (online_lang_splatting_amd/slam_iterations.py)."""
+    from online_lang_splatting_amd.frame_shard import FrameLanes, RasterWorkspace
+    from online_lang_splatting_amd.scene import arc_cameras, default_camera
+    from online_lang_splatting_amd.slam_iterations import MappingStep, PoseState, TrackingLoop
+    P, W, H, F, M = dims
+    out = {"note": "substitute for BASELINE configs[3] (blocked: no Replica data / checkpoints / front-end dependencies); "
+                   f"synthetic scene of config 3: {P} Gaussians, {W}x{H}, F={F}"}
+    cam = default_camera(W, H)
+    proj = cam.projection_matrix.to(dev)
+    T_gt = torch.eye(4, device=dev)
+    pose = PoseState(T_gt, proj, cam.tanfovx, cam.tanfovy)
+    c_gt = pose.camera()
+    R0 = _sized_capacity(F, g_dev, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in c_gt.items()}, H, W,
+                         sc.sh_degree, dev, (15, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE))
+    ws = RasterWorkspace(P, W, H, F, M, int(1.4 * R0) + (1 << 16), dev)
+    ws.set_scene(sh_degree=sc.sh_degree, **c_gt, **g_dev)
+    o = ws.forward()
+    gt_image, gt_depth = o["color"].clone(), o["depth"][0].clone()
+    # a few cm / a fraction of a degree off, like the constant-velocity prior of the front end
+    tau0 = torch.tensor([0.02, -0.015, 0.01, 0.004, -0.006, 0.003])
+    th = tau0[3:]
+    Wm = torch.tensor([[0.0, -th[2], th[1]], [th[2], 0.0, -th[0]], [-th[1], th[0], 0.0]])
+    T0 = torch.eye(4)
+    T0[:3, :3] = torch.eye(3) + Wm + 0.5 * Wm @ Wm
+    T0[:3, 3] = tau0[:3]
+    T0 = T0.to(dev)
+    trk = {}
+    for variant in ("null", "zeros"):
+        for readback in (False, True):
+            pose.reset(T0)
+            loop = TrackingLoop(ws, g_dev, sc.sh_degree, pose, gt_image, gt_depth, language_cotangent=variant)
+            for _ in range(5):
+                loop.iteration(readback)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(tracking_iters):
+                loop.iteration(readback)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            key = ("no_language_cotangent" if variant == "null" else "zero_language_cotangent") + \
+                  ("_with_convergence_readback" if readback else "")
+            trk[key] = round(1e3 * el / tracking_iters, 4)
+    out["tracking_iteration_ms"] = trk["no_language_cotangent"]
+    out["tracking"] = {"ms_per_iteration": trk, "iterations": tracking_iters,
+                       "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) + "
+                               "olsr_tracking_loss + pose-only olsr_backward + olsr_pose_step; dependent iterations",
+                       "pose_error_after": float((pose.T_w2c - T_gt).abs().max())}
+    del ws
+    # mapping iteration: raw parameters (what GaussianModel stores), activations folded into the kernels
+    params = dict(means3D=g_dev["means3D"].clone(), shs=g_dev["shs"].clone(),
+                  opacities=torch.logit(g_dev["opacities"].clamp(1e-4, 1 - 1e-4)).contiguous(),
+                  scales=torch.log(g_dev["scales"]).contiguous(), rotations=g_dev["rotations"].clone(),
+                  language=None if F == 0 else g_dev["language"].clone())
+    cams = arc_cameras(W, H, n=views)
+    camd = [dict(viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev),
+                 projmatrix_raw=c.projection_matrix.to(dev), campos=c.camera_center.to(dev), tanfovx=c.tanfovx,
+                 tanfovy=c.tanfovy) for c in cams]
+    lanes = FrameLanes(4, P, W, H, F, M, int(1.5 * R0) + (1 << 16), dev)
+    lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
+    step = MappingStep(lanes, params, g_dev["bg"], sc.sh_degree, camd, None, lrs, exposure=torch.zeros(2, device=dev))
+    gen = torch.Generator().manual_seed(0)
+    targets = []
+    ws0 = lanes.lanes[0][0]
+    for c in camd:  # targets: renders of the scene itself, perturbed so that every loss term has a gradient
+        o = step.render(ws0, c)
+        targets.append((torch.clamp(o["color"] + 0.05 * torch.randn(3, H, W, generator=gen).to(dev), 0, 1).contiguous(),
+                        (o["depth"][0] * (1 + 0.02 * torch.randn(H, W, generator=gen).to(dev))).contiguous(),
+                        None if F == 0 else torch.nn.functional.normalize(torch.randn(F, 192, 192, generator=gen), dim=0).to(dev)))
+    step.targets = targets
+    step.iteration()
+    first_loss = float(step.last_loss[0])
+    step.iteration()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(mapping_iters):
+        step.iteration()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    ovf = any(ws_.rendered()[1] or ws_.backward_status()[1] for ws_, _, _ in lanes.lanes)
+    out["mapping_iteration_ms"] = round(1e3 * el / mapping_iters, 3)
+    out["mapping"] = {"views": views, "views_in_flight": len(lanes), "iterations": mapping_iters,
+                      "views_per_s": round(views * mapping_iters / el, 1),
+                      "what": f"{views} arc views x (render from raw parameters + olsr_mapping_loss incl. the 192x192 language "
+                              "target + backward into the gradient bucket) + fused Adam step",
+                      "loss_last_view_first_iteration": round(first_loss, 6),
+                      "loss_last_view_final_iteration": round(float(step.last_loss[0]), 6),
+                      "capacity_overflow": bool(ovf)}
+    return out
+
+
 def views_mode(a, sc, dev, rank, world, dist):
     """--views V: one step = one mapping iteration (utils/slam_backend.py:510-760 without the language front end):
     V viewpoints of the same Gaussians, view v rendered forward + backward by rank v mod N straight into the flat
@@ -305,6 +466,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the bracket legs and the config-4 substitute")
     ap.add_argument("--mode", default="reference", choices=["reference", "exact"])
     ap.add_argument("--binning", default="ellipse", choices=["ellipse", "rect"],
                     help="ellipse: exact tile lists (default); rect: the reference's bounding-square lists")
@@ -479,10 +641,17 @@ def main():
                 r["traffic_frac"] = round(traffic / t_s / 1e9 / HBM_PEAK_GBS, 5)
             if valu:
                 ips = valu["SQ_INSTS_VALU"] / t_s
+                cyc_meas, cyc_src = measured_valu_cycles()
                 r["valu"] = {"insts_per_launch": int(valu["SQ_INSTS_VALU"]), "achieved": round(ips / 1e9, 1),
                              "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "G wave-instructions/s",
                              "frac": round(ips / VALU_ISSUE_PEAK, 4),
+                             "peak_basis": "MI355X_MICROARCH.md: v_fma_f32 (wave64) 2 cycles per SIMD-32",
+                             "cycles_per_inst_per_simd": round(1024 * 2.4e9 / ips, 2),
                              "busy_by_counters": valu.get("valu_busy"), "source": valu_src}
+                if cyc_meas:
+                    r["valu"]["peak_measured"] = {"cycles_per_full_rate_inst": round(cyc_meas, 2),
+                                                  "G_wave_instructions_per_s": round(1024 * 2.4e9 / cyc_meas / 1e9, 1),
+                                                  "frac": round(ips / (1024 * 2.4e9 / cyc_meas), 4), "source": cyc_src}
             return r
         roof = roofline_of(prof[1], "profiled leg, 1 frame in flight: event intervals == kernel durations") \
             if prof is not None else None
@@ -520,6 +689,11 @@ def main():
                                "stage_ms_note": "from a separate profiled leg (HIP events between the stages, ~6 us each)"}
         if world == 1 and a.isolated_steps > 0:
             out["dropin"] = dropin_leg(sc, dev, max(a.isolated_steps, 10), 10)
+        if world == 1 and a.isolated_steps > 0 and not a.no_extra_legs:
+            dims = (P, W, H, F, M)
+            out["bracket"] = bracket_legs(sc, g_dev, c0, (dc, dl, dd), dev, max(10, a.isolated_steps), dims)
+            if a.config == 3:
+                out["config4_substitute"] = config4_substitute(sc, g_dev, dev, dims)
         if world == 1 and not a.no_cpu_baseline:
             lane0 = lanes.lanes[0]
             sl = lane0[1].layout.slices()

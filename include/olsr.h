@@ -22,8 +22,8 @@
  *
  * Contents: the rasterizer itself (olsr_forward, olsr_forward_async, olsr_backward, olsr_mark_visible and
  * their size / introspection / profiling helpers — SURVEY.md section 8 rows a-e), then the callers and
- * data either side of it (rows f1-f3): olsr_mapping_loss, olsr_tracking_loss, olsr_accumulate_gradients,
- * olsr_adam_step, olsr_knn_mean_dist2.
+ * data either side of it (rows f1-f3): olsr_mapping_loss, olsr_tracking_loss, olsr_pose_step,
+ * olsr_accumulate_gradients, olsr_adam_step, olsr_knn_mean_dist2.
  */
 #ifndef OLSR_H_INCLUDED
 #define OLSR_H_INCLUDED
@@ -184,6 +184,13 @@ int olsr_forward_async(const olsr_scene *scene,
  *     through status_dev.
  * status_dev (device int32[2], may be NULL) receives {L, overflow flag}.
  *
+ * Cotangents.  dL_dout_color[3,H,W] is required.  dL_dout_language[F,H,W] and dL_dout_depth[H,W] may be NULL: "the loss
+ * does not depend on that image" — what autograd hands the reference's backward as None and PyTorch turns into zeros
+ * (DGR/diff_gaussian_rasterization/__init__.py:296-345).  The front end's tracking loss has no language term
+ * (utils/slam_utils.py:92-121): without a language cotangent the RGB instantiation of the composite backward runs on the
+ * language forward's state (the language terms of dL_dalpha vanish identically), every gradient equals what a zero-filled
+ * cotangent gives, and dL_dlanguage / the bucket's language columns are written as zeros.
+ *
  * Gradient outputs, all fully overwritten:
  *   dL_dmeans2D[P,3]  dL_dcolors[P,3]  dL_dlanguage[P,F]  dL_dopacity[P]
  *   dL_dmeans3D[P,3]  dL_dcov3D[P,6]   dL_dsh[P,M,3]      dL_dscales[P,3]
@@ -306,6 +313,35 @@ int olsr_tracking_loss(const olsr_loss_params *params, const float *image, const
                        const float *grad_mask, const float *exposure,
                        float *dL_dimage, float *dL_ddepth, float *loss, float *dL_dexposure,
                        void *scratch, void *hip_stream);
+
+/* ---- one tracking iteration's pose update (the front end) ----------------------
+ * Replaces, per iteration of the reference's tracking loop (utils/slam_frontend.py:216-243),
+ *   pose_optimizer.step()           torch.optim.Adam over cam_rot_delta (lr config Training.lr.cam_rot_delta = 0.003),
+ *                                   cam_trans_delta (0.001), exposure_a / exposure_b (0.01); eps 1e-8, betas (0.9, 0.999)
+ *   converged = update_pose(cam)    utils/pose_utils.py:79-97: tau = [cam_trans_delta | cam_rot_delta],
+ *                                   new_w2c = SE3_exp(tau) @ T_w2c (:61-76), converged = |tau| < 1e-4, deltas zeroed
+ * and the camera properties the next render reads (utils/camera_utils.py:103-117): world_view_transform = W2C^T,
+ * full_proj_transform = world_view_transform @ projection_matrix, camera_center = world_view_transform^-1 [3, :3]
+ * — one launch instead of ~40 one-element PyTorch kernels and a host read-back between two dependent renders.
+ *   dL_dtau_sum   device float[6] = [rho | theta] as olsr_backward leaves it (rho: gradient of cam_trans_delta,
+ *                 theta: of cam_rot_delta), or NULL: no step, only the matrices of the current pose are (re)derived
+ *   dL_dexposure  device float[2] from olsr_tracking_loss, or NULL (exposure not optimised)
+ *   projection_matrix  device float[16], the P^T the callers hold (Camera.projection_matrix)
+ *   state         device float[80], all zero before the first call except T_w2c:
+ *                 [0,16) T_w2c row-major (in/out) | [16,32) world_view_transform | [32,48) full_proj_transform |
+ *                 [48,51) camera_center | [52,58) exp_avg of tau | [58,64) exp_avg_sq | [64,70) tau this step applied |
+ *                 [70,72) exposure a, b (in/out) | [72,74) their exp_avg | [74,76) exp_avg_sq
+ *   status        device int32[2]: {converged flag of this step, steps done}
+ * params->step is the 1-based Adam step count of this call. */
+typedef struct olsr_pose_params {
+  double lr_rot, lr_trans, lr_exposure;
+  double beta1, beta2, eps;  /* torch.optim.Adam defaults in the reference: 0.9, 0.999, 1e-8 */
+  double converged_threshold; /* 1e-4 */
+  int32_t step;
+  int32_t _pad0;
+} olsr_pose_params;
+int olsr_pose_step(const olsr_pose_params *params, const float *dL_dtau_sum, const float *dL_dexposure,
+                   const float *projection_matrix, float *state, int32_t *status, void *hip_stream);
 
 /* Adds one view's per-Gaussian gradients into the flat fp32 buffer
  *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]

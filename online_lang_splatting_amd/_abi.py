@@ -79,6 +79,13 @@ class OlsrAdamParams(C.Structure):
                                            "lr_language", "beta1", "beta2", "eps")] + [("step", C.c_int32), ("_pad0", C.c_int32)]
 
 
+class OlsrPoseParams(C.Structure):
+    """struct olsr_pose_params, include/olsr.h."""
+
+    _fields_ = [(n, C.c_double) for n in ("lr_rot", "lr_trans", "lr_exposure", "beta1", "beta2", "eps",
+                                           "converged_threshold")] + [("step", C.c_int32), ("_pad0", C.c_int32)]
+
+
 class OlsrLossParams(C.Structure):
     """struct olsr_loss_params, include/olsr.h."""
 

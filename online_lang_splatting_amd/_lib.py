@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("OLSR_LIB") or os.path.join(_HERE, "libolsr.so")
 # every symbol include/olsr.h declares
 EXPORTS = (
     "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_backward_scratch_bytes", "olsr_forward", "olsr_forward_async",
-    "olsr_backward", "olsr_accumulate_gradients", "olsr_mapping_loss", "olsr_mapping_loss_scratch_bytes", "olsr_tracking_loss", "olsr_knn_mean_dist2", "olsr_knn_scratch_bytes", "olsr_adam_step", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
+    "olsr_backward", "olsr_accumulate_gradients", "olsr_mapping_loss", "olsr_mapping_loss_scratch_bytes", "olsr_tracking_loss", "olsr_pose_step", "olsr_knn_mean_dist2", "olsr_knn_scratch_bytes", "olsr_adam_step", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
     "olsr_set_profiling", "olsr_get_stage_times", "olsr_debug_sort_timing", "olsr_debug_sort_plan", "olsr_last_error", "olsr_version",
 )
 
@@ -60,6 +60,8 @@ def lib():
     L.olsr_mapping_loss.restype = C.c_int
     L.olsr_tracking_loss.argtypes = [C.POINTER(_abi.OlsrLossParams)] + [vp] * 13
     L.olsr_tracking_loss.restype = C.c_int
+    L.olsr_pose_step.argtypes = [C.POINTER(_abi.OlsrPoseParams)] + [vp] * 6
+    L.olsr_pose_step.restype = C.c_int
     L.olsr_adam_step.argtypes = [i32, i32, i32, C.POINTER(_abi.OlsrAdamParams)] + [vp] * 10
     L.olsr_adam_step.restype = C.c_int
     L.olsr_knn_scratch_bytes.argtypes, L.olsr_knn_scratch_bytes.restype = [i32], sz

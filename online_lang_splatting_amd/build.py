@@ -33,6 +33,7 @@ UNITS = [
     ("k_loss.hip", "k_loss.o", []),
     ("k_knn.hip", "k_knn.o", []),
     ("k_adam.hip", "k_adam.o", []),
+    ("k_pose.hip", "k_pose.o", []),
 ]
 HEADERS = ["olsr_device.h", "olsr_state.h", "olsr_kernels.h", os.path.join("..", "..", "include", "olsr.h")]
 

@@ -284,11 +284,13 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dtau, float* __restrict__ tau_partials, float* __restrict__ bucket_flat,
     float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign, int act,
-    const float* __restrict__ opacities_raw) {
+    const float* __restrict__ opacities_raw, int F_out) {
+  // F: language channels of the partial-gradient rows; F_out: the scene's (width of dL_dlanguage and of the bucket's
+  // language columns).  F == 0 < F_out: the backward ran without a language cotangent, those gradients are zero.
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   extern __shared__ float s_bucket[];  // [PB_THREADS][width] when a gradient bucket is given
-  const int width = 11 + 3 * M + F;    // floats per Gaussian in the gradient bucket
+  const int width = 11 + 3 * M + F_out;  // floats per Gaussian in the gradient bucket
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (r < P) {
@@ -364,13 +366,17 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
 #pragma unroll
         for (int ch = 0; ch < F; ++ch) dL_dlanguage[(size_t)idx * F + ch] = acc[10 + ch];
       }
+    } else if (dL_dlanguage) {
+      for (int ch = 0; ch < F_out; ++ch) dL_dlanguage[(size_t)idx * F_out + ch] = 0.f;
     }
     if (brow) {
-      float* o = brow + 3 + 3 * M;  // [opacity | scale 3 | rotation 4 | language F]
+      float* o = brow + 3 + 3 * M;  // [opacity | scale 3 | rotation 4 | language F_out]
       o[0] = badd ? o[0] + acc[5] : acc[5];
       if constexpr (F > 0) {
 #pragma unroll
         for (int ch = 0; ch < F; ++ch) o[8 + ch] = badd ? o[8 + ch] + acc[10 + ch] : acc[10 + ch];
+      } else if (!badd) {
+        for (int ch = 0; ch < F_out; ++ch) o[8 + ch] = 0.f;
       }
     }
 
@@ -647,7 +653,8 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
   // (persistent grid: at most one wave per 4 Gaussians — the lists never hold more than a fraction of them)
   const int rr_blocks = std::min(RR_BIG_BLOCKS, std::max(256, s.P / 16));
   row_reduce_big_kernel<F><<<rr_blocks, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, s.P, b.rowbase, g.counters);
-  const size_t bucket_lds = o.bucket_flat ? sizeof(float) * PB_THREADS * (size_t)(11 + 3 * s.M + s.F) : 0;
+  const int F_out = s.F;
+  const size_t bucket_lds = o.bucket_flat ? sizeof(float) * PB_THREADS * (size_t)(11 + 3 * s.M + F_out) : 0;
   preprocess_bwd_kernel<F><<<nb, PB_THREADS, bucket_lds, st>>>(
       s.P, s.D, s.M, g.gacc, g.tiles_touched, g.inst_start, b.rowbase, rows, g.counters, s.means3D, radii, s.shs,
       g.clamped,
@@ -655,18 +662,18 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
       o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign,
-      s.activations, s.opacities);
+      s.activations, s.opacities, F_out);
   if (o.dL_dtau_sum) tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
 }
 
-void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,
                                 const BinningState& b, const float* rows, const int32_t* radii, const GradOut& o,
                                 float* tau_partials, hipStream_t st) {
   if (s.P <= 0) {
     if (o.dL_dtau_sum) (void)hipMemsetAsync(o.dL_dtau_sum, 0, 6 * sizeof(float), st);
     return;
   }
-  switch (s.F) {
+  switch (F_rows) {
     case 0: launch_pb_t<0>(s, d, g, b, rows, radii, o, tau_partials, st); break;
     case 3: launch_pb_t<3>(s, d, g, b, rows, radii, o, tau_partials, st); break;
     case 15: launch_pb_t<15>(s, d, g, b, rows, radii, o, tau_partials, st); break;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   bg_dot += bg0 * dLc[0];
   bg_dot += bg1 * dLc[1];
   bg_dot += bg2 * dLc[2];
-  const float dLd = inside ? dL_dpixels_depth[pix] : 0.f;
+  const float dLd = (inside && dL_dpixels_depth != nullptr) ? dL_dpixels_depth[pix] : 0.f;  // (NULL: no depth term in the loss)
   const v2f dL01 = {dLc[0], dLc[1]}, dL23 = {dLc[2], dLd};  // the pixel's cotangents, in the same pairs
   float A_f = 0.f, D_last = 0.f, dLf[FX];
   bool seen_mine = false;  // wave-uniform: an entry of this wave's own has been visited
@@ -402,11 +402,13 @@ static void launch_bwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
       g.means2D, g.conic_opacity, colors, s.language_precomp, g.depths, im.final_T, im.n_contrib, dc, dl, dd, rows);
 }
 
+// F_rows: the language channels the rows carry — s.F, or 0 when the caller handed no language cotangent (the
+// tracking loss, utils/slam_utils.py:92-121): the RGB instantiation then runs on the language forward's state
 template <int TILE, int MODE>
-static void launch_bwd_f(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+static void launch_bwd_f(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, const float* dc, const float* dl, const float* dd, float* rows,
                          hipStream_t st) {
-  switch (s.F) {
+  switch (F_rows) {
     case 0: launch_bwd_t<TILE, 0, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
     case 3: launch_bwd_t<TILE, 3, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
     case 15: launch_bwd_t<TILE, 15, MODE>(s, d, g, b, im, dc, dl, dd, rows, st); break;
@@ -421,22 +423,22 @@ static void launch_bwd_f(const olsr_scene& s, const FrameDims& d, const Geometry
 #endif
 
 #if OLSR_BWD_TU_MODE == 0
-void launch_render_backward_reference(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+void launch_render_backward_reference(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,
                                       const BinningState& b, const ImageState& im, const float* dc, const float* dl,
                                       const float* dd, float* rows, hipStream_t st) {
   if (d.tile == 15)
-    launch_bwd_f<15, OLSR_BWD_REFERENCE>(s, d, g, b, im, dc, dl, dd, rows, st);
+    launch_bwd_f<15, OLSR_BWD_REFERENCE>(s, F_rows, d, g, b, im, dc, dl, dd, rows, st);
   else
-    launch_bwd_f<16, OLSR_BWD_REFERENCE>(s, d, g, b, im, dc, dl, dd, rows, st);
+    launch_bwd_f<16, OLSR_BWD_REFERENCE>(s, F_rows, d, g, b, im, dc, dl, dd, rows, st);
 }
 #else
-void launch_render_backward_exact(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+void launch_render_backward_exact(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,
                                   const BinningState& b, const ImageState& im, const float* dc, const float* dl,
                                   const float* dd, float* rows, hipStream_t st) {
   if (d.tile == 15)
-    launch_bwd_f<15, OLSR_BWD_EXACT>(s, d, g, b, im, dc, dl, dd, rows, st);
+    launch_bwd_f<15, OLSR_BWD_EXACT>(s, F_rows, d, g, b, im, dc, dl, dd, rows, st);
   else
-    launch_bwd_f<16, OLSR_BWD_EXACT>(s, d, g, b, im, dc, dl, dd, rows, st);
+    launch_bwd_f<16, OLSR_BWD_EXACT>(s, F_rows, d, g, b, im, dc, dl, dd, rows, st);
 }
 #endif
 

@@ -34,6 +34,15 @@ namespace olsr {
 
 constexpr int FWD_BATCH = 128;
 
+#ifdef OLSR_FWD_STATS
+// experiment build only (scripts/build_variant.sh ... -DOLSR_FWD_STATS): how many (entry, wave) pairs the loop looks at,
+// how many pass the wave-level reach test, how many blend, and how many lanes blend — read with olsr_debug_fwd_stats
+__device__ unsigned long long g_fwd_stats[8];
+#define FWD_STAT(i, v) st_##i += (unsigned)(v)
+#else
+#define FWD_STAT(i, v)
+#endif
+
 template <int TILE, int F>
 __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
@@ -93,6 +102,9 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
   const bool lane0 = (tid & 63) == 0;
   if (tid == 0) s_work = 0;
   u32 my_work = 0;  // live (instance, slot) pairs flushed by this thread
+#ifdef OLSR_FWD_STATS
+  unsigned st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0;
+#endif
   float T = 1.0f;
   u32 last_contributor = 0;
   // r g b depth lang[F] in pairs: the accumulation runs on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32)
@@ -163,6 +175,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
         u64 live = ~done_m;
         // wave-level early-out: no live pixel of this slot can reach the alpha floor of either entry
         const u64 reach0 = ballot(!(power.x < q1.x)) & live, reach1 = ballot(!(power.y < q1.y)) & live;
+        FWD_STAT(0, (j + 1 < cnt) ? 2 : 1);
+        FWD_STAT(1, (reach0 != 0ull) + (reach1 != 0ull));
         if ((reach0 | reach1) == 0ull) continue;
         const float2 op = *reinterpret_cast<const float2*>(&s_pair[(j >> 1) * 4 + 3]);
         const v2f G = pinned_expf2(power);
@@ -179,7 +193,10 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
           const u64 term_m = ok_m & ballot(test_T < 0.0001f);
           const u64 contrib_m = ok_m & ~term_m;
           done_m |= term_m;
+          FWD_STAT(4, 1);
           if (contrib_m != 0ull) {
+            FWD_STAT(2, 1);
+            FWD_STAT(3, __popcll(contrib_m));
             if (__builtin_amdgcn_inverse_ballot_w64(contrib_m)) {
               // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
               // reference's expression (CR/forward.cu:479-484), and what the oracle restates
@@ -213,6 +230,16 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
     }
   }
 
+#ifdef OLSR_FWD_STATS
+  if ((tid & 63) == 0) {
+    atomicAdd(&g_fwd_stats[0], (unsigned long long)st_0);
+    atomicAdd(&g_fwd_stats[1], (unsigned long long)st_1);
+    atomicAdd(&g_fwd_stats[2], (unsigned long long)st_2);
+    atomicAdd(&g_fwd_stats[3], (unsigned long long)st_3);
+    atomicAdd(&g_fwd_stats[4], (unsigned long long)st_4);
+    atomicAdd(&g_fwd_stats[5], (unsigned long long)n);
+  }
+#endif
   // backward work estimate of this tile: the number of (instance, slot) pairs it will visit
   if (tid < B) {
     u32 wsum = my_work;
@@ -282,3 +309,14 @@ void launch_render_forward(const olsr_scene& s, const FrameDims& d, const Geomet
 }
 
 }  // namespace olsr
+
+#ifdef OLSR_FWD_STATS
+extern "C" void olsr_debug_fwd_stats(unsigned long long* out8, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(olsr::g_fwd_stats), 8 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(olsr::g_fwd_stats), z, sizeof(z));
+  }
+}
+#endif

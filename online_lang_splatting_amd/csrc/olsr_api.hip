@@ -370,8 +370,13 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
     return fail(OLSR_ERR_ARG, "radii, the three state buffers and num_rendered (>= 0) are required");
   if (!scratch_alloc && (!scratch || scratch_rows < 0))
     return fail(OLSR_ERR_ARG, "either a scratch allocation callback or a scratch buffer with its row capacity is required");
-  if (!dL_dout_color || !dL_dout_depth || (s.F > 0 && !dL_dout_language))
-    return fail(OLSR_ERR_ARG, "upstream gradients must not be NULL");
+  if (!dL_dout_color) return fail(OLSR_ERR_ARG, "dL_dout_color must not be NULL");
+  // A NULL language / depth cotangent means "the loss does not depend on that image" (what autograd hands the
+  // reference's backward as None -> zeros, DGR/diff_gaussian_rasterization/__init__.py:296-345; the tracking loss has
+  // no language term, utils/slam_utils.py:92-121).  Without a language cotangent the RGB instantiation of the composite
+  // backward runs on the language forward's state: D - A == 0 and the rank-0 language row == 0, so every gradient
+  // equals what zero-filled cotangents give, and dL_dlanguage is written as zeros.
+  const int F_rows = (s.F > 0 && !dL_dout_language) ? 0 : s.F;
   if (bucket) {
     if (!bucket->flat || !bucket->densify || !bucket->max_radii)
       return fail(OLSR_ERR_ARG, "bucket.flat, bucket.densify and bucket.max_radii must not be NULL");
@@ -402,9 +407,9 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   float* rows = (float*)(((uintptr_t)scratch + ALIGN - 1) / ALIGN * ALIGN);
 
   if (s.bwd_mode == OLSR_BWD_REFERENCE)
-    launch_render_backward_reference(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
+    launch_render_backward_reference(s, F_rows, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
   else
-    launch_render_backward_exact(s, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
+    launch_render_backward_exact(s, F_rows, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
   STAGE("render_backward");
   GradOut o{dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dlanguage, dL_ddepths, dL_dmeans3D,
             dL_dcov3D,   dL_dsh,    dL_dscales,  dL_drotations, dL_dtau,    dL_dtau_sum};
@@ -414,7 +419,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
     o.bucket_max_radii = bucket->max_radii;
     o.bucket_assign = bucket->assign;
   }
-  launch_preprocess_backward(s, d, g, b, rows, radii, o, g.tau_partials, st);
+  launch_preprocess_backward(s, F_rows, d, g, b, rows, radii, o, g.tau_partials, st);
   STAGE("preprocess_backward");
   (void)gb;
   (void)ib;
@@ -447,6 +452,18 @@ int olsr_adam_step(int32_t P, int32_t M, int32_t F, const olsr_adam_params* para
                    (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("adam_step launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
+int olsr_pose_step(const olsr_pose_params* params, const float* dL_dtau_sum, const float* dL_dexposure,
+                   const float* projection_matrix, float* state, int32_t* status, void* hip_stream) {
+  if (!params || !projection_matrix || !state || !status)
+    return fail(OLSR_ERR_ARG, "pose params, projection_matrix, state and status are required");
+  if (dL_dtau_sum && params->step < 1) return fail(OLSR_ERR_ARG, "step must be >= 1 when a gradient is given");
+  if (!dL_dtau_sum && dL_dexposure) return fail(OLSR_ERR_ARG, "an exposure gradient needs a pose gradient (one optimiser step)");
+  launch_pose_step(*params, dL_dtau_sum, dL_dexposure, projection_matrix, state, status, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("pose_step launch: ") + hipGetErrorString(e));
   return OLSR_OK;
 }
 

@@ -90,10 +90,11 @@ void launch_render_forward(const olsr_scene& s, const FrameDims& d, const Geomet
 
 // k_render_bwd.hip
 // (two translation units, one per backward mode, so they compile in parallel)
-void launch_render_backward_reference(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+// F_rows: language channels of the partial-gradient rows: s.F, or 0 when there is no language cotangent
+void launch_render_backward_reference(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,
                                       const BinningState& b, const ImageState& im, const float* dL_dcolor,
                                       const float* dL_dlanguage, const float* dL_ddepth, float* rows, hipStream_t st);
-void launch_render_backward_exact(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+void launch_render_backward_exact(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,
                                   const BinningState& b, const ImageState& im, const float* dL_dcolor,
                                   const float* dL_dlanguage, const float* dL_ddepth, float* rows, hipStream_t st);
 
@@ -107,7 +108,8 @@ struct GradOut {
   int32_t* bucket_max_radii = nullptr;
   int bucket_assign = 0;
 };
-void launch_preprocess_backward(const olsr_scene& s, const FrameDims& d, const GeometryState& g,
+// F_rows: language channels of `rows` (see above); with F_rows == 0 < s.F the language gradients are written as zeros
+void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,
                                 const BinningState& b, const float* rows, const int32_t* radii, const GradOut& o,
                                 float* tau_partials, hipStream_t st);
 int tau_partial_blocks(int P);
@@ -122,6 +124,10 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
 void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* flat, float* means3D, float* shs,
                       float* opacities, float* scales, float* rotations, float* language, float* exp_avg,
                       float* exp_avg_sq, hipStream_t st);
+
+// k_pose.hip
+void launch_pose_step(const olsr_pose_params& p, const float* dL_dtau_sum, const float* dL_dexposure, const float* proj,
+                      float* state, int32_t* status, hipStream_t st);
 
 // k_knn.hip
 size_t knn_scratch_bytes(int P);

@@ -46,7 +46,10 @@ def _split_tau(tau_sum):
 
 def _cotangent(g, shape, like):
     """Autograd hands None for an output the loss never touched (the Functions do not materialise zero gradients: three
-    memsets per backward for radii / opacity / n_touched, which are ignored anyway): the kernels want zeros."""
+    memsets per backward for radii / opacity / n_touched, which are ignored anyway).  The library takes "no language
+    cotangent" and "no depth cotangent" as NULL pointers (olsr_backward: the tracking loss has no language term,
+    utils/slam_utils.py:92-121, and then the RGB instantiation of the composite backward runs); only the colour
+    cotangent, which also carries the image size, is materialised."""
     return g if g is not None else torch.zeros(shape, dtype=torch.float32, device=like.device)
 
 
@@ -76,7 +79,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         H, W = rs.image_height, rs.image_width
         grad_out_color = _cotangent(grad_out_color, (3, H, W), means3D)
-        grad_out_depth = _cotangent(grad_out_depth, (1, H, W), means3D)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, _grad_tau, tau_sum) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -117,8 +119,6 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
          img) = ctx.saved_tensors
         H, W = rs.image_height, rs.image_width
         grad_out_color = _cotangent(grad_out_color, (3, H, W), means3D)
-        grad_out_language = _cotangent(grad_out_language, (language_precomp.shape[1], H, W), means3D)
-        grad_out_depth = _cotangent(grad_out_depth, (1, H, W), means3D)
         (grad_means2D, grad_colors_precomp, grad_language_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
          grad_sh, grad_scales, grad_rotations, _grad_tau, tau_sum) = _C.rasterize_language_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, language_precomp, scales, rotations, rs.scale_modifier,

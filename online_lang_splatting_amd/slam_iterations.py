@@ -1,0 +1,158 @@
+"""The two loops the reference's SLAM system spends its GPU time in, written over this library's sync-free entry
+points ("the callers either side of the path").  They are the measurable substitute
+for BASELINE.json configs[3] (the Replica `slam.py` loop, which needs data, checkpoints and front-end dependencies this
+image lacks) and are what `bench.py` reports under `config4_substitute`.
+
+TrackingLoop   front end, utils/slam_frontend.py:tracking() (:160-275): up to 100 DEPENDENT iterations per frame of
+               render -> get_loss_tracking (utils/slam_utils.py:92-121, no language term) -> backward to the camera pose
+               only -> Adam on (cam_rot_delta, cam_trans_delta) -> update_pose (utils/pose_utils.py:update_pose).
+               Iterations depend on each other through the pose: this is the single-frame LATENCY of the path.
+MappingStep    back end, utils/slam_backend.py:map() (:499-760): 12 views of the same Gaussians (10 window keyframes +
+               2 random), mapping loss incl. the language L1 (:579-597), gradients summed over the views, ONE Adam step.
+
+Everything numerical happens in libolsr.so (olsr_forward_async, olsr_tracking_loss / olsr_mapping_loss, olsr_backward,
+olsr_pose_step, olsr_adam_step); this module only sequences the calls, like the reference's Python does.
+"""
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _abi, losses
+from ._lib import check, lib
+from .frame_shard import FrameLanes, FusedAdam, GradLayout, RasterWorkspace
+
+
+class PoseState:
+    """Camera pose + the pose optimiser of one tracked frame, resident on the GPU and advanced by ONE kernel per
+    iteration (olsr_pose_step): Adam on the six pose increments (torch.optim.Adam's arithmetic, lr per group as in
+    utils/slam_frontend.py:170-196), new_w2c = SE3_exp(tau) @ T_w2c (utils/pose_utils.py:61-94), then the matrices the
+    rasterizer consumes — world_view_transform = W2C^T, full_proj_transform = W2C^T P^T, camera_center
+    (utils/camera_utils.py:103-117) — and the reference's convergence test |tau| < 1e-4."""
+
+    def __init__(self, T_w2c: torch.Tensor, projection_matrix: torch.Tensor, tanfovx: float, tanfovy: float,
+                 lr_rot=0.003, lr_trans=0.001, lr_exposure=0.01, betas=(0.9, 0.999), eps=1e-8,
+                 converged_threshold=1e-4, optimise_exposure=True):
+        dev = T_w2c.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.device = dev
+        self.tanfovx, self.tanfovy = float(tanfovx), float(tanfovy)
+        self.proj = projection_matrix.to(**f32).contiguous()  # P^T, what the callers hold
+        self.state = torch.zeros(80, **f32)                    # layout: olsr_pose_step, include/olsr.h
+        self.T_w2c = self.state[0:16].view(4, 4)
+        self.viewmatrix = self.state[16:32].view(4, 4)
+        self.projmatrix = self.state[32:48].view(4, 4)
+        self.campos = self.state[48:51]
+        self.last_tau = self.state[64:70]
+        self.exposure = self.state[70:72]
+        self.status = torch.zeros(2, dtype=torch.int32, device=dev)  # {converged flag, steps done}
+        self.optimise_exposure = optimise_exposure
+        self.hp = _abi.OlsrPoseParams(lr_rot=lr_rot, lr_trans=lr_trans, lr_exposure=lr_exposure, beta1=betas[0],
+                                      beta2=betas[1], eps=eps, converged_threshold=converged_threshold, step=0)
+        self.reset(T_w2c)
+
+    def reset(self, T_w2c, exposure=(0.0, 0.0)):
+        """New frame: pose prior, fresh optimiser state (the reference builds a new Adam per tracked frame)."""
+        T = T_w2c.detach().to(self.state).clone()
+        self.state.zero_()
+        self.T_w2c.copy_(T)
+        self.exposure.copy_(torch.tensor(exposure, dtype=torch.float32))
+        self.status.zero_()
+        self.hp.step = 0
+        self._call(None, None)  # the matrices of the start pose (no gradient: no step)
+
+    def _call(self, dL_dtau_sum, dL_dexposure):
+        check(lib().olsr_pose_step(C.byref(self.hp), dL_dtau_sum.data_ptr() if dL_dtau_sum is not None else None,
+                                   dL_dexposure.data_ptr() if dL_dexposure is not None else None,
+                                   self.proj.data_ptr(), self.state.data_ptr(), self.status.data_ptr(),
+                                   C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def step(self, dL_dtau_sum: torch.Tensor, dL_dexposure: Optional[torch.Tensor] = None):
+        """dL_dtau_sum: device float[6] = [rho | theta] as olsr_backward leaves it; dL_dexposure: device float[2] from
+        olsr_tracking_loss (ignored unless optimise_exposure)."""
+        self.hp.step += 1
+        self._call(dL_dtau_sum, dL_dexposure if self.optimise_exposure else None)
+
+    def camera(self) -> Dict:
+        return dict(viewmatrix=self.viewmatrix, projmatrix=self.projmatrix, projmatrix_raw=self.proj,
+                    campos=self.campos, tanfovx=self.tanfovx, tanfovy=self.tanfovy)
+
+
+class TrackingLoop:
+    """render -> tracking loss -> pose-only backward -> pose step, allocation-free and without a host sync unless the
+    caller asks for the convergence flag (the reference reads it back every iteration: `converged = update_pose(...)`)."""
+
+    def __init__(self, workspace: RasterWorkspace, gaussians: Dict[str, torch.Tensor], sh_degree: int, pose: PoseState,
+                 gt_image: torch.Tensor, gt_depth: torch.Tensor, grad_mask: Optional[torch.Tensor] = None,
+                 alpha=0.95, rgb_boundary_threshold=0.01, language_cotangent: str = "null"):
+        """language_cotangent: "null" — olsr_backward gets no language cotangent (what the tracking loss means; the RGB
+        instantiation of the composite backward runs); "zeros" — a zero-filled [F,H,W] cotangent through the language
+        backward (what autograd materialises for the reference, kept for comparison)."""
+        assert language_cotangent in ("null", "zeros")
+        self.ws, self.g, self.sh_degree, self.pose = workspace, gaussians, sh_degree, pose
+        self.gt_image, self.gt_depth, self.grad_mask = gt_image, gt_depth, grad_mask
+        self.alpha, self.thr = alpha, rgb_boundary_threshold
+        dev = workspace.device
+        self.zero_lang = (torch.zeros(workspace.F, workspace.H, workspace.W, device=dev)
+                          if (language_cotangent == "zeros" and workspace.F > 0) else None)
+        self.loss = None
+
+    def iteration(self, read_convergence=False) -> bool:
+        ws = self.ws
+        ws.set_scene(sh_degree=self.sh_degree, **self.pose.camera(), **self.g)
+        out = ws.forward()
+        lo = losses.tracking_loss(out["color"], out["depth"], out["opacity"], self.gt_image, self.gt_depth,
+                                  self.grad_mask, self.pose.exposure, alpha=self.alpha, rgb_boundary_threshold=self.thr)
+        self.loss = lo["loss"]
+        g = ws.backward(lo["dL_dimage"], self.zero_lang, lo["dL_ddepth"], pose_only=True)
+        self.pose.step(g["dL_dtau_sum"], lo["dL_dexposure"])
+        if read_convergence:
+            return bool(int(self.pose.status[0].item()))  # one 4-byte read-back, like the reference
+        return False
+
+
+class MappingStep:
+    """One mapping iteration over `cameras` (all views against the same Gaussians), `lanes` views in flight, gradients
+    written / added straight into the flat bucket by the backward kernel, one fused Adam step on the raw parameters."""
+
+    def __init__(self, lanes: FrameLanes, params: Dict[str, torch.Tensor], bg: torch.Tensor, sh_degree: int,
+                 cameras: Sequence[Dict], targets: Sequence, lrs: Dict[str, float], exposure=None,
+                 activations=_abi.ACT_ALL):
+        self.lanes, self.params, self.bg, self.sh_degree = lanes, params, bg, sh_degree
+        self.cameras, self.targets, self.lrs, self.exposure, self.act = cameras, targets, lrs, exposure, activations
+        ws0 = lanes.lanes[0][0]
+        self.adam = FusedAdam(ws0.P, GradLayout(ws0.M, ws0.F), ws0.device)
+        self.last_loss = None
+
+    def render(self, ws, cam):
+        ws.set_scene(bg=self.bg, sh_degree=self.sh_degree, activations=self.act, **cam, **self.params)
+        return ws.forward()
+
+    def iteration(self):
+        lanes = self.lanes
+        dev = lanes.device
+        used = []
+        for v, cam in enumerate(self.cameras):
+            ws, bucket, stream = lanes.next_lane()
+            first = bucket not in used
+            if first:
+                used.append(bucket)
+            with torch.cuda.stream(stream):
+                out = self.render(ws, cam)
+                lo = losses.mapping_loss(out["color"], out["depth"], out["language"] if ws.F > 0 else None,
+                                         *self.targets[v], self.exposure)
+                ws.backward(lo["dL_dimage"], lo["dL_dlanguage"] if ws.F > 0 else None, lo["dL_ddepth"], bucket=bucket,
+                            first=first, bucket_only=True)
+                self.last_loss = lo["loss"]
+        main = torch.cuda.current_stream(dev)
+        for _, _, st in lanes.lanes:
+            main.wait_stream(st)
+        total = used[0]
+        for b in used[1:]:
+            total.sum_storage.add_(b.sum_storage)
+            torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
+        total.all_reduce()
+        self.adam.step(total, self.params, self.lrs)
+        for _, _, st in lanes.lanes:
+            st.wait_stream(main)
+        return total

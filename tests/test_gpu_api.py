@@ -556,3 +556,101 @@ def test_fused_accumulate_matches_torch_formulation(hip):
     torch.testing.assert_close(got.flat.cpu(), ref.flat, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(got.densify.cpu(), ref.densify, rtol=1e-6, atol=1e-6)
     assert torch.equal(got.max_radii.cpu(), ref.max_radii)
+
+
+@pytest.mark.parametrize("mode", [_abi.BWD_REFERENCE, _abi.BWD_EXACT])
+@pytest.mark.parametrize("tile", [15, 16])
+def test_null_language_and_depth_cotangents_equal_zero_cotangents(hip, oracle, mode, tile):
+    """olsr_backward without a language / depth cotangent (the tracking loss has no language term,
+    utils/slam_utils.py:92-121; autograd hands None, DGR/diff_gaussian_rasterization/__init__.py:296-345): the RGB
+    instantiation of the composite backward runs on the language forward's state.  Every gradient must equal what
+    zero-filled cotangents give (value for value: D - A == 0 and the rank-0 language row == 0), dL_dlanguage must be
+    zeros, and both must sit within the parity tolerance of the oracle fed zeros."""
+    from online_lang_splatting_amd.frame_shard import GradientBucket, GradLayout, RasterWorkspace
+    dev = torch.device(DEV)
+    sc = make_scene(12000, 300, 210, 15, seed=11)
+    cam = sc.camera
+    hip.TILE, hip.BWD_MODE = tile, mode
+    fg, _ = run_backend(hip, sc, dev, 4, tile, mode)
+    M = sc.shs.shape[1]
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(4))
+    kw = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+              rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev),
+              viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+              projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+              tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+    ws = RasterWorkspace(sc.P, 300, 210, 15, M, int(fg["R"] * 1.2) + 1000, dev, tile=tile, bwd_mode=mode)
+    ws.set_scene(**kw)
+    ws.forward()
+    names = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dlanguage", "dL_ddepths", "dL_dmeans3D",
+             "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dtau", "dL_dtau_sum")
+    zl, zd = torch.zeros_like(dl), torch.zeros_like(dd)
+    for lang_cot, depth_cot, zlang, zdepth in ((None, dd, zl, dd), (None, None, zl, zd), (dl, None, dl, zd)):
+        ref = {k: v.clone() for k, v in ws.backward(dc, zlang, zdepth).items()}
+        got = ws.backward(dc, lang_cot, depth_cot)
+        for k in names:
+            if mode == _abi.BWD_REFERENCE or lang_cot is not None:
+                assert torch.equal(got[k], ref[k]), (k, lang_cot is None, depth_cot is None)
+            else:
+                # exact mode reduces 10 + F values per visit: without the language channels the colour / depth sums go
+                # through a differently shaped permlane tree (same values, another rounding order)
+                assert rel_err(got[k], ref[k])[0] <= 2e-6, (k, rel_err(got[k], ref[k]))
+        if lang_cot is None:
+            assert float(got["dL_dlanguage"].abs().max()) == 0.0
+    # pose-only (what tracking runs) and the bucket: same values through the NULL path
+    ref_tau = ws.backward(dc, zl, dd, pose_only=True)["dL_dtau_sum"].clone()
+    got_tau = ws.backward(dc, None, dd, pose_only=True)["dL_dtau_sum"]
+    assert torch.equal(got_tau, ref_tau) if mode == _abi.BWD_REFERENCE else rel_err(got_tau, ref_tau)[0] <= 2e-6
+    lay = GradLayout(M, 15)
+    b0, b1 = GradientBucket(sc.P, lay, dev), GradientBucket(sc.P, lay, dev)
+    ws.backward(dc, zl, dd, bucket=b0, first=True, bucket_only=True)
+    ws.backward(dc, None, dd, bucket=b1, first=True, bucket_only=True)
+    if mode == _abi.BWD_REFERENCE:
+        assert torch.equal(b0.flat, b1.flat) and torch.equal(b0.densify, b1.densify)
+    else:
+        assert rel_err(b1.flat, b0.flat)[0] <= 2e-6 and rel_err(b1.densify, b0.densify)[0] <= 2e-6
+    assert float(b1.view("language").abs().max()) == 0.0
+    # against the oracle with zero language cotangent
+    import types
+    sc0 = types.SimpleNamespace(**{k: getattr(sc, k) for k in ("camera", "means3D", "opacities", "scales", "rotations",
+                                                               "shs", "language", "bg", "sh_degree", "F", "P")})
+    sc0.cotangents = lambda seed: (lambda c: (c[0], torch.zeros_like(c[1]), c[2]))(sc.cotangents(seed))
+    fo, go = run_backend(oracle, sc0, None, 4, tile, mode)
+    got = ws.backward(dc, None, dd)
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D", "dL_dtau"):
+        assert rel_err(got[k].reshape(go[k].shape), go[k])[0] <= 1e-4, k
+    assert float(go["dL_dlanguage"].abs().max()) == 0.0
+    oracle.release(fo["geom"])
+
+
+def test_autograd_without_language_loss_uses_the_null_path(hip, oracle):
+    """A loss without a language term through the drop-in autograd API (what front-end tracking does with
+    gaussian_renderer.render): language_precomp.grad comes back as zeros, everything else as with a zero cotangent."""
+    from diff_gaussian_rasterization import LanguageGaussianRasterizer
+    dev = torch.device(DEV)
+    sc = make_scene(3000, 160, 120, 15, seed=5)
+
+    def grads(with_zero_lang_term, with_depth):
+        leaf = lambda t: t.to(dev).clone().requires_grad_(True)  # noqa: E731
+        means3D, opac, scales, rots, shs, lang = (leaf(t) for t in (sc.means3D, sc.opacities, sc.scales, sc.rotations,
+                                                                    sc.shs, sc.language))
+        means2D = torch.zeros_like(means3D, requires_grad=True)
+        theta = torch.zeros(3, device=dev, requires_grad=True)
+        rho = torch.zeros(3, device=dev, requires_grad=True)
+        rast = LanguageGaussianRasterizer(raster_settings=_settings(sc, dev))
+        image, language, radii, depth, opacity, n_touched = rast(
+            means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, language_precomp=lang, opacities=opac,
+            scales=scales, rotations=rots, cov3D_precomp=None, theta=theta, rho=rho)
+        dc, dl, dd = (t.to(dev) for t in sc.cotangents(3))
+        loss = (image * dc).sum()
+        if with_depth:
+            loss = loss + (depth * dd).sum()
+        if with_zero_lang_term:
+            loss = loss + (language * torch.zeros_like(dl)).sum() + (depth * torch.zeros_like(dd)).sum()
+        loss.backward()
+        return [t.grad for t in (means3D, opac, scales, rots, shs, lang, means2D, theta, rho)]
+    for with_depth in (True, False):
+        a, b = grads(False, with_depth), grads(True, with_depth)
+        for x, y in zip(a, b):
+            assert x is not None and torch.equal(x, y)
+        assert float(a[5].abs().max()) == 0.0 and a[5].shape == (sc.P, 15)

@@ -38,6 +38,35 @@ def test_single_process_line():
     q = d["isolated"]["latency_ms"]["step_completion_interval_ms"]
     assert q["p10"] <= q["median"] <= q["p90"] and q["n"] >= 1
     assert d["isolated"]["stage_ms"]["render_backward"] > 0
+    # the legs that bracket the reference-mode headline: exact backward, 16x16 tiles, the reference's tile lists
+    for name, tile, mode, binning in (("exact_mode", 15, "exact", "ellipse"), ("tile16", 16, "reference", "ellipse"),
+                                      ("rect_binning", 15, "reference", "rect")):
+        leg = d["bracket"][name]
+        assert (leg["tile"], leg["backward_mode"], leg["binning"]) == (tile, mode, binning)
+        assert leg["value"] > 0 and not leg["capacity_overflow"] and leg["R_binned"] > 0
+    assert d["bracket"]["rect_binning"]["R_binned"] == d["config"]["R"] >= d["config"]["R_binned"]
+    assert "config4_substitute" not in d  # (config 3 only)
+
+
+def test_config3_line_carries_the_config4_substitute():
+    """The driver's line (config 3) also reports the measurable substitute of BASELINE configs[3]: the dependent tracking
+    iteration and the 12-view mapping iteration, plus the valu roofline priced against the guide's issue rate."""
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "3", "--isolated-steps", "10",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    c4 = d["config4_substitute"]
+    assert 0 < c4["tracking_iteration_ms"] < 5 and 0 < c4["mapping_iteration_ms"] < 60
+    trk = c4["tracking"]["ms_per_iteration"]
+    assert set(trk) == {"no_language_cotangent", "no_language_cotangent_with_convergence_readback",
+                        "zero_language_cotangent", "zero_language_cotangent_with_convergence_readback"}
+    assert c4["tracking"]["pose_error_after"] < 0.03  # it moved towards the target pose (start: 0.02 m / 6 mrad off)
+    assert not c4["mapping"]["capacity_overflow"] and c4["mapping"]["views"] == 12
+    assert c4["mapping"]["loss_last_view_final_iteration"] < c4["mapping"]["loss_last_view_first_iteration"]
+    assert set(d["bracket"]) == {"exact_mode", "tile16", "rect_binning"}
+    valu = d["roofline"].get("valu")
+    if valu is not None:  # (present when the committed PMC summary covers the kernel)
+        assert abs(valu["peak"] - 1228.8) < 0.1 and 0 < valu["frac"] < 1
 
 
 def test_two_ranks_frame_sharded_over_gloo():
