@@ -347,10 +347,25 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
             key = ("no_language_cotangent" if variant == "null" else "zero_language_cotangent") + \
                   ("_with_convergence_readback" if readback else "")
             trk[key] = round(1e3 * el / tracking_iters, 4)
+    # library stages of the iteration (HIP events between the stages, ~6 us each: a separate, profiled pass)
+    pose.reset(T0)
+    loop = TrackingLoop(ws, g_dev, sc.sh_degree, pose, gt_image, gt_depth, language_cotangent="null")
+    for _ in range(3):
+        loop.iteration()
+    torch.cuda.synchronize(dev)
+    _lib.set_profiling(True)
+    for _ in range(10):
+        loop.iteration()
+    per = {}
+    for name, ms in _lib.stage_times():
+        per.setdefault(name, []).append(ms)
+    _lib.set_profiling(False)
+    stage = {k: round(sum(v) / len(v), 4) for k, v in per.items()}
     out["tracking_iteration_ms"] = trk["no_language_cotangent"]
     out["tracking"] = {"ms_per_iteration": trk, "iterations": tracking_iters,
                        "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) + "
                                "olsr_tracking_loss + pose-only olsr_backward + olsr_pose_step; dependent iterations",
+                       "library_stage_ms": stage, "library_ms": round(sum(stage.values()), 4),
                        "pose_error_after": float((pose.T_w2c - T_gt).abs().max())}
     del ws
     # mapping iteration: raw parameters (what GaussianModel stores), activations folded into the kernels

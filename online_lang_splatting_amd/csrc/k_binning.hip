@@ -754,14 +754,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
   __shared__ u32 s_bid;
   __shared__ u32 s_wsum[ROWS_THREADS / 64 + 1];
   __shared__ u32 s_last;
-  // block index: the launch order while the whole grid is resident at once (one 1024-thread block per CU always fits:
-  // a waiting block then never keeps a predecessor from starting), else a ticket — a dependent trip to the fabric
-  u32 b = blockIdx.x;
-  if (gridDim.x > 256u) {
-    if (threadIdx.x == 0) s_bid = atomicAdd(&sync[0], 1u);
-    __syncthreads();
-    b = s_bid;
-  }
+  // block index = a ticket, always: a block waits only for blocks that have started (deadlock-free under any dispatch
+  // order and any co-tenancy with other frames' kernels; see sort_pass_kernel)
+  if (threadIdx.x == 0) s_bid = atomicAdd(&sync[0], 1u);
+  __syncthreads();
+  const u32 b = s_bid;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t n = bounded_n(n_host, n_dev);  // flags beyond the instances of this frame are stale
   const int64_t bbase = (int64_t)b * ROWS_CHUNK;

@@ -76,26 +76,6 @@ __device__ __forceinline__ bool fs_granule_ready(const u32x4& v) {
   return ((v.x & v.y & v.z & v.w) & FS_READY_PAIR) == FS_READY_PAIR;
 }
 
-// two exclusive prefixes at once (the same two barriers); s_w2: 32 words of LDS scratch
-__device__ __forceinline__ void fs_block_excl_scan2(u32 a, u32 b, u32* s_w2, u32& out_a, u32& out_b) {
-  const int lane = lane_id(), w = threadIdx.x >> 6;
-  const u32 ia = fs_wave_incl_scan(a), ib = fs_wave_incl_scan(b);
-  if (lane == 63) {
-    s_w2[w] = ia;
-    s_w2[FS_W + w] = ib;
-  }
-  __syncthreads();
-  u32 ba = 0, bb = 0;
-#pragma unroll
-  for (int i = 0; i < FS_W; ++i) {
-    ba += (i < w) ? s_w2[i] : 0u;
-    bb += (i < w) ? s_w2[FS_W + i] : 0u;
-  }
-  __syncthreads();
-  out_a = ba + ia - a;
-  out_b = bb + ib - b;
-}
-
 // ---- digit totals of every pass of a sort, one read of the keys ---------------------------------------------
 // hist[p][d] += #keys whose digit p is d (hist zeroed by an earlier kernel of the frame); digits are `db` bits wide.
 // `house` (block 0 only, may be null): the frame's bookkeeping that used to be finalize_counts_kernel.
@@ -239,8 +219,7 @@ void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_laun
 // bit 1 = do not write the sorted keys (last pass of a sort), bit 2 = derive tile ranges (last tile-sort pass).
 // bit 3 = last depth pass: add every Gaussian's instance count (emit_rec[2 g + 1].w) to the total of the emission block
 // its final depth rank falls in (emit_totals[rank / EMIT_CHUNK]), so the emission needs no scan of its own.
-constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4, FSF_EMIT_TOTALS = 8, FSF_NO_TICKET = 16;
-constexpr int FS_ALWAYS_RESIDENT_BLOCKS = 256;  // one 1024-thread block per CU fits whatever its LDS size
+constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4, FSF_EMIT_TOTALS = 8;
 
 template <int DB, int KPT>
 __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num_sgpr(80))) void sort_pass_kernel(const u32* __restrict__ keys_in,
@@ -267,11 +246,15 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   __shared__ u32 s_bid;
   __shared__ u32 s_w[2 * FS_W];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // chunk index: the launch order (blockIdx) when the whole grid is resident at once (at most one block per CU: a
-  // spinning block then never keeps a predecessor from starting), else a ticket
-  if (tid == 0) s_bid = (fsf & FSF_NO_TICKET) ? blockIdx.x : atomicAdd(ticket, 1u);
+  // Chunk index = a TICKET, always: a block only ever waits for blocks that hold a smaller ticket, i.e. that have
+  // started — deadlock-free under any dispatch order and any co-tenancy.  (Round 2 took the launch order instead while
+  // the grid had at most one block per CU; with several frames in flight two such grids can capture each other's XCDs
+  // and wait for predecessors that can no longer be placed — ADVICE round 2.)  The ticket's round trip to the fabric
+  // (~2 us) is covered by what needs no chunk: clearing the counters and the prefix of the global digit totals.
+  if (tid == 0) s_bid = atomicAdd(ticket, 1u);
   for (u32 i = tid; i < FS_W * NB; i += FS_T) cnt[i] = 0;
-  __syncthreads();
+  const u32 gh = ((u32)tid < NB) ? ghist[tid] : 0u;
+  const u32 gdig = fs_block_excl_scan(gh, s_w);  // global start of every digit (two barriers: s_bid is visible after them)
   const u32 b = s_bid;
   FS_STAMP(0);
   if (timing != nullptr && tid == 0) {
@@ -282,7 +265,6 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   const int64_t bbase = (int64_t)b * CHUNK;
   if (bbase >= n) return;  // (an empty block has only empty successors: nobody waits for it)
   const int64_t wbase = bbase + (int64_t)w * (64 * KPT);
-  const u32 gh = ((u32)tid < NB) ? ghist[tid] : 0u;  // (needed after the count: its latency hides behind it)
 
   u32 key[KPT], val[KPT];
 #pragma unroll
@@ -309,10 +291,8 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
     }
     pub[d] = (u16)(FS_READY16 | tot);
   }
-  // local start of every digit inside the block and global start of every digit (from the up-front totals), one pair
-  // of barriers for both prefixes
-  u32 start, gdig;
-  fs_block_excl_scan2(d < NB ? tot : 0u, gh, s_w, start, gdig);
+  // local start of every digit inside the block
+  const u32 start = fs_block_excl_scan(d < NB ? tot : 0u, s_w);
   // publish this block's row: NB / 8 granules of eight 16-bit counts, write-through (sc1)
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)(gridDim.x * NB * 2u), 0x00020000);
   if (tid < C) {
@@ -583,7 +563,6 @@ int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host
     int fsf = 0;
     if (p == 0 && vals_in_identity) fsf |= FSF_IDENTITY;
     if (p == passes - 1) fsf |= FSF_NO_KEYS | (ranges ? FSF_RANGES : 0) | (emit_totals ? FSF_EMIT_TOTALS : 0);
-    if (plan.nblk <= FS_ALWAYS_RESIDENT_BLOCKS) fsf |= FSF_NO_TICKET;
     PassArgs a{kin, vin, n_host, n_dev, db * p, hist + 256 * p,
                reinterpret_cast<u16*>(status) + (size_t)p * plan.nblk * NB, tickets + p, kout, vout, fsf, flags_clear,
                ranges, inst_count, emit_totals, plan.nblk};

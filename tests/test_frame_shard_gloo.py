@@ -149,3 +149,38 @@ def test_reduce_scatter_gives_every_rank_its_owned_rows():
         covered += list(range(r0, r1))
     assert covered == list(range(301))
     assert torch.equal(rs["densify"], dense["densify"]) and torch.equal(rs["max_radii"], dense["max_radii"])
+
+
+def test_eight_ranks_ragged_rows_all_three_exchanges():
+    """The shape the driver's 8-GPU run has: 8 ranks, 12 views (ranks 0-3 render two, ranks 4-7 one), a Gaussian count
+    that 8 does not divide (owned row ranges are ragged, the last rank owns fewer rows).  With more than two ranks the
+    order in which gloo adds the partial sums is its own, so sums are compared to 1e-6; what must hold exactly: every
+    rank ends with the same bucket, the owned ranges tile [0, P), and the sparse exchange moves fewer bytes."""
+    P, V, world = 301, 12, 8
+    assert P % world != 0
+    ref = GradientBucket(P, GradLayout(1, 15), "cpu")
+    for v in range(V):
+        g, radii = _fake_view_grads(P, 1, 15, v)
+        hidden = torch.arange(P) % (3 + v) == 0
+        for k in g:
+            g[k][hidden] = 0
+        radii[hidden] = 0
+        radii[~hidden] += 1
+        ref.accumulate(g, radii)
+    res = {m: _run_exchange(m, P=P, V=V, world=world) for m in ("all_reduce", "sparse", "reduce_scatter")}
+    for m, r in res.items():
+        torch.testing.assert_close(r["flat"], ref.flat, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(r["densify"], ref.densify, rtol=1e-5, atol=1e-5)
+        assert torch.equal(r["max_radii"], ref.max_radii), m
+    w = res["sparse"]["wire0"]
+    assert all(res["sparse"][f"wire{r}"] == w for r in range(world))
+    assert w["active_rows"] == int((ref.densify[:, 1] > 0).sum()) and w["bytes_sparse"] < w["bytes_dense"]
+    covered = []
+    for rank in range(world):
+        r0, r1, rows = res["reduce_scatter"][f"rows{rank}"]
+        assert (r0, r1) == GradientBucket.owned_rows(P, rank, world)
+        torch.testing.assert_close(rows, ref.flat[r0:r1], rtol=1e-5, atol=1e-5)
+        covered += list(range(r0, r1))
+    assert covered == list(range(P))
+    assert GradientBucket.owned_rows(P, world - 1, world)[1] - GradientBucket.owned_rows(P, world - 1, world)[0] < \
+        GradientBucket.owned_rows(P, 0, world)[1]  # the ragged tail

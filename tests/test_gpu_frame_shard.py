@@ -16,7 +16,7 @@ P, W, H, F, V = 6000, 200, 150, 15, 5
 LRS = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
 
 
-def _inputs(dev):
+def _inputs(dev, P=P, V=V):
     from online_lang_splatting_amd.scene import arc_cameras, make_scene
     sc = make_scene(P, W, H, F, seed=17)
     g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
@@ -120,3 +120,65 @@ def test_two_ranks_equal_the_single_process_sum(hip):
 def test_overflow_on_any_rank_surfaces_on_every_rank(hip):
     res = _spawn("all_reduce", capacity=2000)
     assert "overflow0" in res and "overflow1" in res and "capacity >=" in res["overflow0"]
+
+
+# ---- eight ranks (the driver's 8-GPU shape) sharing the one device of the test box -------------------------------------
+P8, V8 = 6001, 12  # a Gaussian count 8 does not divide (ragged owned rows), the 12 views of a mapping iteration
+
+
+def _worker8(rank, world, port, ret):
+    from online_lang_splatting_amd.frame_shard import FrameShardedStep, FusedAdam, GradLayout, RasterWorkspace
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    sc, g, cams, cot = _inputs(dev, P8, V8)
+    M = sc.shs.shape[1]
+    ws = RasterWorkspace(P8, W, H, F, M, 400000, dev)
+    for exchange in ("all_reduce", "sparse", "reduce_scatter"):
+        st = FrameShardedStep(ws, rank, world, exchange=exchange)
+        params = {k: v.clone() for k, v in g.items() if k != "bg"}
+        adam = FusedAdam(P8, GradLayout(M, F), dev)
+        for _ in range(3):  # three optimisation steps: the parameters every rank renders from must stay identical
+            bucket = st.run(dict(bg=g["bg"], **params), cams, lambda v, out: cot[v], sh_degree=sc.sh_degree)
+            st.optimizer_step(adam, params, LRS)
+        torch.cuda.synchronize()
+        ret[f"{exchange}:params{rank}"] = {k: v.cpu() for k, v in params.items()}
+        ret[f"{exchange}:owned{rank}"] = st.owned
+        ret[f"{exchange}:views{rank}"] = sorted(st.pose_grads)
+        if rank == 0:
+            ret[f"{exchange}:flat"] = bucket.flat.cpu()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_three_steps_every_exchange(hip):
+    """12 views on 8 ranks (ranks 0-3 render two views, 4-7 one), ragged owned rows, three optimisation steps per
+    exchange mode: every rank holds bit-identical parameters afterwards, the three exchanges agree with each other to
+    summation-order noise, each view's pose gradient stays on exactly one rank, and the parameters moved."""
+    from online_lang_splatting_amd.frame_shard import GradientBucket
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_worker8, args=(world, port, ret), nprocs=world, join=True)
+    res = dict(ret)
+    start = _inputs(torch.device("cpu"), P8, V8)[1]
+    for m in ("all_reduce", "sparse", "reduce_scatter"):
+        ref = res[f"{m}:params0"]
+        for r in range(1, world):
+            for k in ref:
+                assert torch.equal(res[f"{m}:params{r}"][k], ref[k]), (m, r, k)
+        assert not torch.equal(ref["means3D"], start["means3D"])
+        views = sorted(v for r in range(world) for v in res[f"{m}:views{r}"])
+        assert views == list(range(V8))
+        assert [len(res[f"{m}:views{r}"]) for r in range(world)] == [2, 2, 2, 2, 1, 1, 1, 1]
+    covered = []
+    for r in range(world):
+        r0, r1 = res[f"reduce_scatter:owned{r}"]
+        assert (r0, r1) == GradientBucket.owned_rows(P8, r, world)
+        covered += list(range(r0, r1))
+    assert covered == list(range(P8)) and P8 % world != 0
+    for k in res["all_reduce:params0"]:
+        for m in ("sparse", "reduce_scatter"):
+            torch.testing.assert_close(res[f"{m}:params0"][k], res["all_reduce:params0"][k], rtol=2e-4, atol=2e-5)
