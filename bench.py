@@ -331,6 +331,20 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
     T0[:3, :3] = torch.eye(3) + Wm + 0.5 * Wm @ Wm
     T0[:3, 3] = tau0[:3]
     T0 = T0.to(dev)
+    # library stages of the iteration (HIP events between the stages, ~6 us each: a separate, profiled pass)
+    pose.reset(T0)
+    loop = TrackingLoop(ws, g_dev, sc.sh_degree, pose, gt_image, gt_depth, language_cotangent="null")
+    for _ in range(3):
+        loop.iteration()
+    torch.cuda.synchronize(dev)
+    _lib.set_profiling(True)
+    for _ in range(10):
+        loop.iteration()
+    per = {}
+    for name, ms in _lib.stage_times():
+        per.setdefault(name, []).append(ms)
+    _lib.set_profiling(False)
+    stage = {k: round(sum(v) / len(v), 4) for k, v in per.items()}
     trk = {}
     for variant in ("null", "zeros"):
         for readback in (False, True):
@@ -347,26 +361,13 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
             key = ("no_language_cotangent" if variant == "null" else "zero_language_cotangent") + \
                   ("_with_convergence_readback" if readback else "")
             trk[key] = round(1e3 * el / tracking_iters, 4)
-    # library stages of the iteration (HIP events between the stages, ~6 us each: a separate, profiled pass)
-    pose.reset(T0)
-    loop = TrackingLoop(ws, g_dev, sc.sh_degree, pose, gt_image, gt_depth, language_cotangent="null")
-    for _ in range(3):
-        loop.iteration()
-    torch.cuda.synchronize(dev)
-    _lib.set_profiling(True)
-    for _ in range(10):
-        loop.iteration()
-    per = {}
-    for name, ms in _lib.stage_times():
-        per.setdefault(name, []).append(ms)
-    _lib.set_profiling(False)
-    stage = {k: round(sum(v) / len(v), 4) for k, v in per.items()}
     out["tracking_iteration_ms"] = trk["no_language_cotangent"]
     out["tracking"] = {"ms_per_iteration": trk, "iterations": tracking_iters,
                        "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) + "
                                "olsr_tracking_loss + pose-only olsr_backward + olsr_pose_step; dependent iterations",
                        "library_stage_ms": stage, "library_ms": round(sum(stage.values()), 4),
-                       "pose_error_after": float((pose.T_w2c - T_gt).abs().max())}
+                       "pose_error_start": round(float((T0 - T_gt).abs().max()), 6),
+                       "pose_error_after": round(float((pose.T_w2c - T_gt).abs().max()), 6)}
     del ws
     # mapping iteration: raw parameters (what GaussianModel stores), activations folded into the kernels
     params = dict(means3D=g_dev["means3D"].clone(), shs=g_dev["shs"].clone(),
@@ -485,6 +486,9 @@ def main():
     ap.add_argument("--mode", default="reference", choices=["reference", "exact"])
     ap.add_argument("--binning", default="ellipse", choices=["ellipse", "rect"],
                     help="ellipse: exact tile lists (default); rect: the reference's bounding-square lists")
+    ap.add_argument("--fwd-accum", default="valu", choices=["valu", "mfma"],
+                    help="forward feature accumulation: vector ALU (bit-identical to the oracle) or matrix cores "
+                         "(OLSR_FLAG_FWD_ACCUM_MFMA: images to ~1e-7 relative)")
     ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (workspaces on separate HIP streams)")
     ap.add_argument("--views", type=int, default=0,
                     help="mapping-iteration mode: every step renders this many viewpoints in total, view v on rank v mod N "
@@ -548,7 +552,8 @@ def main():
     del r
     _C.BINNING = _abi.BINNING_ELLIPSE
     capacity = int(R * 1.25) + (1 << 16)
-    lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning)
+    fwd_flags = _abi.FLAG_FWD_ACCUM_MFMA if a.fwd_accum == "mfma" else 0
+    lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning, flags=fwd_flags)
 
     pending = {}  # bucket id -> outstanding all-reduce handles of that lane's previous frame
     step_done = []  # one event per step of the current timed region, recorded on the step's stream
@@ -686,7 +691,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{a.config - 1}]: {P} Gaussians, {W}x{H}, RGB+depth+{F} "
                                    f"language channels, forward+backward, tile 15, backward mode {a.mode}",
                        "P": P, "width": W, "height": H, "F": F, "R": R_ref, "R_over_P": round(R_ref / max(P, 1), 3),
-                       "binning": a.binning, "R_binned": Rr,
+                       "binning": a.binning, "R_binned": Rr, "forward_accumulation": a.fwd_accum,
                        "views_per_step": world, "parallelism": f"frame-shard x{world}",
                        "frames_in_flight_per_gpu": len(lanes), "live_gradient_rows": L_rows,
                        "capacity_overflow": bool(overflow or row_overflow)},

@@ -73,6 +73,14 @@ typedef void *(*olsr_alloc_fn)(void *user, size_t nbytes);
  *       (DGR-D/cuda_rasterizer/forward.cu:391-431), so the caller that composes the two passes must know the radius of
  *       the set that covered none.  A backward must be given max(radii, 0). */
 #define OLSR_FLAG_SIGNED_EMPTY_RADII 1
+/*   OLSR_FLAG_FWD_ACCUM_MFMA  (forward) the per-pixel feature accumulation C += f alpha T of the forward composite — a dense
+ *       [64 pixels x K entries] x [K x (4 + F) channels] contraction per wave — runs on the matrix cores
+ *       (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fma chain) instead of the vector ALU.  Every decision (alpha
+ *       floor, saturation, n_touched, the backward's liveness flags) stays on the vector ALU and is unchanged, so
+ *       final_T / n_contrib / radii / n_touched are bit-identical; the images are rounded as fma(alpha T, f, C) where the
+ *       reference's source order (CR/forward.cu:479-484) gives fma(f alpha, T, C): equal to ~1e-7 relative, not bit for
+ *       bit.  Non-finite features then poison the 16-pixel block instead of the blending pixels only. */
+#define OLSR_FLAG_FWD_ACCUM_MFMA 2
 
 /* How Gaussians are binned into tiles.
  *   OLSR_BINNING_RECT     every tile of the reference's bounding square (getRect, CR/auxiliary.h:46-56):

@@ -30,6 +30,9 @@ from ._lib import check, lib
 TILE = 15
 BWD_MODE = _abi.BWD_REFERENCE
 BINNING = _abi.BINNING_ELLIPSE
+FLAGS = 0  # _abi.FLAG_* bits OR-ed into every forward (e.g. _abi.FLAG_FWD_ACCUM_MFMA); OLSR_FWD_ACCUM=mfma sets that one
+if os.environ.get("OLSR_FWD_ACCUM", "") == "mfma":
+    FLAGS |= _abi.FLAG_FWD_ACCUM_MFMA
 
 _EMPTY = torch.empty(0)
 _ext = None
@@ -135,6 +138,7 @@ def _forward(F, bg, means3D, colors, language, opacity, scales, rotations, scale
              projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
              prefiltered, debug, cfg=None, flags=0):
     """`cfg` (tile, bwd_mode, binning) overrides the module knobs for this call; `flags`: _abi.FLAG_*."""
+    flags = int(flags) | FLAGS
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # DGR/rasterize_points.cu:159-161
     _require_gpu(means3D, "means3D")

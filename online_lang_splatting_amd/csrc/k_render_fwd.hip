@@ -43,8 +43,15 @@ __device__ unsigned long long g_fwd_stats[8];
 #define FWD_STAT(i, v)
 #endif
 
-template <int TILE, int F>
-__global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
+// MFMA (OLSR_FLAG_FWD_ACCUM_MFMA): the accumulation acc[64 px x (4 + F)] += w[64 px x K] feat[K x (4 + F)], w = alpha T, runs on
+// the matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32, a k-ordered fma chain) in groups of K = 4 blending entries per
+// wave, beside the VALU that evaluates alpha and the transmittance; every decision stays on the VALU, bit for bit.
+// The product is then rounded as fma(alpha T, f, C) instead of the reference's fma(f alpha, T, C): images agree with the
+// oracle to ~1e-7 relative instead of bit for bit (final_T, n_contrib, radii, n_touched, flags stay bit-identical).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TILE, int F, bool MFMA>
+__global__ __launch_bounds__(256, (F <= 16 ? (MFMA ? 5 : 7) : (MFMA ? 4 : 5))) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
@@ -56,11 +63,12 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
   constexpr int FR = feat_row(F);
   constexpr int NA = 4 + F;  // r g b depth lang[F]
   constexpr int B = FWD_BATCH;
+  constexpr int NC = (NA + 15) / 16;  // MFMA: channel blocks of 16
 
   // geometry of two consecutive list entries side by side, so that 16-byte LDS reads land as register pairs for
   // packed fp32 math: {x0 x1 y0 y1} {thr0 thr1 a0 a1} {b0 b1 c0 c1} {op0 op1 - -}
   __shared__ float4 s_pair[(B / 2) * 4];
-  __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
+  __shared__ __attribute__((aligned(16))) float s_feat[B * FR + 16];  // (+16: the MFMA B operand reads whole 16-channel blocks)
   __shared__ u32 s_id[B];
   __shared__ u32 s_src[B];
   // per staged splat, 16 bits per wave: bit 15 = the wave's slot blended it, bits 0-6 = how many of its pixels
@@ -109,9 +117,42 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
   u32 last_contributor = 0;
   // r g b depth lang[F] in pairs: the accumulation runs on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32)
   constexpr int NA2 = (NA + 1) / 2;
-  v2f acc2[NA2];
+  v2f acc2[MFMA ? 1 : NA2];
 #pragma unroll
-  for (int k = 0; k < NA2; ++k) acc2[k] = v2f{0.0f, 0.0f};
+  for (int k = 0; k < (MFMA ? 1 : NA2); ++k) acc2[k] = v2f{0.0f, 0.0f};
+  // MFMA: accm[b][c] = the 16 x 16 block (pixels 16 b .. 16 b + 15 of this wave) x (channels 16 c .. 16 c + 15) in the D
+  // layout (lane l, register r: pixel 4 (l >> 4) + r, channel l & 15); up to four blending entries wait in w0..w3
+  // (w = alpha T per pixel, 0 where the pixel does not blend) with their LDS slots in `myslot` (row k of the wave: entry k)
+  f32x4 accm[MFMA ? 4 : 1][MFMA ? NC : 1];
+#pragma unroll
+  for (int b_ = 0; b_ < (MFMA ? 4 : 1); ++b_)
+#pragma unroll
+    for (int c_ = 0; c_ < (MFMA ? NC : 1); ++c_) accm[b_][c_] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+  int gfill = 0;   // wave-uniform: entries waiting
+  u32 myslot = 0;
+  const int bcol = tid & 15;
+  auto mfma_flush = [&]() {
+    if constexpr (MFMA) {
+      // 4 x 4 transpose of (row of 16 lanes, register): A_b[row k] = w_k[row b] — two half swaps, two row swaps
+      const auto s02 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, w0), __builtin_bit_cast(unsigned, w2), false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, w1), __builtin_bit_cast(unsigned, w3), false, false);
+      const unsigned p0 = s02[0], p2 = s02[1], p1 = s13[0], p3 = s13[1];
+      const auto t01 = __builtin_amdgcn_permlane16_swap(p0, p1, false, false);
+      const auto t23 = __builtin_amdgcn_permlane16_swap(p2, p3, false, false);
+      const unsigned q0 = t01[0], q1 = t01[1], q2 = t23[0], q3 = t23[1];
+      const float a_[4] = {__builtin_bit_cast(float, q0), __builtin_bit_cast(float, q1), __builtin_bit_cast(float, q2),
+                           __builtin_bit_cast(float, q3)};
+#pragma unroll
+      for (int c_ = 0; c_ < NC; ++c_) {
+        const float bv = s_feat[myslot * FR + 16 * c_ + bcol];  // B[k][j]: channel 16 c + j of the entry in row k
+#pragma unroll
+        for (int b_ = 0; b_ < 4; ++b_) accm[b_][c_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[b_], bv, accm[b_][c_], 0, 0, 0);
+      }
+      w0 = 0.f; w1 = 0.f; w2 = 0.f; w3 = 0.f;
+      gfill = 0;
+    }
+  };
 
   for (int base = 0; base < n; base += B) {
     // also the barrier that separates the previous batch's flush from this batch's staging
@@ -194,10 +235,22 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
           const u64 contrib_m = ok_m & ~term_m;
           done_m |= term_m;
           FWD_STAT(4, 1);
+          if (MFMA && contrib_m != 0ull) {
+            const bool cl = __builtin_amdgcn_inverse_ballot_w64(contrib_m);
+            const float wv = cl ? alpha * T : 0.0f;
+            T = cl ? test_T : T;
+            last_contributor = cl ? (u32)(base + jj + 1) : last_contributor;
+            if (__builtin_amdgcn_inverse_ballot_w64(0xFFFFull << (16 * gfill))) myslot = (u32)jj;
+            if (gfill == 0) w0 = wv;
+            else if (gfill == 1) w1 = wv;
+            else if (gfill == 2) w2 = wv;
+            else w3 = wv;
+            if (++gfill == 4) mfma_flush();
+          }
           if (contrib_m != 0ull) {
             FWD_STAT(2, 1);
             FWD_STAT(3, __popcll(contrib_m));
-            if (__builtin_amdgcn_inverse_ballot_w64(contrib_m)) {
+            if (!MFMA && __builtin_amdgcn_inverse_ballot_w64(contrib_m)) {
               // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
               // reference's expression (CR/forward.cu:479-484), and what the oracle restates
               const v2f* fr2 = reinterpret_cast<const v2f*>(&s_feat[jj * FR]);
@@ -216,6 +269,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
         }
         if (done_m == ~0ull) break;
       }
+      // the entries still waiting read their features from THIS batch's LDS rows: flush before it is restaged
+      if (MFMA && gfill != 0) mfma_flush();
     }
     __syncthreads();
     if (tid < cnt) {
@@ -250,17 +305,43 @@ __global__ __launch_bounds__(256, (F <= 16 ? 7 : 5)) void render_fwd_kernel(
   __syncthreads();
   if (tid == 0) tile_work[tile_id] = s_work;
 
-  if (inside) {
-    const size_t HW = (size_t)H * W;
-    const u32 p = (u32)W * (u32)py + (u32)px;
-    final_T[p] = T;
-    n_contrib[p] = last_contributor;
-    float acc[2 * NA2];
+  float acc[2 * NA2];
+  if constexpr (MFMA) {
+    // D layout -> one pixel per lane, through the (now idle) feature rows: two waves at a time, 64 pixels x FR floats each
+    const int lane = tid & 63;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      float* o = s_feat + (w & 1) * 64 * FR;
+      if ((w >> 1) == round) {
+#pragma unroll
+        for (int b_ = 0; b_ < 4; ++b_)
+#pragma unroll
+          for (int c_ = 0; c_ < NC; ++c_)
+#pragma unroll
+            for (int r_ = 0; r_ < 4; ++r_) {
+              const int ch = 16 * c_ + bcol;
+              if (ch < NA) o[(16 * b_ + 4 * (lane >> 4) + r_) * FR + ch] = accm[b_][c_][r_];
+            }
+      }
+      __syncthreads();
+      if ((w >> 1) == round) {
+#pragma unroll
+        for (int ch = 0; ch < NA; ++ch) acc[ch] = o[lane * FR + ch];
+      }
+      __syncthreads();
+    }
+  } else {
 #pragma unroll
     for (int k = 0; k < NA2; ++k) {
       acc[2 * k] = acc2[k].x;
       acc[2 * k + 1] = acc2[k].y;
     }
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W;
+    const u32 p = (u32)W * (u32)py + (u32)px;
+    final_T[p] = T;
+    n_contrib[p] = last_contributor;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) out_color[ch * HW + p] = acc[ch] + T * bg[ch];
     out_depth[p] = acc[3];
@@ -277,11 +358,15 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                          const ImageState& im, float* out_color, float* out_language, float* out_depth,
                          float* out_opacity, int32_t* n_touched, uint32_t* order_inout, hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
-  render_fwd_kernel<TILE, F><<<d.ntiles, 256, 0, st>>>(im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles,
-                                                       g.means2D, g.conic_opacity, g.depths, colors,
-                                                       s.language_precomp, s.background, im.final_T, im.n_contrib,
-                                                       out_color, out_language, out_depth, out_opacity, n_touched,
-                                                       b.flags, im.tile_work, order_inout);
+#define OLSR_FWD_ARGS                                                                                                  \
+  im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
+      s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
+      n_touched, b.flags, im.tile_work, order_inout
+  if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
+    render_fwd_kernel<TILE, F, true><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
+  else
+    render_fwd_kernel<TILE, F, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
+#undef OLSR_FWD_ARGS
   launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, st);
 }
 

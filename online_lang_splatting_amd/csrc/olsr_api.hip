@@ -90,7 +90,7 @@ int check_scene(const olsr_scene* s, bool backward) {
   if (!s->means3D || !s->background || !s->viewmatrix || !s->projmatrix || !s->cam_pos)
     return fail(OLSR_ERR_ARG, "means3D, background, viewmatrix, projmatrix and cam_pos are required");
   if (!backward && !s->opacities) return fail(OLSR_ERR_ARG, "opacities are required");
-  if (s->flags & ~OLSR_FLAG_SIGNED_EMPTY_RADII) return fail(OLSR_ERR_ARG, "flags holds unknown OLSR_FLAG_* bits");
+  if (s->flags & ~(OLSR_FLAG_SIGNED_EMPTY_RADII | OLSR_FLAG_FWD_ACCUM_MFMA)) return fail(OLSR_ERR_ARG, "flags holds unknown OLSR_FLAG_* bits");
   if (s->activations & ~(OLSR_ACT_OPACITY_SIGMOID | OLSR_ACT_SCALE_EXP | OLSR_ACT_ROTATION_NORMALIZE))
     return fail(OLSR_ERR_ARG, "activations holds unknown OLSR_ACT_* bits");
   if (backward && (s->activations & OLSR_ACT_OPACITY_SIGMOID) && !s->opacities)

@@ -232,10 +232,11 @@ class RasterWorkspace:
     """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
 
     def __init__(self, P, W, H, F, M, capacity, device, tile=15, bwd_mode=_abi.BWD_REFERENCE, row_capacity=None,
-                 binning=_abi.BINNING_ELLIPSE):
+                 binning=_abi.BINNING_ELLIPSE, flags=0):
         self.P, self.W, self.H, self.F, self.M = int(P), int(W), int(H), int(F), int(M)
         self.capacity, self.tile, self.bwd_mode = int(capacity), int(tile), int(bwd_mode)
         self.binning_mode = int(binning)
+        self.flags = int(flags)  # _abi.FLAG_* (e.g. FLAG_FWD_ACCUM_MFMA)
         # rows of the backward scratch: live (instance, slot) pairs, at most 4 per instance; one per
         # instance covers ordinary scenes several times over (config 3 needs 0.24), overflow is reported
         self.row_capacity = int(row_capacity) if row_capacity is not None else self.capacity
@@ -290,7 +291,7 @@ class RasterWorkspace:
             P=self.P, D=sh_degree, M=self.M if shs is not None else 0, F=self.F, width=self.W, height=self.H,
             tile=self.tile, prefiltered=False, debug=False, bwd_mode=self.bwd_mode, tan_fovx=tanfovx,
             tan_fovy=tanfovy, scale_modifier=scale_modifier, binning=self.binning_mode, activations=activations,
-            background=bg,
+            flags=self.flags, background=bg,
             means3D=means3D, shs=shs,
             colors_precomp=colors_precomp, language_precomp=language, opacities=opacities, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix,
