@@ -435,8 +435,9 @@ def views_mode(a, sc, dev, rank, world, dist):
             c["projmatrix"], c["projmatrix_raw"], c["tanfovx"], c["tanfovy"], H, W, g_dev["shs"], sc.sh_degree,
             c["campos"], False, False]
         need = max(need, int((_C.rasterize_language_gaussians if F > 0 else _C.rasterize_gaussians)(*args)[0]))
-    ws = RasterWorkspace(P, W, H, F, M, int(need * 1.3) + (1 << 16), dev)
-    step = FrameShardedStep(ws, rank, world, exchange=a.exchange)
+    # this rank's views are rendered a.streams at a time (FrameLanes: one workspace, bucket and HIP stream per lane)
+    lanes = FrameLanes(max(1, min(a.streams, len(mine))), P, W, H, F, M, int(need * 1.3) + (1 << 16), dev)
+    step = FrameShardedStep(lanes, rank, world, exchange=a.exchange)
     adam = FusedAdam(P, GradLayout(M, F), dev)
     params = dict(means3D=g_dev["means3D"], shs=g_dev["shs"], opacities=g_dev["opacities"], scales=g_dev["scales"],
                   rotations=g_dev["rotations"], language=g_dev["language"])
@@ -470,6 +471,7 @@ def views_mode(a, sc, dev, rank, world, dist):
             "config": {"workload": f"BASELINE.json configs[{a.config - 1}] Gaussians, {a.views} arc viewpoints per step, "
                                    f"view v on rank v mod {world}, exchange {a.exchange}, fused Adam",
                        "P": P, "width": W, "height": H, "F": F, "views_per_step": a.views,
+                       "views_in_flight_per_gpu": len(lanes),
                        "views_of_rank0": len(views_of_rank(a.views, 0, world)), "parallelism": f"frame-shard x{world}",
                        "exchange": a.exchange, "bucket_bytes": P * width * 4,
                        "wire": step.wire}}), flush=True)

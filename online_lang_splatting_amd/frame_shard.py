@@ -391,59 +391,104 @@ class FrameShardedStep:
     per-rank flag travels with the MAX all-reduce and `run` raises OverflowError on every rank, with the capacity
     that would have sufficed, so the caller can regrow its workspace and repeat the step."""
 
-    def __init__(self, workspace: RasterWorkspace, rank=0, world=1, group=None, exchange="all_reduce"):
+    def __init__(self, workspace, rank=0, world=1, group=None, exchange="all_reduce"):
+        """workspace: a RasterWorkspace (this rank's views are rendered one after the other) or a FrameLanes (they are
+        rendered `len(lanes)` at a time on the lanes' streams, each lane accumulating into its own bucket; the lane
+        buckets are summed — in lane order, a fixed order — before the exchange)."""
         assert exchange in ("all_reduce", "reduce_scatter", "sparse")
-        self.ws = workspace
+        if isinstance(workspace, FrameLanes):
+            self.lanes = list(workspace.lanes)
+        else:
+            self.lanes = [(workspace, GradientBucket(workspace.P, GradLayout(workspace.M, workspace.F), workspace.device),
+                           None)]
+        self.ws = self.lanes[0][0]
+        ws = self.ws
         self.rank, self.world, self.group, self.exchange = rank, world, group, exchange
-        self.bucket = GradientBucket(workspace.P, GradLayout(workspace.M, workspace.F), workspace.device)
+        self.bucket = self.lanes[0][1]
         self.pose_grads: Dict[int, torch.Tensor] = {}
-        self.owned = GradientBucket.owned_rows(workspace.P, rank, world)
+        self.owned = GradientBucket.owned_rows(ws.P, rank, world)
         self.wire = None  # dict from the sparse exchange
-        self._need = torch.zeros(2, dtype=torch.int32, device=workspace.device)  # max over views {R, live rows}
-        self._ovf = torch.zeros(1, dtype=torch.int32, device=workspace.device)
+        # per lane: max over its views {R, live rows} and the overflow flag (stay on the device, on the lane's stream)
+        self._need = [torch.zeros(2, dtype=torch.int32, device=ws.device) for _ in self.lanes]
+        self._ovf = [torch.zeros(1, dtype=torch.int32, device=ws.device) for _ in self.lanes]
 
     def run(self, gaussians: Dict[str, torch.Tensor], cameras: Sequence[Dict], cotangents, sh_degree=0):
         """gaussians: bg, means3D, opacities, scales, rotations, shs, language.
         cameras[v]: viewmatrix, projmatrix, projmatrix_raw, campos (device tensors), tanfovx, tanfovy.
-        cotangents(v, outputs) -> (dL_dcolor, dL_dlanguage, dL_ddepth): the caller's loss gradient."""
+        cotangents(v, outputs) -> (dL_dcolor, dL_dlanguage, dL_ddepth): the caller's loss gradient (called on the
+        lane's stream)."""
         import torch.distributed as dist
-        ws = self.ws
+        dev = self.ws.device
+        main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         self.pose_grads.clear()
-        self._need.zero_()
-        self._ovf.zero_()
         mine = views_of_rank(len(cameras), self.rank, self.world)
-        if not mine:
-            self.bucket.zero_()
+        L = len(self.lanes)
+        used = []
+        for i, (ws, bucket, stream) in enumerate(self.lanes):
+            st = stream if stream is not None else main
+            if st != main:
+                st.wait_stream(main)  # the parameters this step renders from were written on the caller's stream
+            with torch.cuda.stream(st):
+                self._need[i].zero_()
+                self._ovf[i].zero_()
         for n_done, v in enumerate(mine):
+            i = n_done % L
+            ws, bucket, stream = self.lanes[i]
+            st = stream if stream is not None else main
+            first = i not in used
+            if first:
+                used.append(i)
             cam = cameras[v]
-            ws.set_scene(sh_degree=sh_degree, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
-                         projmatrix_raw=cam["projmatrix_raw"], campos=cam["campos"], tanfovx=cam["tanfovx"],
-                         tanfovy=cam["tanfovy"], **gaussians)
-            out = ws.forward()
-            dc, dl, dd = cotangents(v, out)
-            # the per-Gaussian backward kernel writes / adds straight into the bucket (fused accumulate)
-            g = ws.backward(dc, dl, dd, bucket=self.bucket, first=(n_done == 0), bucket_only=True)
-            self.pose_grads[v] = g["dL_dtau_sum"].clone()  # [rho | theta], stays on the owning rank
-            # overflow bookkeeping stays on the device (no sync inside the loop)
-            torch.maximum(self._need[0:1], ws.num_rendered[0:1], out=self._need[0:1])
-            torch.maximum(self._need[1:2], ws.bwd_status[0:1], out=self._need[1:2])
-            torch.maximum(self._ovf, torch.maximum(ws.num_rendered[1:2], ws.bwd_status[1:2]), out=self._ovf)
+            with torch.cuda.stream(st):
+                ws.set_scene(sh_degree=sh_degree, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
+                             projmatrix_raw=cam["projmatrix_raw"], campos=cam["campos"], tanfovx=cam["tanfovx"],
+                             tanfovy=cam["tanfovy"], **gaussians)
+                out = ws.forward()
+                dc, dl, dd = cotangents(v, out)
+                # the per-Gaussian backward kernel writes / adds straight into the lane's bucket (fused accumulate)
+                g = ws.backward(dc, dl, dd, bucket=bucket, first=first, bucket_only=True)
+                self.pose_grads[v] = g["dL_dtau_sum"].clone()  # [rho | theta], stays on the owning rank
+                # overflow bookkeeping stays on the device (no sync inside the loop)
+                torch.maximum(self._need[i][0:1], ws.num_rendered[0:1], out=self._need[i][0:1])
+                torch.maximum(self._need[i][1:2], ws.bwd_status[0:1], out=self._need[i][1:2])
+                torch.maximum(self._ovf[i], torch.maximum(ws.num_rendered[1:2], ws.bwd_status[1:2]), out=self._ovf[i])
+        for i in used:
+            st = self.lanes[i][2]
+            if st is not None and st != main:
+                main.wait_stream(st)
+        total = self.bucket
+        if not used:
+            total.zero_()
+        else:
+            if used[0] != 0:  # (never: lane 0 takes this rank's first view)
+                total.sum_storage.copy_(self.lanes[used[0]][1].sum_storage)
+                total.max_radii.copy_(self.lanes[used[0]][1].max_radii)
+            for i in used[1:]:
+                b = self.lanes[i][1]
+                total.sum_storage.add_(b.sum_storage)
+                torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
         multi = self.world > 1 and dist.is_available() and dist.is_initialized()
         if self.exchange == "reduce_scatter":
-            self.owned = self.bucket.reduce_scatter(self.rank, self.world, self.group)
+            self.owned = total.reduce_scatter(self.rank, self.world, self.group)
         elif self.exchange == "sparse":
-            self.wire = self.bucket.sparse_all_reduce(self.group)
+            self.wire = total.sparse_all_reduce(self.group)
         else:
-            self.bucket.all_reduce(self.group)
-        flags = torch.cat([self._ovf, self._need])
+            total.all_reduce(self.group)
+        ovf = self._ovf[0].clone()
+        need = self._need[0].clone()
+        for i in range(1, L):
+            torch.maximum(ovf, self._ovf[i], out=ovf)
+            torch.maximum(need, self._need[i], out=need)
+        flags = torch.cat([ovf, need])
         if multi:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
         ovf, need_R, need_L = (int(x) for x in flags.cpu())  # the step's one host synchronisation
         if ovf:
+            ws = self.ws
             raise OverflowError(f"a view overflowed the workspace on some rank: it needs capacity >= {need_R} instances "
                                 f"and row_capacity >= {need_L} gradient rows (has {ws.capacity} / {ws.row_capacity}); "
                                 "regrow the RasterWorkspace and repeat the step")
-        return self.bucket
+        return total
 
     def optimizer_step(self, adam: "FusedAdam", params: Dict[str, torch.Tensor], lrs: Dict[str, float]):
         """Apply the step to the raw parameters.  all_reduce / sparse: every rank updates every row (identical

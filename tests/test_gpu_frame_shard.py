@@ -127,13 +127,13 @@ P8, V8 = 6001, 12  # a Gaussian count 8 does not divide (ragged owned rows), the
 
 
 def _worker8(rank, world, port, ret):
-    from online_lang_splatting_amd.frame_shard import FrameShardedStep, FusedAdam, GradLayout, RasterWorkspace
+    from online_lang_splatting_amd.frame_shard import FrameLanes, FrameShardedStep, FusedAdam, GradLayout
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     sc, g, cams, cot = _inputs(dev, P8, V8)
     M = sc.shs.shape[1]
-    ws = RasterWorkspace(P8, W, H, F, M, 400000, dev)
+    ws = FrameLanes(2, P8, W, H, F, M, 400000, dev)  # a rank's two views are in flight together (ranks 0-3)
     for exchange in ("all_reduce", "sparse", "reduce_scatter"):
         st = FrameShardedStep(ws, rank, world, exchange=exchange)
         params = {k: v.clone() for k, v in g.items() if k != "bg"}
