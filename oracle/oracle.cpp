@@ -344,19 +344,63 @@ static void bin_and_sort(const olsr_scene& s, State& st, const int* radii) {
   const int bit = (int)getHigherMsb((uint32_t)(st.gx * st.gy));
   const uint64_t mask = (32 + bit >= 64) ? ~0ull : ((1ull << (32 + bit)) - 1);
   std::vector<uint32_t> order(R);
-  for (size_t i = 0; i < R; ++i) order[i] = (uint32_t)i;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    return (keys_unsorted[a] & mask) < (keys_unsorted[b] & mask);
-  });
+  const size_t ntiles = (size_t)st.gx * (size_t)st.gy;
+  if (bit < 32 && ((uint64_t)(ntiles ? ntiles - 1 : 0) >> bit) == 0) {
+    // Every tile id fits below the mask (always, by getHigherMsb's definition): the stable sort by (tile, depth bits)
+    // is a stable partition by tile followed by an independent stable sort of every tile's run by depth bits — the
+    // same permutation, bit for bit, with the parallelism of a host CPU (the baseline spent most of a
+    // frame in one thread's std::stable_sort).  Partition: per-chunk tile histograms -> exclusive prefix in (tile,
+    // chunk) order -> scatter (chunks are contiguous index ranges in ascending order, so equal tiles keep their order).
+    const int nthr = std::max(1, omp_get_max_threads());
+    const size_t chunk = (R + (size_t)nthr - 1) / (size_t)nthr;
+    std::vector<uint32_t> hist((size_t)nthr * ntiles, 0u);
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nthr; ++t) {
+      uint32_t* h = &hist[(size_t)t * ntiles];
+      const size_t b = std::min(R, (size_t)t * chunk), e = std::min(R, b + chunk);
+      for (size_t i = b; i < e; ++i) h[keys_unsorted[i] >> 32]++;
+    }
+    std::vector<uint32_t> tile_start(ntiles + 1, 0u);
+    {
+      uint32_t run2 = 0;
+      for (size_t tl = 0; tl < ntiles; ++tl) {
+        tile_start[tl] = run2;
+        for (int t = 0; t < nthr; ++t) {
+          const uint32_t c = hist[(size_t)t * ntiles + tl];
+          hist[(size_t)t * ntiles + tl] = run2;
+          run2 += c;
+        }
+      }
+      tile_start[ntiles] = run2;
+    }
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nthr; ++t) {
+      uint32_t* h = &hist[(size_t)t * ntiles];
+      const size_t b = std::min(R, (size_t)t * chunk), e = std::min(R, b + chunk);
+      for (size_t i = b; i < e; ++i) order[h[keys_unsorted[i] >> 32]++] = (uint32_t)i;
+    }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (long long tl = 0; tl < (long long)ntiles; ++tl)
+      std::stable_sort(order.begin() + tile_start[tl], order.begin() + tile_start[tl + 1], [&](uint32_t a, uint32_t b) {
+        return (uint32_t)keys_unsorted[a] < (uint32_t)keys_unsorted[b];
+      });
+  } else {
+    for (size_t i = 0; i < R; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+      return (keys_unsorted[a] & mask) < (keys_unsorted[b] & mask);
+    });
+  }
   st.keys.resize(R);
   st.point_list.resize(R);
-  for (size_t i = 0; i < R; ++i) {
+#pragma omp parallel for schedule(static)
+  for (long long i = 0; i < (long long)R; ++i) {
     st.keys[i] = keys_unsorted[order[i]];
     st.point_list[i] = vals_unsorted[order[i]];
   }
-  // cudaMemset + identifyTileRanges
+  // cudaMemset + identifyTileRanges (every write below is to a distinct element: the loop order does not matter)
   std::fill(st.ranges.begin(), st.ranges.end(), 0u);
-  for (size_t idx = 0; idx < R; ++idx) {
+#pragma omp parallel for schedule(static)
+  for (long long idx = 0; idx < (long long)R; ++idx) {
     uint32_t currtile = (uint32_t)(st.keys[idx] >> 32);
     if (idx == 0)
       st.ranges[2 * currtile] = 0;
@@ -367,7 +411,7 @@ static void bin_and_sort(const olsr_scene& s, State& st, const int* radii) {
         st.ranges[2 * currtile] = (uint32_t)idx;
       }
     }
-    if (idx == R - 1) st.ranges[2 * currtile + 1] = (uint32_t)R;
+    if ((size_t)idx == R - 1) st.ranges[2 * currtile + 1] = (uint32_t)R;
   }
 }
 
@@ -616,22 +660,33 @@ static void render_backward(const olsr_scene& s, State& st, int mode, const floa
       }
     }
   }
-  // "atomicAdd" of every tile's thread 0, in sorted (tile-major, then depth) order
-  for (size_t sp = 0; sp < R; ++sp) {
-    if (!inst_used[sp]) continue;
-    const uint32_t gid = st.point_list[sp];
-    const float* row = &inst[sp * NV];
-    dL_dmean2D[3 * (size_t)gid + 0] += row[0];
-    dL_dmean2D[3 * (size_t)gid + 1] += row[1];
-    dL_dconic2D[4 * (size_t)gid + 0] += row[2];
-    dL_dconic2D[4 * (size_t)gid + 1] += row[3];
-    dL_dconic2D[4 * (size_t)gid + 3] += row[4];
-    dL_dopacity[gid] += row[5];
-    dL_dcolors[(size_t)gid * 3 + 0] += row[6];
-    dL_dcolors[(size_t)gid * 3 + 1] += row[7];
-    dL_dcolors[(size_t)gid * 3 + 2] += row[8];
-    dL_ddepths[gid] += row[9];
-    for (int ch = 0; ch < F; ++ch) dL_dlanguage[(size_t)gid * F + ch] += row[10 + ch];
+  // "atomicAdd" of every tile's thread 0, in sorted (tile-major, then depth) order.  A Gaussian's sum only depends on the
+  // order of ITS OWN rows, so the Gaussians are dealt to threads by index range and every thread walks the whole sorted
+  // list, adding the rows of its Gaussians as it meets them: the same additions in the same order as the serial loop.
+  {
+    const int nthr = std::max(1, omp_get_max_threads());
+    const int P = s.P;
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < nthr; ++t) {
+      const uint32_t g0 = (uint32_t)((long long)P * t / nthr), g1 = (uint32_t)((long long)P * (t + 1) / nthr);
+      if (g0 == g1) continue;
+      for (size_t sp = 0; sp < R; ++sp) {
+        const uint32_t gid = st.point_list[sp];
+        if (gid < g0 || gid >= g1 || !inst_used[sp]) continue;
+        const float* row = &inst[sp * NV];
+        dL_dmean2D[3 * (size_t)gid + 0] += row[0];
+        dL_dmean2D[3 * (size_t)gid + 1] += row[1];
+        dL_dconic2D[4 * (size_t)gid + 0] += row[2];
+        dL_dconic2D[4 * (size_t)gid + 1] += row[3];
+        dL_dconic2D[4 * (size_t)gid + 3] += row[4];
+        dL_dopacity[gid] += row[5];
+        dL_dcolors[(size_t)gid * 3 + 0] += row[6];
+        dL_dcolors[(size_t)gid * 3 + 1] += row[7];
+        dL_dcolors[(size_t)gid * 3 + 2] += row[8];
+        dL_ddepths[gid] += row[9];
+        for (int ch = 0; ch < F; ++ch) dL_dlanguage[(size_t)gid * F + ch] += row[10 + ch];
+      }
+    }
   }
 }
 
