@@ -66,7 +66,7 @@ def algorithmic_bytes(P, R, N, C=3, F=15, M=1):
     return per
 
 
-PROFILE_TAG = "r2"  # the committed counter summaries of the current kernels: profiles/<tag>_pmc_{traffic,valu}.json
+PROFILE_TAG = "r3"  # the committed counter summaries of the current kernels: profiles/<tag>_pmc_{traffic,valu}.json
 
 
 def _pmc_summary(kind):
@@ -488,7 +488,7 @@ def main():
     ap.add_argument("--mode", default="reference", choices=["reference", "exact"])
     ap.add_argument("--binning", default="ellipse", choices=["ellipse", "rect"],
                     help="ellipse: exact tile lists (default); rect: the reference's bounding-square lists")
-    ap.add_argument("--fwd-accum", default="valu", choices=["valu", "mfma"],
+    ap.add_argument("--fwd-accum", default="valu", choices=["valu", "mfma", "weight"],
                     help="forward feature accumulation: vector ALU (bit-identical to the oracle) or matrix cores "
                          "(OLSR_FLAG_FWD_ACCUM_MFMA: images to ~1e-7 relative)")
     ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (workspaces on separate HIP streams)")
@@ -554,7 +554,7 @@ def main():
     del r
     _C.BINNING = _abi.BINNING_ELLIPSE
     capacity = int(R * 1.25) + (1 << 16)
-    fwd_flags = _abi.FLAG_FWD_ACCUM_MFMA if a.fwd_accum == "mfma" else 0
+    fwd_flags = {"mfma": _abi.FLAG_FWD_ACCUM_MFMA, "weight": _abi.FLAG_FWD_ACCUM_WEIGHT}.get(a.fwd_accum, 0)
     lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning, flags=fwd_flags)
 
     pending = {}  # bucket id -> outstanding all-reduce handles of that lane's previous frame

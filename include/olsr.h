@@ -81,6 +81,10 @@ typedef void *(*olsr_alloc_fn)(void *user, size_t nbytes);
  *       reference's source order (CR/forward.cu:479-484) gives fma(f alpha, T, C): equal to ~1e-7 relative, not bit for
  *       bit.  Non-finite features then poison the 16-pixel block instead of the blending pixels only. */
 #define OLSR_FLAG_FWD_ACCUM_MFMA 2
+/*   OLSR_FLAG_FWD_ACCUM_WEIGHT  (forward) the same rounding as the MFMA variant on the vector ALU: w = alpha T once per pixel,
+ *       then one fma(w, f, C) per channel instead of the reference's mul + fma (half the lane operations of the
+ *       accumulation).  Decisions unchanged and bit-identical; images to ~1e-7 relative of the reference's rounding. */
+#define OLSR_FLAG_FWD_ACCUM_WEIGHT 4
 
 /* How Gaussians are binned into tiles.
  *   OLSR_BINNING_RECT     every tile of the reference's bounding square (getRect, CR/auxiliary.h:46-56):

@@ -33,6 +33,8 @@ BINNING = _abi.BINNING_ELLIPSE
 FLAGS = 0  # _abi.FLAG_* bits OR-ed into every forward (e.g. _abi.FLAG_FWD_ACCUM_MFMA); OLSR_FWD_ACCUM=mfma sets that one
 if os.environ.get("OLSR_FWD_ACCUM", "") == "mfma":
     FLAGS |= _abi.FLAG_FWD_ACCUM_MFMA
+elif os.environ.get("OLSR_FWD_ACCUM", "") == "weight":
+    FLAGS |= _abi.FLAG_FWD_ACCUM_WEIGHT
 
 _EMPTY = torch.empty(0)
 _ext = None

@@ -50,8 +50,11 @@ __device__ unsigned long long g_fwd_stats[8];
 // oracle to ~1e-7 relative instead of bit for bit (final_T, n_contrib, radii, n_touched, flags stay bit-identical).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int TILE, int F, bool MFMA>
-__global__ __launch_bounds__(256, (F <= 16 ? (MFMA ? 5 : 7) : (MFMA ? 4 : 5))) void render_fwd_kernel(
+// ACC: 0 = the reference's rounding fma(f alpha, T, C) on the vector ALU (bit-identical to the oracle, default);
+//      1 = matrix cores (OLSR_FLAG_FWD_ACCUM_MFMA); 2 = w = alpha T once per pixel, then ONE fma(w, f, C) per channel on
+//      the vector ALU (OLSR_FLAG_FWD_ACCUM_WEIGHT: half the lane operations of the accumulation, the MFMA variant's rounding)
+template <int TILE, int F, int ACC>
+__global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (MFMA ? 5 : 7) : (MFMA ? 4 : 5))) v
   constexpr int FR = feat_row(F);
   constexpr int NA = 4 + F;  // r g b depth lang[F]
   constexpr int B = FWD_BATCH;
+  constexpr bool MFMA = (ACC == 1);
   constexpr int NC = (NA + 15) / 16;  // MFMA: channel blocks of 16
 
   // geometry of two consecutive list entries side by side, so that 16-byte LDS reads land as register pairs for
@@ -254,9 +258,16 @@ __global__ __launch_bounds__(256, (F <= 16 ? (MFMA ? 5 : 7) : (MFMA ? 4 : 5))) v
               // C += f * alpha * T as fma(f * alpha, T, C): what nvcc's default contraction makes of the
               // reference's expression (CR/forward.cu:479-484), and what the oracle restates
               const v2f* fr2 = reinterpret_cast<const v2f*>(&s_feat[jj * FR]);
-              const v2f a2 = {alpha, alpha}, T2 = {T, T};
+              if constexpr (ACC == 2) {
+                const float wv = alpha * T;
+                const v2f w2 = {wv, wv};
 #pragma unroll
-              for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
+                for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k], w2, acc2[k]);
+              } else {
+                const v2f a2 = {alpha, alpha}, T2 = {T, T};
+#pragma unroll
+                for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
+              }
               T = test_T;
               last_contributor = (u32)(base + jj + 1);
             }
@@ -363,9 +374,11 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
       n_touched, b.flags, im.tile_work, order_inout
   if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
-    render_fwd_kernel<TILE, F, true><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
+    render_fwd_kernel<TILE, F, 1><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
+  else if (s.flags & OLSR_FLAG_FWD_ACCUM_WEIGHT)
+    render_fwd_kernel<TILE, F, 2><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
   else
-    render_fwd_kernel<TILE, F, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
+    render_fwd_kernel<TILE, F, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
 #undef OLSR_FWD_ARGS
   launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, st);
 }

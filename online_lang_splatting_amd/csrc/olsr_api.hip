@@ -90,7 +90,7 @@ int check_scene(const olsr_scene* s, bool backward) {
   if (!s->means3D || !s->background || !s->viewmatrix || !s->projmatrix || !s->cam_pos)
     return fail(OLSR_ERR_ARG, "means3D, background, viewmatrix, projmatrix and cam_pos are required");
   if (!backward && !s->opacities) return fail(OLSR_ERR_ARG, "opacities are required");
-  if (s->flags & ~(OLSR_FLAG_SIGNED_EMPTY_RADII | OLSR_FLAG_FWD_ACCUM_MFMA)) return fail(OLSR_ERR_ARG, "flags holds unknown OLSR_FLAG_* bits");
+  if (s->flags & ~(OLSR_FLAG_SIGNED_EMPTY_RADII | OLSR_FLAG_FWD_ACCUM_MFMA | OLSR_FLAG_FWD_ACCUM_WEIGHT)) return fail(OLSR_ERR_ARG, "flags holds unknown OLSR_FLAG_* bits");
   if (s->activations & ~(OLSR_ACT_OPACITY_SIGMOID | OLSR_ACT_SCALE_EXP | OLSR_ACT_ROTATION_NORMALIZE))
     return fail(OLSR_ERR_ARG, "activations holds unknown OLSR_ACT_* bits");
   if (backward && (s->activations & OLSR_ACT_OPACITY_SIGMOID) && !s->opacities)
@@ -149,13 +149,11 @@ bool force_legacy_sort() {
 // sequence number into two words of mapped, coherent host memory with system-scope stores ("the data is the flag"),
 // and the host polls the second word — while the GPU goes straight on to the depth sort.  (A hipMemcpyAsync in the
 // stream cost a 4 us copy kernel and a 6 us bubble in front of the first radix pass.)
+// (the two words live until the process ends: a thread_local destructor could run after the HIP runtime's teardown)
 struct PinnedCount {
   int32_t* p = nullptr;   // host view: {count, sequence}
   int32_t* dp = nullptr;  // device view of the same two words
   int32_t seq = 0;
-  ~PinnedCount() {
-    if (p) (void)hipHostFree(p);
-  }
 };
 thread_local PinnedCount g_pinned;
 
@@ -229,8 +227,12 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
         if ((spin & 0xFFFFu) == 0xFFFFu) {  // every ~65 k polls: did the stream die, or is this taking seconds?
           const hipError_t q = hipStreamQuery(st);
           if (q != hipSuccess && q != hipErrorNotReady) return fail(OLSR_ERR_DEVICE, hipGetErrorString(q));
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            // the frame's kernels are still enqueued and write into buffers the caller frees on error: drain first
+            (void)hipStreamSynchronize(st);
+            if (__atomic_load_n(&box[1], __ATOMIC_ACQUIRE) == g_pinned.seq) break;  // (it was only slow)
             return fail(OLSR_ERR_DEVICE, "the instance count never arrived from the device");
+          }
         }
       }
       R = box[0];

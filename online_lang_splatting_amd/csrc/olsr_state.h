@@ -60,6 +60,8 @@ inline SortPlan sort_plan(long long n, bool n_is_capacity = false) {
   const long long res = sort_plan_resident_blocks();
   const long long n_est = n_is_capacity ? (n * 85 + 99) / 100 : n;
   int best = sort_plan_forced_kpt();
+  // (a forced kpt whose block count would overrun the status rows reserved for FUSED_SORT_MAX_BLOCKS is ignored)
+  if (best != 0 && (n + 1024LL * best - 1) / (1024LL * best) > FUSED_SORT_MAX_BLOCKS) best = 0;
   if (best == 0) {
     double best_cost = 0.0;
     for (int i = 0; i < 5; ++i) {

@@ -120,6 +120,8 @@ std::tuple<int, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, 
   Tensor radii = torch::empty({P}, i32), n_touched = torch::empty({P}, i32);
   Tensor geom = torch::empty({0}, u8), binb = torch::empty({0}, u8), img = torch::empty({0}, u8);
   int32_t R = 0;
+  // (the GIL stays held: the allocation callbacks resize torch tensors, and the host only waits while the instance
+  //  count travels — microseconds behind the depth sort)
   check(olsr_forward(&sc.s, resize, &geom, resize, &binb, resize, &img, out_color.data_ptr<float>(), fpw(out_lang),
                      out_depth.data_ptr<float>(), out_opacity.data_ptr<float>(), P ? radii.data_ptr<int32_t>() : nullptr,
                      P ? n_touched.data_ptr<int32_t>() : nullptr, &R, stream_of(means3D)));
@@ -178,10 +180,15 @@ std::vector<Tensor> backward(int F, const Tensor &bg, const Tensor &means3D, con
   const int64_t rows = static_cast<int64_t>(R > 0 ? R : 0) * slots;
   Tensor scratch = torch::empty({static_cast<int64_t>(olsr_backward_scratch_bytes(rows, F))},
                                 means3D.options().dtype(torch::kUInt8));
-  check(olsr_backward(&sc.s, P ? rad.data_ptr<int32_t>() : nullptr, geomBuffer.data_ptr(), R, binningBuffer.data_ptr(),
-                      imageBuffer.data_ptr(), nullptr, nullptr, scratch.data_ptr(), rows, fp(dc), fp(dl), fp(dd),
-                      fpw(g[0]), fpw(g[11]), fpw(g[3]), fpw(g[1]), fpw(g[2]), fpw(g[12]), fpw(g[4]), fpw(g[5]),
-                      fpw(g[6]), fpw(g[7]), fpw(g[8]), fpw(g[9]), fpw(g[10]), nullptr, nullptr, stream_of(means3D)));
+  int rc;
+  {
+    pybind11::gil_scoped_release nogil;  // pure launches, no callback into Python
+    rc = olsr_backward(&sc.s, P ? rad.data_ptr<int32_t>() : nullptr, geomBuffer.data_ptr(), R, binningBuffer.data_ptr(),
+                       imageBuffer.data_ptr(), nullptr, nullptr, scratch.data_ptr(), rows, fp(dc), fp(dl), fp(dd),
+                       fpw(g[0]), fpw(g[11]), fpw(g[3]), fpw(g[1]), fpw(g[2]), fpw(g[12]), fpw(g[4]), fpw(g[5]),
+                       fpw(g[6]), fpw(g[7]), fpw(g[8]), fpw(g[9]), fpw(g[10]), nullptr, nullptr, stream_of(means3D));
+  }
+  check(rc);
   return g;
 }
 

@@ -8,7 +8,7 @@ STEPS=${2:-20}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-extra-legs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B --steps $STEPS --warmup 5 > $OUT/bench_stats.log 2>&1
 # the same kernels with ONE frame in flight (no co-scheduling): per-kernel durations of the `isolated` leg
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- $B --steps $STEPS --warmup 5 --streams 1 --isolated-steps 0 > $OUT/bench_stats1.log 2>&1

@@ -14,11 +14,11 @@ DEV = "cuda:0"
 IMG_TOL = 1e-6
 
 
-def _compare(hip, oracle, sc, seed, tile=15, mode=0, binning=_abi.BINNING_ELLIPSE):
+def _compare(hip, oracle, sc, seed, tile=15, mode=0, binning=_abi.BINNING_ELLIPSE, flag=_abi.FLAG_FWD_ACCUM_MFMA):
     dev = torch.device(DEV)
     fo, go = run_backend(oracle, sc, None, seed, tile, mode)
     fv, gv = run_backend(hip, sc, dev, seed, tile, mode, binning=binning)
-    hip.FLAGS = _abi.FLAG_FWD_ACCUM_MFMA
+    hip.FLAGS = flag
     try:
         fm, gm = run_backend(hip, sc, dev, seed, tile, mode, binning=binning)
     finally:
@@ -52,6 +52,15 @@ def _compare(hip, oracle, sc, seed, tile=15, mode=0, binning=_abi.BINNING_ELLIPS
 @pytest.mark.parametrize("F", [0, 3, 15, 16, 32])
 def test_mfma_accumulation_all_channel_counts(hip, oracle, F):
     _compare(hip, oracle, make_scene(3000, 160, 120, F, seed=60 + F), seed=F)
+
+
+@pytest.mark.parametrize("F", [0, 15, 32])
+def test_weight_accumulation_on_the_vector_alu(hip, oracle, F):
+    """OLSR_FLAG_FWD_ACCUM_WEIGHT: the MFMA variant's rounding (fma(alpha T, f, C)) on the vector ALU."""
+    _compare(hip, oracle, make_scene(3000, 160, 120, F, seed=60 + F), seed=F, flag=_abi.FLAG_FWD_ACCUM_WEIGHT)
+    if F == 15:
+        _compare(hip, oracle, make_scene(6000, 200, 150, 15, seed=83, scale_mult=6.0), seed=3, tile=16,
+                 flag=_abi.FLAG_FWD_ACCUM_WEIGHT)
 
 
 @pytest.mark.parametrize("tile,mode", [(15, _abi.BWD_EXACT), (16, _abi.BWD_REFERENCE), (16, _abi.BWD_EXACT)])
