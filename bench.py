@@ -361,6 +361,23 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
             key = ("no_language_cotangent" if variant == "null" else "zero_language_cotangent") + \
                   ("_with_convergence_readback" if readback else "")
             trk[key] = round(1e3 * el / tracking_iters, 4)
+    # the tracking loss reads colour, depth and opacity only: a front end may render the SAME images with the RGB rasterizer
+    # (identical arithmetic for those channels) and skip the language accumulation altogether
+    if F > 0:
+        ws_rgb = RasterWorkspace(P, W, H, 0, M, int(1.4 * R0) + (1 << 16), dev)
+        g_rgb = {k: v for k, v in g_dev.items() if k != "language"}
+        g_rgb["language"] = None
+        pose.reset(T0)
+        loop = TrackingLoop(ws_rgb, g_rgb, sc.sh_degree, pose, gt_image, gt_depth)
+        for _ in range(5):
+            loop.iteration()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(tracking_iters):
+            loop.iteration()
+        torch.cuda.synchronize(dev)
+        trk["rgb_rasterizer_render"] = round(1e3 * (time.perf_counter() - t0) / tracking_iters, 4)
+        del ws_rgb
     out["tracking_iteration_ms"] = trk["no_language_cotangent"]
     out["tracking"] = {"ms_per_iteration": trk, "iterations": tracking_iters,
                        "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) + "

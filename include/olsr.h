@@ -228,6 +228,14 @@ typedef struct olsr_grad_bucket {
   int32_t _pad0;
 } olsr_grad_bucket;
 size_t olsr_backward_scratch_bytes(int64_t rows, int32_t F);
+/* Exact scratch rows for the backward of an olsr_forward (the synchronising entry) without a synchronisation.  The
+ * forward's last kernel posts the frame's gradient-row counts into mapped host memory; olsr_last_forward_token() names the
+ * olsr_forward this thread issued last, olsr_live_rows(token, packed) returns that frame's row count — `packed` != 0: the
+ * reference-mode backward of 15x15 tiles (one row per packed survivor wave), else one row per 64-pixel slot — or -1 while
+ * the forward has not finished or after 256 later forwards of the thread reused the slot: size the scratch by the bound
+ * (2 resp. 4 rows per instance) then.  No reference counterpart (its backward accumulates with atomics). */
+int32_t olsr_last_forward_token(void);
+int64_t olsr_live_rows(int32_t token, int32_t packed_survivor_waves);
 int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   void *geometry_buffer, int32_t num_rendered,
                   void *binning_buffer, const void *image_buffer,

@@ -205,7 +205,10 @@ _GRAD_NAMES = ("dL_dmeans2D", "dL_dcolors", "dL_dlanguage", "dL_dopacity", "dL_d
 
 def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
               projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language, dL_dout_depth, sh,
-              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, want_internal=False, cfg=None):
+              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, want_internal=False, cfg=None,
+              rows_token=0):
+    """rows_token: last_forward_token() taken right after the matching forward — lets the row scratch be sized by the
+    frame's exact gradient-row count (olsr_live_rows) instead of the bound of 2 / 4 rows per instance; 0: the bound."""
     _require_gpu(means3D, "means3D")
     ext = compiled_binding()
     if ext is not None:
@@ -214,7 +217,7 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
                          float(scale_modifier), _t(cov3D_precomp), _t(viewmatrix), _t(projmatrix), _t(projmatrix_raw),
                          float(tan_fovx), float(tan_fovy), dL_dout_color, _t(dL_dout_language), _t(dL_dout_depth), _t(sh),
                          int(degree), _t(campos), geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug),
-                         bool(want_internal), tile, bwd_mode, binning)
+                         bool(want_internal), tile, bwd_mode, binning, int(rows_token))
         out = dict(zip(_GRAD_NAMES, g))
         if not want_internal:
             del out["dL_dconic"], out["dL_ddepths"]
@@ -249,8 +252,9 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
         # survivor waves per instance in the reference mode of 15x15 tiles, else four slots).  The caching allocator
         # hands the same block back call after call, and a backward without a sync keeps the GPU fed.
         tile, bwd_mode, _binning = cfg if cfg is not None else current_config()
-        slots = 2 if (bwd_mode == _abi.BWD_REFERENCE and tile == 15) else 4
-        rows = max(int(R), 0) * slots
+        packed = bwd_mode == _abi.BWD_REFERENCE and tile == 15
+        exact = lib().olsr_live_rows(int(rows_token), 1 if packed else 0)
+        rows = exact if exact >= 0 else max(int(R), 0) * (2 if packed else 4)
         scratch = torch.empty(lib().olsr_backward_scratch_bytes(rows, F), dtype=torch.uint8, device=dev)
         check(lib().olsr_backward(
             C.byref(s), rad.data_ptr() if P else None, geomBuffer.data_ptr(), int(R), binningBuffer.data_ptr(),
@@ -268,13 +272,13 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
 def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-                                 cfg=None, with_tau_sum=False):
+                                 cfg=None, with_tau_sum=False, rows_token=0):
     """RasterizeGaussiansBackwardCUDA, DGR/rasterize_points.cu:243-331.  `cfg`: see current_config().
     with_tau_sum: append the device-reduced sum over P of dL_dtau ([6] = [rho | theta]) to the tuple — what the
     reference's Python layer computes with torch.sum (DGR/diff_gaussian_rasterization/__init__.py:383-385)."""
     g = _backward(0, bg, means3D, radii, colors, None, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                   projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, None, dL_dout_depths, sh, degree,
-                  campos, geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=cfg)
+                  campos, geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=cfg, rows_token=rows_token)
     out = (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dopacity"], g["dL_dmeans3D"], g["dL_dcov3D"], g["dL_dsh"],
            g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
     return out + (g["dL_dtau_sum"],) if with_tau_sum else out
@@ -283,16 +287,23 @@ def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, 
 def rasterize_language_gaussians_backward(bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
                                           cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy,
                                           dL_dout_color, dL_dout_language, dL_dout_depth, sh, degree, campos,
-                                          geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=None, with_tau_sum=False):
+                                          geomBuffer, R, binningBuffer, imageBuffer, debug, cfg=None, with_tau_sum=False,
+                                          rows_token=0):
     """RasterizeLanguageGaussiansBackwardCUDA, DGR/rasterize_points.cu:333-455.  `cfg`: see current_config();
     `with_tau_sum`: see rasterize_gaussians_backward."""
     g = _backward(language.shape[1], bg, means3D, radii, colors, language, scales, rotations, scale_modifier,
                   cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
                   dL_dout_language, dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                  debug, cfg=cfg)
+                  debug, cfg=cfg, rows_token=rows_token)
     out = (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dlanguage"], g["dL_dopacity"], g["dL_dmeans3D"],
            g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
     return out + (g["dL_dtau_sum"],) if with_tau_sum else out
+
+
+def last_forward_token():
+    """Names the rasterize_*gaussians call this thread made last (olsr_last_forward_token); hand it to the matching
+    backward as `rows_token`."""
+    return int(lib().olsr_last_forward_token())
 
 
 def backward_all(F, *args, **kw):

@@ -884,8 +884,18 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
 // tiles [start_x, start_x + len_x); workgroup b = 8k + x of the backward composite takes the k-th
 // heaviest tile of chunk x, so stragglers start early while neighbouring tiles still share an L2.
 // Rank sort (len <= a few thousand): rank = #tiles heavier, ties by index -> a permutation.
+__device__ __forceinline__ void post_live_rows(const u32* live_rows, int32_t* mailbox, int32_t seq) {
+  // the frame's gradient-row counts, complete since the forward composite finished, travel to the host like the instance
+  // count does: plain system-scope stores into mapped host memory, the sequence number last
+  __hip_atomic_store(&mailbox[0], (int32_t)live_rows[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&mailbox[1], (int32_t)live_rows[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
-                                                         u32* __restrict__ order_copy, int ntiles) {
+                                                         u32* __restrict__ order_copy, int ntiles,
+                                                         const u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq) {
+  if (mailbox != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) post_live_rows(live_rows, mailbox, seq);
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
   const int x = blockIdx.x;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
@@ -924,7 +934,9 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
 
 // images beyond ~120 k tiles (8K x 8K): a chunk no longer fits the LDS rank sort; keep the natural order
 __global__ __launch_bounds__(256) void tile_order_identity_kernel(u32* __restrict__ order, u32* __restrict__ order_copy,
-                                                                  int ntiles) {
+                                                                  int ntiles, const u32* __restrict__ live_rows,
+                                                                  int32_t* mailbox, int32_t seq) {
+  if (mailbox != nullptr && blockIdx.x == 0 && threadIdx.x == 0) post_live_rows(live_rows, mailbox, seq);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= ntiles) return;
   order[i] = (u32)i;
@@ -932,15 +944,16 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(u32* __restric
 }
 
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
-                       hipStream_t st) {
+                       const uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
   if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
-    tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_order, order_copy, ntiles);
+    tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_order, order_copy, ntiles, live_rows,
+                                                                     rows_mailbox, rows_seq);
     return;
   }
-  tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(tile_work, tile_order,
-                                                                                           order_copy, ntiles);
+  tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(
+      tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq);
 }
 
 }  // namespace olsr

@@ -150,7 +150,6 @@ __device__ __forceinline__ u32 preprocess_one(
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
   sort_key[idx] = 0xFFFFFFFFu;
-  sort_val[idx] = (u32)idx;
   // the emission reads the instance count from the record (one gather in depth order): zero for culled Gaussians
   emit_rec[2 * (size_t)idx + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
 

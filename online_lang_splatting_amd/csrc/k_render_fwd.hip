@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
-    u32* __restrict__ tile_work, const u32* __restrict__ order_hint) {
+    u32* __restrict__ tile_work, const u32* __restrict__ order_hint, u32* __restrict__ live_rows) {
   constexpr int BS = TILE * TILE;
   constexpr int FR = feat_row(F);
   constexpr int NA = 4 + F;  // r g b depth lang[F]
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
   // counted it as touched (<= 64), bits 8-9 = which packed survivor wave of the reference-mode backward a
   // blending pixel belongs to (15x15 tiles); each wave writes only its own 16 bits
   __shared__ uint2 s_hit[B];
-  __shared__ u32 s_work;
+  __shared__ u32 s_work, s_work2;
 
   // workgroup b runs on XCD b % 8; with a hint it takes the (b / 8)-th heaviest tile of that XCD's chunk as
   // measured on the caller's previous frame, else the (b / 8)-th tile of the chunk
@@ -112,8 +112,12 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
   const u64 cls_m0 = ballot(cls == 0), cls_m1 = ballot(cls == 1);  // wave-uniform lane masks (scalar registers)
   u64 done_m = ballot(done);  // lanes that are outside the image or saturated
   const bool lane0 = (tid & 63) == 0;
-  if (tid == 0) s_work = 0;
-  u32 my_work = 0;  // live (instance, slot) pairs flushed by this thread
+  if (tid == 0) {
+    s_work = 0;
+    s_work2 = 0;
+  }
+  u32 my_work = 0;   // live (instance, slot) pairs flushed by this thread
+  u32 my_work2 = 0;  // ... and live (instance, packed survivor wave) pairs: the reference-mode backward's rows
 #ifdef OLSR_FWD_STATS
   unsigned st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0;
 #endif
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
       const u32 cl2 = ((hit.x >> 8) | (hit.x >> 24) | (hit.y >> 8) | (hit.y >> 24)) & 3u;
       if (fl) flags[s_src[tid]] = (uint8_t)(fl | (cl2 << 4));
       my_work += (u32)__popc(fl);
+      my_work2 += (u32)__popc(cl2);
       const u32 tc = (hit.x & 0x7Fu) + ((hit.x >> 16) & 0x7Fu) + (hit.y & 0x7Fu) + ((hit.y >> 16) & 0x7Fu);
       if (tc) atomicAdd(&n_touched[s_id[tid]], (int)tc);
     }
@@ -308,13 +313,24 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
 #endif
   // backward work estimate of this tile: the number of (instance, slot) pairs it will visit
   if (tid < B) {
-    u32 wsum = my_work;
+    u32 wsum = my_work, wsum2 = my_work2;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) wsum += __shfl_xor(wsum, m);
-    if ((tid & 63) == 0 && wsum) atomicAdd(&s_work, wsum);
+    for (int m = 32; m >= 1; m >>= 1) {
+      wsum += __shfl_xor(wsum, m);
+      wsum2 += __shfl_xor(wsum2, m);
+    }
+    if ((tid & 63) == 0 && wsum) {
+      atomicAdd(&s_work, wsum);
+      atomicAdd(&s_work2, wsum2);
+    }
   }
   __syncthreads();
-  if (tid == 0) tile_work[tile_id] = s_work;
+  if (tid == 0) {
+    tile_work[tile_id] = s_work;
+    // the frame's totals (the backward's gradient-row counts): two fire-and-forget atomics per tile
+    if (s_work) atomicAdd(&live_rows[0], s_work);
+    if (s_work2) atomicAdd(&live_rows[1], s_work2);
+  }
 
   float acc[2 * NA2];
   if constexpr (MFMA) {
@@ -372,7 +388,7 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
 #define OLSR_FWD_ARGS                                                                                                  \
   im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
-      n_touched, b.flags, im.tile_work, order_inout
+      n_touched, b.flags, im.tile_work, order_inout, im.live_rows
   if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
     render_fwd_kernel<TILE, F, 1><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
   else if (s.flags & OLSR_FLAG_FWD_ACCUM_WEIGHT)
@@ -380,7 +396,8 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
   else
     render_fwd_kernel<TILE, F, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
 #undef OLSR_FWD_ARGS
-  launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, st);
+  const RowsMailbox& rm = rows_mailbox_of_this_call();
+  launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, st);
 }
 
 template <int TILE>

@@ -90,6 +90,7 @@ struct FrameHousekeeping {
   int nranges;  // 2 * tiles
   int32_t* host_mailbox;
   int32_t host_seq;
+  u32* live_rows;  // [4] zeroed here, counted by the forward composite
 };
 
 __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
       house.counters[5] = 0;
       house.counters[6] = 0;
       house.counters[7] = 0;
+      if (house.live_rows) {
+        house.live_rows[0] = 0;
+        house.live_rows[1] = 0;
+      }
       if (house.num_rendered_dev) {
         house.num_rendered_dev[0] = (int32_t)cnt;
         house.num_rendered_dev[1] = ok ? 0 : 1;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
     key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
     val[r] = (fsf & FSF_IDENTITY) ? (u32)i : (valid ? vals_in[i] : 0u);
     if (valid) atomicAdd(&cnt[w * NB + ((key[r] >> shift) & DMASK)], 1u);
-    if ((fsf & FSF_IDENTITY) && valid) flags_clear[i] = 0;
+    if ((fsf & FSF_IDENTITY) && valid && flags_clear != nullptr) flags_clear[i] = 0;
   }
   __syncthreads();
   FS_STAMP(1);
@@ -537,6 +542,7 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
     h.nranges = house->nranges;
     h.host_mailbox = house->host_mailbox;
     h.host_seq = house->host_seq;
+    h.live_rows = house->live_rows;
   }
   int64_t nb = (n_host + (int64_t)FS_T * 4 - 1) / ((int64_t)FS_T * 4);  // 4 keys (one 16-byte load) per thread ...
   if (nb < 1) nb = 1;

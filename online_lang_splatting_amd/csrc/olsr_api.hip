@@ -15,7 +15,9 @@
 #include "olsr_device.h"
 #include "olsr_kernels.h"
 
+#include <atomic>
 #include <chrono>
+#include <mutex>
 #include "olsr_state.h"
 
 using namespace olsr;
@@ -157,6 +159,22 @@ struct PinnedCount {
 };
 thread_local PinnedCount g_pinned;
 
+// The drop-in backward sizes its row scratch from the frame's exact gradient-row count without a synchronisation: the
+// forward's last kernel posts {rows (4 slots), rows (packed survivor waves), sequence} into one slot of a ring of mapped
+// host words; the matching backward — which runs after the caller's loss, long after the forward finished — looks its
+// token up (olsr_live_rows) and falls back to the bound when the slot is not there (yet, or any more).
+constexpr int ROWS_RING = 256;
+// (process-wide: PyTorch runs a backward on its autograd thread, not on the thread that called the forward)
+struct RowsRing {
+  std::atomic<int32_t*> p{nullptr};  // host view: [ROWS_RING][4]
+  int32_t* dp = nullptr;             // device view
+  std::atomic<int32_t> seq{0};
+  std::mutex init;
+};
+RowsRing g_rows;
+thread_local int32_t g_last_token = 0;  // token of the last olsr_forward of this thread (0: none)
+thread_local RowsMailbox g_rows_call;
+
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
                  int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st) {
@@ -174,6 +192,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   if (s.P <= 0) {  // nothing below runs: leave a consistent empty state behind
     HIP_TRY(hipMemsetAsync(g.counters, 0, sizeof(int32_t) * 8, st));
     HIP_TRY(hipMemsetAsync(im.ranges, 0, sizeof(uint32_t) * 2 * (size_t)d.ntiles, st));
+    HIP_TRY(hipMemsetAsync(im.live_rows, 0, sizeof(uint32_t) * 4, st));
   }
 
   const bool legacy = force_legacy_sort();
@@ -186,7 +205,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     // digit totals of the four depth passes in one read of the keys + the frame's counters (instances emitted,
     // the reference's num_rendered, overflow against the capacity), tile ranges reset to "empty"
     FusedHouse house{g.part_rect, g.part_count, (s.P + 255) / 256, sync_mode ? 0x7FFFFFFFLL : (long long)bp.capacity,
-                     g.counters, num_rendered_dev, im.ranges, 2 * d.ntiles, nullptr, 0};
+                     g.counters, num_rendered_dev, im.ranges, 2 * d.ntiles, nullptr, 0, im.live_rows};
     if (sync_mode) {
       if (!g_pinned.p) {
         HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 2 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -202,10 +221,11 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
     // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
     if (!legacy && fused_sort_applicable(s.P, 32)) {
-      launch_sort_fused(sb, sort_plan(s.P), s.P, nullptr, 32, false, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
+      // (values = Gaussian indices: the first pass takes them from the position, preprocess writes no index array)
+      launch_sort_fused(sb, sort_plan(s.P), s.P, nullptr, 32, true, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
                         g.tiles_touched, g.emit_status, st);
     } else {
-      launch_radix_sort(sb, s.P, nullptr, 32, false, st);
+      launch_radix_sort(sb, s.P, nullptr, 32, true, st);
       launch_emit_totals(g.depth_order, s.P, g.tiles_touched, g.emit_status, st);
     }
     STAGE("depth_sort");
@@ -275,8 +295,30 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       STAGE("tile_sort");
     }
   }
+  g_rows_call = RowsMailbox{};
+  if (sync_mode) {  // the drop-in entry: post the frame's gradient-row counts for the matching backward
+    if (!g_rows.p.load(std::memory_order_acquire)) {
+      std::lock_guard<std::mutex> lk(g_rows.init);
+      if (!g_rows.p.load(std::memory_order_relaxed)) {
+        int32_t* hp = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&hp, ROWS_RING * 4 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void**)&g_rows.dp, hp, 0));
+        std::memset(hp, 0, ROWS_RING * 4 * sizeof(int32_t));
+        g_rows.p.store(hp, std::memory_order_release);
+      }
+    }
+    int32_t tok = g_rows.seq.fetch_add(1) + 1;
+    if (tok <= 0 || tok >= 0x7FFFFF00) {  // (wrap: tokens stay positive)
+      g_rows.seq.store(1);
+      tok = 1;
+    }
+    g_last_token = tok;
+    g_rows_call.dev = g_rows.dp + 4 * (tok % ROWS_RING);
+    g_rows_call.seq = tok;
+  }
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
                         st);
+  g_rows_call = RowsMailbox{};
   STAGE("render_forward");
 
   if (num_rendered_dev && s.P == 0) HIP_TRY(hipMemsetAsync(num_rendered_dev, 0, 2 * sizeof(int32_t), st));
@@ -288,7 +330,22 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
 
 }  // namespace
 
+namespace olsr {
+RowsMailbox& rows_mailbox_of_this_call() { return g_rows_call; }
+}  // namespace olsr
+
 extern "C" {
+
+int32_t olsr_last_forward_token(void) { return g_last_token; }
+
+int64_t olsr_live_rows(int32_t token, int32_t packed_survivor_waves) {
+  int32_t* ring = g_rows.p.load(std::memory_order_acquire);
+  if (token <= 0 || !ring) return -1;
+  const volatile int32_t* slot = ring + 4 * (token % ROWS_RING);
+  if (__atomic_load_n(&slot[2], __ATOMIC_ACQUIRE) != token) return -1;
+  const int64_t v = (int64_t)(uint32_t)slot[packed_survivor_waves ? 1 : 0];
+  return (__atomic_load_n(&slot[2], __ATOMIC_ACQUIRE) == token) ? v : -1;  // (not overwritten meanwhile)
+}
 
 size_t olsr_geometry_bytes(int32_t P, int32_t F) {
   size_t bytes = 0;

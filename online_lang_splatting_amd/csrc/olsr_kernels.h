@@ -47,8 +47,15 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
                            uint32_t* rowbase, uint32_t* row_status, uint32_t* sync, int64_t row_capacity,
                            int32_t* counters, int32_t* status_dev, hipStream_t st);
 // backward launch order: inside each XCD's contiguous chunk of tiles, heaviest (most live pairs) first
+// rows_mailbox (may be null): device view of four host words that receive {live_rows[0], live_rows[1], rows_seq, 0} once
+// the forward composite has finished (the drop-in path sizes its backward scratch from them without a synchronisation)
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
-                       hipStream_t st);
+                       const uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st);
+struct RowsMailbox {  // set by olsr_forward for the duration of one call (thread-local in olsr_api.hip)
+  int32_t* dev = nullptr;
+  int32_t seq = 0;
+};
+RowsMailbox& rows_mailbox_of_this_call();
 // ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)
 void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32_t* n_dev, uint32_t* ranges,
                         uint8_t* flags, hipStream_t st);
@@ -65,6 +72,7 @@ struct FusedHouse {  // the frame's bookkeeping done by block 0 of the depth sor
   int nranges;
   int32_t* host_mailbox;  // (may be null) device view of two host words: receives {R, host_seq}, in this order
   int32_t host_seq;
+  uint32_t* live_rows;    // ImageState::live_rows (zeroed by the kernel)
 };
 bool fused_sort_applicable(int64_t n_host, int bits);
 int fused_sort_digit_bits(int bits, int* passes_out);

@@ -140,7 +140,7 @@ std::vector<Tensor> backward(int F, const Tensor &bg, const Tensor &means3D, con
                              const Tensor &dL_dout_language, const Tensor &dL_dout_depth, const Tensor &sh, int degree,
                              const Tensor &campos, const Tensor &geomBuffer, int R, const Tensor &binningBuffer,
                              const Tensor &imageBuffer, bool debug, bool want_internal, int tile, int bwd_mode,
-                             int binning) {
+                             int binning, int rows_token) {
   TORCH_CHECK(means3D.is_cuda(), "means3D must live on the GPU: this rasterizer has no CPU path");
   TORCH_CHECK(dL_dout_color.dim() == 3, "dL_dout_color must be [3, H, W]");
   const c10::DeviceGuard guard(means3D.device());
@@ -172,12 +172,14 @@ std::vector<Tensor> backward(int F, const Tensor &bg, const Tensor &means3D, con
   Tensor dc = prep(dL_dout_color, "dL_dout_color"), dl = prep(dL_dout_language, "dL_dout_language"),
          dd = prep(dL_dout_depth, "dL_dout_depth");
   Tensor rad = radii.contiguous();
-  // Row scratch: one partial-gradient row per live (instance, 64-pixel slot) pair.  Their number L is only known on
-  // the device; instead of a host sync for it the scratch is sized by the bound L <= slots * R (two packed survivor
-  // waves per instance in the reference mode of 15x15 tiles, else four slots).  The caching allocator hands the
-  // same block back call after call, and it reuses blocks stream-ordered, so the tensor may die at return.
-  const int64_t slots = (bwd_mode == OLSR_BWD_REFERENCE && tile == 15) ? 2 : 4;
-  const int64_t rows = static_cast<int64_t>(R > 0 ? R : 0) * slots;
+  // Row scratch: one partial-gradient row per live (instance, 64-pixel slot) pair (reference mode of 15x15 tiles: per
+  // packed survivor wave).  The caching allocator reuses blocks stream-ordered, so the tensor may die at return.
+  // The forward posted the frame's exact row count to the host (olsr_live_rows); only when that has not arrived (or its
+  // slot was reused) the bound L <= slots * R stands in.
+  const bool packed = (bwd_mode == OLSR_BWD_REFERENCE && tile == 15);
+  const int64_t slots = packed ? 2 : 4;
+  const int64_t exact = olsr_live_rows(rows_token, packed ? 1 : 0);
+  const int64_t rows = exact >= 0 ? exact : static_cast<int64_t>(R > 0 ? R : 0) * slots;
   Tensor scratch = torch::empty({static_cast<int64_t>(olsr_backward_scratch_bytes(rows, F))},
                                 means3D.options().dtype(torch::kUInt8));
   int rc;
@@ -213,5 +215,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("forward", &forward);
   m.def("backward", &backward);
   m.def("mark_visible", &mark_visible);
+  m.def("last_forward_token", []() { return static_cast<int>(olsr_last_forward_token()); });
   m.def("version", []() { return std::string(olsr_version()); });
 }

@@ -68,6 +68,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.olsr_cfg = cfg
+        ctx.olsr_rows_token = _C.last_forward_token()  # the backward sizes its row scratch from this frame's exact count
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
         ctx.set_materialize_grads(False)
@@ -83,7 +84,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          grad_rotations, _grad_tau, tau_sum) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             *_settings_args(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-            binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True)
+            binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True, rows_token=ctx.olsr_rows_token)
         grad_theta, grad_rho = _split_tau(tau_sum)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
@@ -105,6 +106,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.olsr_cfg = cfg
+        ctx.olsr_rows_token = _C.last_forward_token()  # the backward sizes its row scratch from this frame's exact count
         ctx.save_for_backward(colors_precomp, language_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
@@ -123,7 +125,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
          grad_sh, grad_scales, grad_rotations, _grad_tau, tau_sum) = _C.rasterize_language_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, language_precomp, scales, rotations, rs.scale_modifier,
             cov3Ds_precomp, *_settings_args(rs), grad_out_color, grad_out_language, grad_out_depth, sh, rs.sh_degree,
-            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True)
+            rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True, rows_token=ctx.olsr_rows_token)
         grad_theta, grad_rho = _split_tau(tau_sum)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_language_precomp, grad_opacities,
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)

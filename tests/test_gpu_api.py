@@ -654,3 +654,59 @@ def test_autograd_without_language_loss_uses_the_null_path(hip, oracle):
         for x, y in zip(a, b):
             assert x is not None and torch.equal(x, y)
         assert float(a[5].abs().max()) == 0.0 and a[5].shape == (sc.P, 15)
+
+
+def test_live_row_counts_reach_the_host_without_a_sync(hip):
+    """The drop-in forward posts the frame's gradient-row counts into mapped host memory; the matching backward — also from
+    PyTorch's autograd thread — sizes its scratch from them (olsr_live_rows) instead of the bound of 2 / 4 rows per
+    instance.  Counts equal what the backward's own row compaction finds; a token whose slot was reused says so."""
+    from online_lang_splatting_amd._lib import lib
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    dev = torch.device(DEV)
+    sc = make_scene(20000, 320, 240, 15, seed=7)
+    cam = sc.camera
+    kw = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+              rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev),
+              viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+              projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+              tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(5))
+    want = {}
+    for mode in (_abi.BWD_REFERENCE, _abi.BWD_EXACT):
+        ws = RasterWorkspace(sc.P, 320, 240, 15, sc.shs.shape[1], 600000, dev, bwd_mode=mode)
+        ws.set_scene(**kw)
+        ws.forward()
+        ws.backward(dc, dl, dd)
+        want[mode] = ws.backward_status()[0]
+    fg, gg = run_backend(hip, sc, dev, 5, 15, 0)
+    tok = hip.last_forward_token()
+    torch.cuda.synchronize()
+    L = lib()
+    assert tok > 0
+    assert L.olsr_live_rows(tok, 1) == want[_abi.BWD_REFERENCE] and L.olsr_live_rows(tok, 0) == want[_abi.BWD_EXACT]
+    assert 0 < want[_abi.BWD_REFERENCE] < want[_abi.BWD_EXACT] <= 4 * fg["R"]
+    assert L.olsr_live_rows(tok + 1, 1) == -1 and L.olsr_live_rows(0, 1) == -1
+    # the exact count suffices (a backward with it equals the backward with the bound)
+    a = hip.backward_all(15, *_bwd_args(sc, fg, dev, 5), rows_token=tok)
+    b = hip.backward_all(15, *_bwd_args(sc, fg, dev, 5))
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    # 256 forwards later the slot belongs to another frame
+    small = make_scene(50, 32, 32, 15, seed=1)
+    for _ in range(257):
+        run_fwd_only(hip, small, dev)
+    torch.cuda.synchronize()
+    assert L.olsr_live_rows(tok, 1) == -1
+
+
+def run_fwd_only(hip, sc, dev):
+    from parity_common import fwd_args
+    return hip.rasterize_language_gaussians(*fwd_args(sc, dev))
+
+
+def _bwd_args(sc, fwd, dev, seed):
+    from parity_common import fwd_args
+    a = fwd_args(sc, dev)
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(seed))
+    return [a[0], a[1], fwd["radii"], a[2], a[3], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], dc, dl, dd,
+            a[16], a[17], a[18], fwd["geom"], fwd["R"], fwd["binning"], fwd["img"], False]

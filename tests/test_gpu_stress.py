@@ -1,0 +1,28 @@
+"""A slice of the randomised oracle-vs-GPU campaign inside the suite: OLSR_STRESS_SCENES random
+scenes per generation (default 6; the campaign of scripts/oracle_stress.py ran 9 300) through the full `_check` — forward
+bit-identical in both binning modes, instance lists, every gradient.  A breach of the max-norm bound is re-judged by
+the north-star criterion per element, exactly as the campaign did (screen-filling splats amplify summation-order noise
+in the inverse of the 2D covariance)."""
+import os
+
+import pytest
+
+from stress_scenes import random_scene
+from test_gpu_parity import _check
+
+pytestmark = pytest.mark.gpu
+N = int(os.environ.get("OLSR_STRESS_SCENES", "6"))
+SEED0 = int(os.environ.get("OLSR_STRESS_SEED0", "20000"))
+
+
+@pytest.mark.parametrize("generation", ["base", "vary"])
+@pytest.mark.parametrize("k", range(N))
+def test_random_scene_against_the_oracle(hip, oracle, generation, k):
+    sc, tile, mode, kw, desc = random_scene(k, SEED0, generation)
+    try:
+        _check(hip, oracle, sc, seed=k, tile=tile, mode=mode, **kw)
+    except AssertionError as e:
+        if "not bit-identical" in str(e) or "forward" in str(e):
+            raise
+        print("max-norm breach, re-judged per element:", desc, str(e)[:160])
+        _check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2, **kw)
