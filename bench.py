@@ -148,7 +148,7 @@ def device_inputs(sc, cam, dev):
     return g, c
 
 
-def cpu_baseline(sc, seed, gpu=None, budget_s=12.0, max_frames=6, single_thread=True):
+def cpu_baseline(sc, seed, gpu=None, budget_s=12.0, max_frames=16, single_thread=True):
     """The oracle (port) on full frames of the same workload, forward+backward, all host cores: whole
     frames until about `budget_s` seconds of CPU work have been timed (at least one, at most max_frames);
     then ONE frame on one thread.  `gpu` = (forward outputs, gradient bucket rows) of the same view from the
@@ -156,7 +156,10 @@ def cpu_baseline(sc, seed, gpu=None, budget_s=12.0, max_frames=6, single_thread=
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from parity_common import rel_err, run_backend
     from oracle import oracle_C as O
-    threads = os.cpu_count() or 1
+    # the CPUs the process may really use (affinity capped by the container's quota), not every visible one: the GPU box
+    # shows 256 hardware threads and grants 16, and 256 OpenMP threads on 16 CPUs ran the frame 7x slower than 16 do
+    threads = O.usable_cpus()
+    torch.set_num_threads(threads)
     O.set_threads(threads)
     frames, R, dt = 0, 0, 0.0
     checked = None
@@ -182,7 +185,8 @@ def cpu_baseline(sc, seed, gpu=None, budget_s=12.0, max_frames=6, single_thread=
             break
     res = {"value": round(frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
            "sample": f"{frames} full frame(s) of the same workload (P={sc.P}, R={R}), forward+backward, "
-                     f"OpenMP over tiles/Gaussians on {threads} threads, {dt:.2f} s wall",
+                     f"OpenMP over tiles/Gaussians on {threads} threads ({os.cpu_count()} visible CPUs, quota {threads}), "
+                     f"{dt:.2f} s wall",
            "checked_against_gpu": checked}
     if single_thread:
         O.set_threads(1)

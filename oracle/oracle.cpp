@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1018,6 +1019,7 @@ void oracle_destroy(void* h) { delete (State*)h; }
 int oracle_forward(void* h, const olsr_scene* s, float* out_color, float* out_language, float* out_depth,
                    float* out_opacity, int32_t* radii, int32_t* n_touched, int32_t* num_rendered) {
   if (!h || !check_scene(s)) return OLSR_ERR_ARG;
+  const double t_in = omp_get_wtime();
   State& st = *(State*)h;
   const int P = s->P, W = s->width, H = s->height, F = s->F;
   st.P = P; st.F = F; st.W = W; st.H = H; st.tile = s->tile;
@@ -1045,10 +1047,17 @@ int oracle_forward(void* h, const olsr_scene* s, float* out_color, float* out_la
   st.keys.clear();
   st.point_list.clear();
   if (P != 0) {
+    const bool tm = std::getenv("ORACLE_TIMING") != nullptr;  // phase times to stderr (profiling the CPU baseline)
+    const double t0 = omp_get_wtime();
     preprocess(*s, st, radii);
     st.radii.assign(radii, radii + P);
+    const double t1 = omp_get_wtime();
     bin_and_sort(*s, st, radii);
+    const double t2 = omp_get_wtime();
     render_forward(*s, st, out_color, out_language, out_depth, out_opacity, n_touched);
+    const double t3 = omp_get_wtime();
+    if (tm) std::fprintf(stderr, "[oracle fwd] alloc+fill %.3f preprocess %.3f bin_and_sort %.3f render %.3f s (%d threads)\n",
+                         t0 - t_in, t1 - t0, t2 - t1, t3 - t2, omp_get_max_threads());
   }
   *num_rendered = st.R;
   return OLSR_OK;
@@ -1080,12 +1089,16 @@ int oracle_backward(void* h, const olsr_scene* s, const int32_t* radii, const fl
   std::fill(dL_drotations, dL_drotations + (size_t)4 * P, 0.f);
   std::fill(dL_dtau, dL_dtau + (size_t)6 * P, 0.f);
   if (P == 0) return OLSR_OK;
+  const double t0 = omp_get_wtime();
   render_backward(*s, st, s->bwd_mode, dL_dout_color, dL_dout_language, dL_dout_depth, dL_dmeans2D, dL_dconic,
                   dL_dopacity, dL_dcolors, dL_dlanguage, dL_ddepths);
+  const double t1 = omp_get_wtime();
   const float* cov3D_ptr = s->cov3D_precomp ? s->cov3D_precomp : st.cov3D.data();
   computeCov2D_backward(*s, st, radii, cov3D_ptr, dL_dconic, dL_dmeans3D, dL_dcov3D, dL_dtau);
   preprocess_backward(*s, st, radii, dL_dmeans2D, dL_dmeans3D, dL_dcolors, dL_ddepths, dL_dcov3D, dL_dsh, dL_dscales,
                       dL_drotations, dL_dtau);
+  if (std::getenv("ORACLE_TIMING"))
+    std::fprintf(stderr, "[oracle bwd] render %.3f per-Gaussian %.3f s\n", t1 - t0, omp_get_wtime() - t1);
   return OLSR_OK;
 }
 

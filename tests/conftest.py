@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # torch's and OpenMP's defaults are every visible CPU; a container with a CPU quota (the GPU box: 256 visible, 16
+    # granted) runs the CPU-side work several times slower oversubscribed
+    try:
+        import torch
+        from oracle.oracle_C import usable_cpus
+        torch.set_num_threads(usable_cpus())
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
