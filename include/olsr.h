@@ -45,7 +45,12 @@ extern "C" {
  * 15x15 tiles (CR/config.h:17-18): the 225-lane tree reduction of
  * CR/backward.cu:684-702 keeps 128 of 225 pixel ranks, language gradients come from
  * tile rank 0 only (CR/backward.cu:1137,1194-1197) and the language recursion is not
- * skip-guarded (CR/backward.cu:1127-1139).  EXACT is the true gradient. */
+ * skip-guarded (CR/backward.cu:1127-1139).  EXACT is the true gradient.
+ * Both modes are tolerance-level, not bit-level, restatements of the reference's backward: the value path is re-associated
+ * (running form of the behind-colour recursion, dot form of the language recursion, a wave-level reduction tree instead of
+ * the shared-memory tree + float atomics), so gradients agree with the reference's arithmetic to the north-star tolerance
+ * (>= 99.99 % of the elements of every tensor within 1e-4), not bit for bit; recursion-only visits are skipped while a
+ * wave's last_alpha is still zero, which presumes finite features and cotangents (0 * x == 0). */
 #define OLSR_BWD_REFERENCE 0
 #define OLSR_BWD_EXACT 1
 
