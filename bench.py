@@ -273,12 +273,16 @@ def bracket_legs(sc, g_dev, c0, cots, dev, steps, dims):
     P, W, H, F, M = dims
     dc, dl, dd = cots
     legs = {}
-    for name, cfg in (("exact_mode", (15, _abi.BWD_EXACT, _abi.BINNING_ELLIPSE)),
-                      ("tile16", (16, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE)),
-                      ("rect_binning", (15, _abi.BWD_REFERENCE, _abi.BINNING_RECT))):
+    for name, cfg, flags in (("exact_mode", (15, _abi.BWD_EXACT, _abi.BINNING_ELLIPSE), 0),
+                             ("tile16", (16, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE), 0),
+                             ("rect_binning", (15, _abi.BWD_REFERENCE, _abi.BINNING_RECT), 0),
+                             # ... and one that bounds it from above: the headline's settings with the forward's
+                             # one-fma-per-channel accumulation (images to 1e-7 of the reference's rounding)
+                             ("fwd_accum_weight", (15, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE), _abi.FLAG_FWD_ACCUM_WEIGHT)):
         tile, mode, binning = cfg
         R = _sized_capacity(F, g_dev, c0, H, W, sc.sh_degree, dev, cfg)
-        ws = RasterWorkspace(P, W, H, F, M, int(R * 1.1) + (1 << 16), dev, tile=tile, bwd_mode=mode, binning=binning)
+        ws = RasterWorkspace(P, W, H, F, M, int(R * 1.1) + (1 << 16), dev, tile=tile, bwd_mode=mode, binning=binning,
+                             flags=flags)
         bucket = GradientBucket(P, GradLayout(M, F), dev)
 
         def one():
@@ -295,7 +299,9 @@ def bracket_legs(sc, g_dev, c0, cots, dev, steps, dims):
         el = time.perf_counter() - t0
         L_rows, row_ovf = ws.backward_status()
         legs[name] = {"tile": tile, "backward_mode": "exact" if mode == _abi.BWD_EXACT else "reference",
-                      "binning": "rect" if binning == _abi.BINNING_RECT else "ellipse", "value": round(steps / el, 3),
+                      "binning": "rect" if binning == _abi.BINNING_RECT else "ellipse",
+                      "forward_accumulation": "weight" if flags & _abi.FLAG_FWD_ACCUM_WEIGHT else "valu",
+                      "value": round(steps / el, 3),
                       "unit": "frames/s", "ms_per_frame": round(1e3 * el / steps, 4), "steps": steps, "R_binned": R,
                       "live_gradient_rows": L_rows, "capacity_overflow": bool(ws.rendered()[1] or row_ovf)}
         del ws, bucket

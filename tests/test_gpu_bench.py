@@ -64,7 +64,8 @@ def test_config3_line_carries_the_config4_substitute():
     assert c4["tracking"]["pose_error_after"] < c4["tracking"]["pose_error_start"]  # it moved towards the target pose
     assert not c4["mapping"]["capacity_overflow"] and c4["mapping"]["views"] == 12
     assert c4["mapping"]["loss_last_view_final_iteration"] < c4["mapping"]["loss_last_view_first_iteration"]
-    assert set(d["bracket"]) == {"exact_mode", "tile16", "rect_binning"}
+    assert set(d["bracket"]) == {"exact_mode", "tile16", "rect_binning", "fwd_accum_weight"}
+    assert d["bracket"]["fwd_accum_weight"]["forward_accumulation"] == "weight"
     valu = d["roofline"].get("valu")
     if valu is not None:  # (present when the committed PMC summary covers the kernel)
         assert abs(valu["peak"] - 1228.8) < 0.1 and 0 < valu["frac"] < 1
