@@ -179,3 +179,24 @@ def test_sort_plan_host_logic(L, monkeypatch):
     assert plan(4096 * 16384 + 1)[0] == 0          # more than 4096 blocks even at kpt 16: the multi-kernel passes
     monkeypatch.setenv("OLSR_SORT_KPT", "4")
     assert plan(500_000)[1:] == (4, 123)
+
+
+def test_usable_cpus_respects_affinity_and_quota(monkeypatch, tmp_path):
+    """The oracle's thread pool (and bench.py's cpu_baseline `cores`) is sized by the CPUs the container may use — the
+    GPU box shows 256 hardware threads and grants 16 — not by os.cpu_count()."""
+    import builtins
+    import os
+    from oracle import oracle_C
+    n = oracle_C.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text("300000 100000\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    assert oracle_C.usable_cpus() == 3
