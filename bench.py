@@ -25,14 +25,18 @@ therefore takes the dominant kernel â€” the longest stage of the isolated leg â€
     exact tile binning, `R_binned`) / its duration, against the 8 TB/s HBM peak (the tier's convention);
   * model_reference_R: the same per-unit bytes x the reference algorithm's units (its num_rendered);
   * traffic: HBM bytes per launch by the PMC counters (profiles/*_pmc_traffic.json);
-  * valu: the compositing kernels are VALU-issue bound (bound = "valu"): wave-instructions per launch by the
-    PMC counters (profiles/*_pmc_valu.json) / duration against the chip's issue peak of one wave64 VALU
-    instruction per quad-cycle per SIMD (1024 SIMDs x 2.4 GHz / 4; the counters show SQ_ACTIVE_INST_VALU ==
-    SQ_INSTS_VALU quad-cycles for every kernel, packed instructions included).
+  * valu: the compositing kernels are bound by the VALU pipe (bound = "valu"): wave-instructions per launch by the
+    PMC counters (profiles/*_pmc_valu.json) / duration against the issue peak of the hardware guide â€” one full-rate
+    wave64 instruction per 2 cycles per SIMD-32, 1024 SIMDs x 2.4 GHz / 2 â€” with the figure the micro-benchmark
+    measured beside it (profiles/r3_valu_ubench.json: 2.3-2.7 cycles; packed fp32, selects, DPP at half rate,
+    transcendentals and permlane swaps at quarter rate) and the pipe's busy fraction by SQ_ACTIVE_INST_VALU.
 `latency_ms` holds median / p10 / p90 of the per-step completion intervals of the timed region and of the
-isolated leg's per-frame GPU time.  `cpu_baseline` is the CPU oracle (a port â€” the reference has no CPU path) on
-whole frames of the same workload with all host cores and, once, with one thread; the frame it times is checked
-against the GPU's result of the same view.
+isolated leg's per-frame GPU time.  `bracket`: one frame in flight under the settings the headline does not use
+(exact backward, 16x16 tiles, the reference's tile lists, the one-fma accumulation).  `config4_substitute`: the
+tracking and the 12-view mapping iteration (BASELINE configs[3] itself is blocked in this image).  `cpu_baseline` is
+the CPU oracle (a port â€” the reference has no CPU path) on whole frames of the same workload with the CPUs the
+container may use and, once, with one thread; the frame it times is checked against the GPU's result of the same
+view.
 """
 import argparse
 import json
