@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    try:  # no example database: the property tests must not leave a .hypothesis/ directory in the repository root
+        import hypothesis
+        hypothesis.settings.register_profile("olsr", database=None)
+        hypothesis.settings.load_profile("olsr")
+    except ImportError:
+        pass
     # torch's and OpenMP's defaults are every visible CPU; a container with a CPU quota (the GPU box: 256 visible, 16
     # granted) runs the CPU-side work several times slower oversubscribed
     try:
