@@ -1,7 +1,12 @@
 import os
 import sys
 
+import tempfile
+
 import pytest
+
+# hypothesis keeps caches (example database, unicode tables) in ./.hypothesis unless told otherwise: not in the repository
+os.environ.setdefault("HYPOTHESIS_STORAGE_DIRECTORY", os.path.join(tempfile.gettempdir(), "olsr_hypothesis"))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
