@@ -80,7 +80,7 @@ class _RasterizeGaussians16(torch.autograd.Function):
         rs = ctx.rs
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         H, W = rs.image_height, rs.image_width
-        g_color, g_depth = _cotangent(g_color, (3, H, W), means3D), _cotangent(g_depth, (1, H, W), means3D)
+        g_color = _cotangent(g_color, (3, H, W), means3D)  # (a missing depth cotangent stays None: NULL for the library)
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot, _g_tau,
          tau_sum) = _C.rasterize_gaussians_backward(
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -124,7 +124,7 @@ class _RasterizeLanguageGaussiansDisentangled(torch.autograd.Function):
         (colors_precomp, language_precomp, means3D, scales, scales_lang, rotations, rotations_lang, cov3Ds_precomp,
          cov3Ds_precomp_lang, radii1, radii2, sh, dummy_rgb, geom1, bin1, img1, geom2, bin2, img2) = ctx.saved_tensors
         H, W = rs.image_height, rs.image_width
-        g_color, g_depth = _cotangent(g_color, (3, H, W), means3D), _cotangent(g_depth, (1, H, W), means3D)
+        g_color = _cotangent(g_color, (3, H, W), means3D)  # (a missing depth cotangent stays None: NULL for the library)
         g_language = _cotangent(g_language, (language_precomp.shape[1], H, W), means3D)
         (g_means2D, g_colors, g_opac, g_means3D, g_cov3D, g_sh, g_scales, g_rot, _g_tau,
          tau_sum) = _C.rasterize_gaussians_backward(
@@ -136,7 +136,7 @@ class _RasterizeLanguageGaussiansDisentangled(torch.autograd.Function):
         (_m2, _c, g_language_precomp, g_opac_lang, _m3, g_cov3D_lang, _sh, g_scales_lang, g_rot_lang,
          _tau) = _C.rasterize_language_gaussians_backward(
             rs.bg, means3D, radii2, dummy_rgb, language_precomp, scales_lang, rotations_lang, rs.scale_modifier,
-            cov3Ds_precomp_lang, *_settings_args(rs), torch.zeros_like(g_color), g_language, torch.zeros_like(g_depth),
+            cov3Ds_precomp_lang, *_settings_args(rs), torch.zeros_like(g_color), g_language, None,
             None, 0, rs.campos, geom2, ctx.R2, bin2, img2, rs.debug, cfg=ctx.cfg)
         g_theta, g_rho = _split_tau(tau_sum)
         return (g_means3D, g_means2D, g_sh, g_colors, g_language_precomp, g_opac, g_opac_lang, g_scales, g_scales_lang,
