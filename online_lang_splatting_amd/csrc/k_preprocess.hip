@@ -150,8 +150,8 @@ __device__ __forceinline__ u32 preprocess_one(
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
   sort_key[idx] = 0xFFFFFFFFu;
-  // the emission reads the instance count from the record (one gather in depth order): zero for culled Gaussians
-  emit_rec[2 * (size_t)idx + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (the emission record of a Gaussian without instances is never read — the emission goes by tiles_touched — so culled
+  //  Gaussians leave theirs untouched)
 
   // in_frustum, CR/auxiliary.h:139-164
   const f3 p_orig = {orig_points[3 * (size_t)idx], orig_points[3 * (size_t)idx + 1], orig_points[3 * (size_t)idx + 2]};

@@ -222,7 +222,7 @@ void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_laun
 // ---- one pass ---------------------------------------------------------------------------------------------
 // FLAGS (runtime, uniform): bit 0 = values are the identity (first tile-sort pass; also clears flags_clear[i]),
 // bit 1 = do not write the sorted keys (last pass of a sort), bit 2 = derive tile ranges (last tile-sort pass).
-// bit 3 = last depth pass: add every Gaussian's instance count (emit_rec[2 g + 1].w) to the total of the emission block
+// bit 3 = last depth pass: add every Gaussian's instance count (inst_count[g] = tiles_touched) to the total of the emission block
 // its final depth rank falls in (emit_totals[rank / EMIT_CHUNK]), so the emission needs no scan of its own.
 constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4, FSF_EMIT_TOTALS = 8;
 
