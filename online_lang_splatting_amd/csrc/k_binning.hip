@@ -884,26 +884,56 @@ void launch_tile_ranges(const uint32_t* sorted_keys, int64_t n_host, const int32
 // tiles [start_x, start_x + len_x); workgroup b = 8k + x of the backward composite takes the k-th
 // heaviest tile of chunk x, so stragglers start early while neighbouring tiles still share an L2.
 // Rank sort (len <= a few thousand): rank = #tiles heavier, ties by index -> a permutation.
-__device__ __forceinline__ void post_live_rows(const u32* live_rows, int32_t* mailbox, int32_t seq) {
-  // the frame's gradient-row counts, complete since the forward composite finished, travel to the host like the instance
-  // count does: plain system-scope stores into mapped host memory, the sequence number last
-  __hip_atomic_store(&mailbox[0], (int32_t)live_rows[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(&mailbox[1], (int32_t)live_rows[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// The frame's gradient-row counts = the sums of the two tile_work planes.  Every participating block adds its share
+// (a, b: this thread's partial sums) to live_rows[0..1]; the block that finishes last sends the totals to the host like
+// the instance count travels: plain system-scope stores into mapped host memory, the sequence number last.
+__device__ __forceinline__ void sum_and_post_live_rows(u32 a, u32 b, u32 nblocks, u32* live_rows, int32_t* mailbox,
+                                                       int32_t seq) {
+  __shared__ u32 s_sum[2];
+  if (threadIdx.x == 0) s_sum[0] = s_sum[1] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    a += __shfl_xor(a, m);
+    b += __shfl_xor(b, m);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (a) atomicAdd(&s_sum[0], a);
+    if (b) atomicAdd(&s_sum[1], b);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (s_sum[0]) atomicAdd(&live_rows[0], s_sum[0]);
+  if (s_sum[1]) atomicAdd(&live_rows[1], s_sum[1]);
+  __threadfence();
+  if (atomicAdd(&live_rows[3], 1u) != nblocks - 1) return;
+  __threadfence();
+  const u32 t0 = __hip_atomic_load(&live_rows[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u32 t1 = __hip_atomic_load(&live_rows[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&mailbox[0], (int32_t)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&mailbox[1], (int32_t)t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
                                                          u32* __restrict__ order_copy, int ntiles,
-                                                         const u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq) {
-  if (mailbox != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) post_live_rows(live_rows, mailbox, seq);
+                                                         u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq) {
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
   const int x = blockIdx.x;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   const int len = q + (x < r ? 1 : 0);
-  if (len == 0) return;  // (fewer than 8 tiles: this XCD's chunk is empty)
   const int len64 = (len + 63) & ~63;
-  for (int j = threadIdx.x; j < len64; j += blockDim.x) s_work[j] = (j < len) ? work[start + j] : 0u;
+  u32 sum0 = 0, sum1 = 0;
+  const bool summing = mailbox != nullptr && blockIdx.y == 0;  // the first block of each chunk also sums its two planes
+  for (int j = threadIdx.x; j < len64; j += blockDim.x) {
+    const u32 w = (j < len) ? work[start + j] : 0u;
+    s_work[j] = w;
+    sum0 += w;
+    if (summing && j < len) sum1 += work[ntiles + start + j];
+  }
+  if (summing) sum_and_post_live_rows(sum0, sum1, gridDim.x, live_rows, mailbox, seq);  // (block-uniform; syncs inside)
+  if (len == 0) return;  // (fewer than 8 tiles: this XCD's chunk is empty)
   __syncthreads();
   // 16 tiles per block, 16 lanes per tile: lane s of a tile's row compares against the entries j = 4 s + 64 k ..
   // (one 16-byte LDS read each), the 16 partial ranks are summed inside the row with DPP rotations.  The zero padding
@@ -933,22 +963,25 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
 }
 
 // images beyond ~120 k tiles (8K x 8K): a chunk no longer fits the LDS rank sort; keep the natural order
-__global__ __launch_bounds__(256) void tile_order_identity_kernel(u32* __restrict__ order, u32* __restrict__ order_copy,
-                                                                  int ntiles, const u32* __restrict__ live_rows,
-                                                                  int32_t* mailbox, int32_t seq) {
-  if (mailbox != nullptr && blockIdx.x == 0 && threadIdx.x == 0) post_live_rows(live_rows, mailbox, seq);
+__global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __restrict__ work, u32* __restrict__ order,
+                                                                  u32* __restrict__ order_copy, int ntiles,
+                                                                  u32* __restrict__ live_rows, int32_t* mailbox,
+                                                                  int32_t seq) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= ntiles) return;
-  order[i] = (u32)i;
-  if (order_copy != nullptr) order_copy[i] = (u32)i;
+  if (i < ntiles) {
+    order[i] = (u32)i;
+    if (order_copy != nullptr) order_copy[i] = (u32)i;
+  }
+  if (mailbox != nullptr)
+    sum_and_post_live_rows(i < ntiles ? work[i] : 0u, i < ntiles ? work[ntiles + i] : 0u, gridDim.x, live_rows, mailbox, seq);
 }
 
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
-                       const uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st) {
+                       uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
   if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
-    tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_order, order_copy, ntiles, live_rows,
+    tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_work, tile_order, order_copy, ntiles, live_rows,
                                                                      rows_mailbox, rows_seq);
     return;
   }

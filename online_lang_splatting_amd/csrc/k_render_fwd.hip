@@ -33,6 +33,9 @@
 namespace olsr {
 
 constexpr int FWD_BATCH = 128;
+#ifndef OLSR_FWD_ACC2_WAVES
+#define OLSR_FWD_ACC2_WAVES 7  // waves per SIMD the weight-accumulation variant is compiled for
+#endif
 
 #ifdef OLSR_FWD_STATS
 // experiment build only (scripts/build_variant.sh ... -DOLSR_FWD_STATS): how many (entry, wave) pairs the loop looks at,
@@ -54,14 +57,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //      1 = matrix cores (OLSR_FLAG_FWD_ACCUM_MFMA); 2 = w = alpha T once per pixel, then ONE fma(w, f, C) per channel on
 //      the vector ALU (OLSR_FLAG_FWD_ACCUM_WEIGHT: half the lane operations of the accumulation, the MFMA variant's rounding)
 template <int TILE, int F, int ACC>
-__global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
+__global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FWD_ACC2_WAVES : 7)) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
-    u32* __restrict__ tile_work, const u32* __restrict__ order_hint, u32* __restrict__ live_rows) {
+    u32* __restrict__ tile_work, const u32* __restrict__ order_hint) {
   constexpr int BS = TILE * TILE;
   constexpr int FR = feat_row(F);
   constexpr int NA = 4 + F;  // r g b depth lang[F]
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
     s_work = 0;
     s_work2 = 0;
   }
-  u32 my_work = 0;   // live (instance, slot) pairs flushed by this thread
-  u32 my_work2 = 0;  // ... and live (instance, packed survivor wave) pairs: the reference-mode backward's rows
+  // (the tile's live-pair counts are summed per flush with wave ballots straight into LDS: a per-thread counter kept across
+  //  the loop cost a register the accumulation variants do not have)
 #ifdef OLSR_FWD_STATS
   unsigned st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0;
 #endif
@@ -288,16 +291,25 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
       if (MFMA && gfill != 0) mfma_flush();
     }
     __syncthreads();
-    if (tid < cnt) {
-      const uint2 hit = s_hit[tid];
-      // bits 0-3: forward slots that blended it; bits 4-5: backward waves of the reference-mode survivors
-      const u32 fl = ((hit.x >> 15) & 1u) | ((hit.x >> 30) & 2u) | ((hit.y >> 13) & 4u) | ((hit.y >> 28) & 8u);
-      const u32 cl2 = ((hit.x >> 8) | (hit.x >> 24) | (hit.y >> 8) | (hit.y >> 24)) & 3u;
-      if (fl) flags[s_src[tid]] = (uint8_t)(fl | (cl2 << 4));
-      my_work += (u32)__popc(fl);
-      my_work2 += (u32)__popc(cl2);
-      const u32 tc = (hit.x & 0x7Fu) + ((hit.x >> 16) & 0x7Fu) + (hit.y & 0x7Fu) + ((hit.y >> 16) & 0x7Fu);
-      if (tc) atomicAdd(&n_touched[s_id[tid]], (int)tc);
+    if (tid < B) {  // (waves 0 and 1, whole: the ballots below need every lane)
+      u32 fl = 0, cl2 = 0;
+      if (tid < cnt) {
+        const uint2 hit = s_hit[tid];
+        // bits 0-3: forward slots that blended it; bits 4-5: backward waves of the reference-mode survivors
+        fl = ((hit.x >> 15) & 1u) | ((hit.x >> 30) & 2u) | ((hit.y >> 13) & 4u) | ((hit.y >> 28) & 8u);
+        cl2 = ((hit.x >> 8) | (hit.x >> 24) | (hit.y >> 8) | (hit.y >> 24)) & 3u;
+        if (fl) flags[s_src[tid]] = (uint8_t)(fl | (cl2 << 4));
+        const u32 tc = (hit.x & 0x7Fu) + ((hit.x >> 16) & 0x7Fu) + (hit.y & 0x7Fu) + ((hit.y >> 16) & 0x7Fu);
+        if (tc) atomicAdd(&n_touched[s_id[tid]], (int)tc);
+      }
+      // live (instance, slot) pairs and live (instance, packed survivor wave) pairs of this flush: six ballots per wave
+      const u32 c1 = (u32)(__popcll(ballot(fl & 1u)) + __popcll(ballot(fl & 2u)) + __popcll(ballot(fl & 4u)) +
+                           __popcll(ballot(fl & 8u)));
+      const u32 c2 = (u32)(__popcll(ballot(cl2 & 1u)) + __popcll(ballot(cl2 & 2u)));
+      if (lane0 && c1) {
+        atomicAdd(&s_work, c1);
+        atomicAdd(&s_work2, c2);
+      }
     }
   }
 
@@ -312,24 +324,12 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : 7) : (ACC == 1 ? 4 
   }
 #endif
   // backward work estimate of this tile: the number of (instance, slot) pairs it will visit
-  if (tid < B) {
-    u32 wsum = my_work, wsum2 = my_work2;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      wsum += __shfl_xor(wsum, m);
-      wsum2 += __shfl_xor(wsum2, m);
-    }
-    if ((tid & 63) == 0 && wsum) {
-      atomicAdd(&s_work, wsum);
-      atomicAdd(&s_work2, wsum2);
-    }
-  }
   __syncthreads();
   if (tid == 0) {
+    // (the frame's totals are summed by the tile-order kernel: thousands of same-address atomics from here held the
+    //  kernel's tail back by up to 13 us)
     tile_work[tile_id] = s_work;
-    // the frame's totals (the backward's gradient-row counts): two fire-and-forget atomics per tile
-    if (s_work) atomicAdd(&live_rows[0], s_work);
-    if (s_work2) atomicAdd(&live_rows[1], s_work2);
+    tile_work[ntiles + tile_id] = s_work2;
   }
 
   float acc[2 * NA2];
@@ -388,7 +388,7 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
 #define OLSR_FWD_ARGS                                                                                                  \
   im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
-      n_touched, b.flags, im.tile_work, order_inout, im.live_rows
+      n_touched, b.flags, im.tile_work, order_inout
   if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
     render_fwd_kernel<TILE, F, 1><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
   else if (s.flags & OLSR_FLAG_FWD_ACCUM_WEIGHT)

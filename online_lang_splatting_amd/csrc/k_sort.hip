@@ -90,7 +90,7 @@ struct FrameHousekeeping {
   int nranges;  // 2 * tiles
   int32_t* host_mailbox;
   int32_t host_seq;
-  u32* live_rows;  // [4] zeroed here, counted by the forward composite
+  u32* live_rows;  // [4] zeroed here, summed by the tile-order kernel
 };
 
 __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
       if (house.live_rows) {
         house.live_rows[0] = 0;
         house.live_rows[1] = 0;
+        house.live_rows[3] = 0;
       }
       if (house.num_rendered_dev) {
         house.num_rendered_dev[0] = (int32_t)cnt;

@@ -47,10 +47,11 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
                            uint32_t* rowbase, uint32_t* row_status, uint32_t* sync, int64_t row_capacity,
                            int32_t* counters, int32_t* status_dev, hipStream_t st);
 // backward launch order: inside each XCD's contiguous chunk of tiles, heaviest (most live pairs) first
-// rows_mailbox (may be null): device view of four host words that receive {live_rows[0], live_rows[1], rows_seq, 0} once
-// the forward composite has finished (the drop-in path sizes its backward scratch from them without a synchronisation)
+// tile_work: [2][ntiles] (ImageState).  rows_mailbox (may be null): device view of four host words that receive {sum of
+// tile_work[0], sum of tile_work[1], rows_seq, 0} (the drop-in path sizes its backward scratch from them without a
+// synchronisation); live_rows: ImageState::live_rows, zero on entry, the staging of those sums
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
-                       const uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st);
+                       uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st);
 struct RowsMailbox {  // set by olsr_forward for the duration of one call (thread-local in olsr_api.hip)
   int32_t* dev = nullptr;
   int32_t seq = 0;

@@ -186,17 +186,19 @@ struct ImageState {
   float* final_T;       // [H*W]
   uint32_t* n_contrib;  // [H*W]
   uint32_t* ranges;     // [tiles][2]
-  uint32_t* tile_work;  // [tiles] live (instance, slot) pairs of the tile (written by the forward composite)
+  uint32_t* tile_work;  // [2][tiles] live (instance, slot) pairs, then live (instance, packed survivor wave) pairs of the
+                        //     tile (written by the forward composite)
   uint32_t* tile_order; // [tiles] backward launch order: per XCD chunk, heaviest tile first
-  uint32_t* live_rows;  // [4] {live (instance, slot) pairs, live (instance, packed survivor wave) pairs} of the frame: the
-                        //     backward's gradient-row count in its two row layouts, summed by the forward composite
+  uint32_t* live_rows;  // [4] {live (instance, slot) pairs, live (instance, packed survivor wave) pairs, -, blocks done} of
+                        //     the frame: the backward's gradient-row count in its two row layouts, summed from tile_work
+                        //     by the tile-order kernel when a host mailbox wants them
   static ImageState carve(void* buf, size_t N, size_t tiles, size_t& bytes) {
     Carver c(buf);
     ImageState s;
     s.final_T = c.take<float>(N);
     s.n_contrib = c.take<uint32_t>(N);
     s.ranges = c.take<uint32_t>(2 * tiles);
-    s.tile_work = c.take<uint32_t>(tiles);
+    s.tile_work = c.take<uint32_t>(2 * tiles);
     s.tile_order = c.take<uint32_t>(tiles);
     s.live_rows = c.take<uint32_t>(4);
     bytes = c.total();
