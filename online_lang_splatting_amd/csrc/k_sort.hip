@@ -413,6 +413,9 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
       const u32 dg = (kk >> shift) & DMASK;
       const u32 ds = dstart[dg];
       const u32 pos = gbase[dg] + (slot - ds);
+      // (always true for a healthy state buffer; if the look-back above ran into its spin bound — a state buffer
+      //  corrupted from outside mid-frame — the counts are garbage and nothing may be written out of bounds)
+      if ((int64_t)pos >= n) continue;
       if (!(fsf & FSF_NO_KEYS)) keys_out[pos] = kk;
       const u32 vv = ex_val[slot];
       vals_out[pos] = vv;
