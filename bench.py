@@ -428,12 +428,14 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
     t0 = time.perf_counter()
     for _ in range(mapping_iters):
         step.iteration()
+    issue = time.perf_counter() - t0  # host time to enqueue the iterations (the GPU is still working)
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     ovf = any(ws_.rendered()[1] or ws_.backward_status()[1] for ws_, _, _ in lanes.lanes)
     out["mapping_iteration_ms"] = round(1e3 * el / mapping_iters, 3)
     out["mapping"] = {"views": views, "views_in_flight": len(lanes), "iterations": mapping_iters,
                       "views_per_s": round(views * mapping_iters / el, 1),
+                      "host_enqueue_ms_per_iteration": round(1e3 * issue / mapping_iters, 3),
                       "what": f"{views} arc views x (render from raw parameters + olsr_mapping_loss incl. the 192x192 language "
                               "target + backward into the gradient bucket) + fused Adam step",
                       "loss_last_view_first_iteration": round(first_loss, 6),

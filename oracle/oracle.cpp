@@ -1102,6 +1102,34 @@ int oracle_backward(void* h, const olsr_scene* s, const int32_t* radii, const fl
   return OLSR_OK;
 }
 
+// The per-Gaussian half of the backward alone (CR/rasterizer_impl.cu:702-756: computeCov2DCUDA, then
+// language_preprocessCUDA / preprocessCUDA), fed with composite-level gradients the CALLER provides instead of the ones
+// oracle_backward's own composite produced.  Test infrastructure for one question: with identical inputs, does the
+// product's fused per-Gaussian kernel agree with the reference's chain?  (Fed with the product's own composite-level
+// gradients it separates the chain's arithmetic from the chain's sensitivity to its inputs.)
+int oracle_backward_chain(void* h, const olsr_scene* s, const int32_t* radii, const float* dL_dmeans2D_in,
+                          const float* dL_dconic_in, const float* dL_dcolors_in, const float* dL_ddepths_in,
+                          float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations,
+                          float* dL_dtau) {
+  if (!h || !check_scene(s) || !s->projmatrix_raw) return OLSR_ERR_ARG;
+  State& st = *(State*)h;
+  const int P = s->P, M = s->M;
+  if (st.P != P || st.F != s->F || st.W != s->width || st.H != s->height) return OLSR_ERR_ARG;
+  std::fill(dL_dmeans3D, dL_dmeans3D + (size_t)3 * P, 0.f);
+  std::fill(dL_dcov3D, dL_dcov3D + (size_t)6 * P, 0.f);
+  if (M > 0) std::fill(dL_dsh, dL_dsh + (size_t)3 * M * P, 0.f);
+  std::fill(dL_dscales, dL_dscales + (size_t)3 * P, 0.f);
+  std::fill(dL_drotations, dL_drotations + (size_t)4 * P, 0.f);
+  std::fill(dL_dtau, dL_dtau + (size_t)6 * P, 0.f);
+  if (P == 0) return OLSR_OK;
+  std::vector<float> colors(dL_dcolors_in, dL_dcolors_in + (size_t)3 * P);  // (the chain may write into it)
+  const float* cov3D_ptr = s->cov3D_precomp ? s->cov3D_precomp : st.cov3D.data();
+  computeCov2D_backward(*s, st, radii, cov3D_ptr, dL_dconic_in, dL_dmeans3D, dL_dcov3D, dL_dtau);
+  preprocess_backward(*s, st, radii, dL_dmeans2D_in, dL_dmeans3D, colors.data(), dL_ddepths_in, dL_dcov3D, dL_dsh,
+                      dL_dscales, dL_drotations, dL_dtau);
+  return OLSR_OK;
+}
+
 // DGR/rasterize_points.cu:457-476 + CR/rasterizer_impl.cu:54-66
 int oracle_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                         uint8_t* present) {

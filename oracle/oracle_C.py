@@ -69,6 +69,8 @@ def lib():
         L.oracle_forward.restype = C.c_int
         L.oracle_backward.argtypes = [vp, C.POINTER(_abi.OlsrScene)] + [vp] * 16
         L.oracle_backward.restype = C.c_int
+        L.oracle_backward_chain.argtypes = [vp, C.POINTER(_abi.OlsrScene)] + [vp] * 11
+        L.oracle_backward_chain.restype = C.c_int
         L.oracle_mark_visible.argtypes = [C.c_int32, vp, vp, vp, vp]
         L.oracle_mark_visible.restype = C.c_int
         L.oracle_get_field.argtypes = [vp, C.c_char_p, vp]
@@ -225,7 +227,9 @@ def rasterize_language_gaussians(bg, means3D, colors, language, opacity, scales,
 
 def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
               projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_language, dL_dout_depth, sh,
-              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, keep_internal=False):
+              degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, keep_internal=False, composite=None):
+    """composite: dict with dL_dmeans2D [P,3], dL_dconic [P,2,2], dL_dcolors [P,3], dL_ddepths [P,1] — run only the
+    per-Gaussian chain (oracle_backward_chain) on THESE composite-level gradients and return its six outputs."""
     P = means3D.shape[0]
     H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
     st = state_of(geomBuffer)
@@ -245,6 +249,17 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
     dl = dL_dout_language.contiguous().float() if F > 0 else torch.zeros(1)
     dd = dL_dout_depth.contiguous().float()
     rad = radii.contiguous().to(torch.int32)
+    if composite is not None:
+        cin = {k: composite[k].detach().cpu().contiguous().float() for k in
+               ("dL_dmeans2D", "dL_dconic", "dL_dcolors", "dL_ddepths")}
+        assert cin["dL_dmeans2D"].numel() == 3 * P and cin["dL_dconic"].numel() == 4 * P
+        assert cin["dL_dcolors"].numel() == 3 * P and cin["dL_ddepths"].numel() == P
+        _check(lib().oracle_backward_chain(
+            st.h, C.byref(s), rad.data_ptr(), cin["dL_dmeans2D"].data_ptr(), cin["dL_dconic"].data_ptr(),
+            cin["dL_dcolors"].data_ptr(), cin["dL_ddepths"].data_ptr(), g["dL_dmeans3D"].data_ptr(),
+            g["dL_dcov3D"].data_ptr(), g["dL_dsh"].data_ptr(), g["dL_dscales"].data_ptr(),
+            g["dL_drotations"].data_ptr(), g["dL_dtau"].data_ptr()), "backward_chain")
+        return {k: g[k] for k in CHAIN_KEYS}
     _check(lib().oracle_backward(
         st.h, C.byref(s), rad.data_ptr(), dc.data_ptr(), dl.data_ptr(), dd.data_ptr(),
         g["dL_dmeans2D"].data_ptr(), g["dL_dconic"].data_ptr(), g["dL_dopacity"].data_ptr(),
@@ -277,6 +292,14 @@ def rasterize_language_gaussians_backward(bg, means3D, radii, colors, language, 
                   dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug)
     return (g["dL_dmeans2D"], g["dL_dcolors"], g["dL_dlanguage"], g["dL_dopacity"], g["dL_dmeans3D"],
             g["dL_dcov3D"], g["dL_dsh"], g["dL_dscales"], g["dL_drotations"], g["dL_dtau"])
+
+
+CHAIN_KEYS = ("dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dtau")
+
+
+def backward_chain(F, composite, *args, **kw):
+    """The per-Gaussian chain alone on caller-provided composite-level gradients; args as backward_all."""
+    return _backward(F, *args, composite=composite, **kw)
 
 
 def backward_all(F, *args, **kw):

@@ -66,13 +66,12 @@ def run_backend(C, sc, dev=None, seed=0, tile=15, mode=0, binning=1, **kw):
     if F > 0:
         b.append(mv(dl))
     b += [mv(dd), a[15 + off], a[16 + off], a[17 + off], geom, R, binb, img, False]
-    if F > 0:
-        grads = C.backward_all(F, *b)
-    else:
-        b2 = list(b)
-        b2.insert(4, None)   # language slot
-        b2.insert(15, None)  # dL_dout_language slot
-        grads = C.backward_all(0, *b2)
+    if F <= 0:
+        b = list(b)
+        b.insert(4, None)   # language slot
+        b.insert(15, None)  # dL_dout_language slot
+    grads = C.backward_all(max(F, 0), *b)
+    fwd["bwd_args"] = b  # (oracle_C.backward_chain replays the per-Gaussian half on other composite-level gradients)
     return fwd, grads
 
 
@@ -113,15 +112,18 @@ def elementwise_report(a, b, rtol=ELEM_RTOL, atol_rel=ELEM_ATOL_REL):
                 worst_abs=diff.max().item(), max_ref=scale)
 
 
-def assert_elementwise(a, b, name, worst_bound, log=None, min_fraction=ELEM_MIN_FRACTION):
+def assert_elementwise(a, b, name, worst_bound, log=None, min_fraction=ELEM_MIN_FRACTION, allow_outliers=0):
     """Asserts the element-wise criterion and a bound on the worst element (in relative units, see
-    elementwise_report); prints both (pytest -s / the failure message) and appends them to `log`."""
+    elementwise_report); prints both (pytest -s / the failure message) and appends them to `log`.
+    allow_outliers: that many elements may sit outside the band whatever the fraction says (tensors of fewer than 10^4
+    elements, where 99.99 % means "none"); the worst-element bound applies to them all the same."""
     r = elementwise_report(a, b)
     line = (f"{name:24s} n={r['n']:>9d} within={100.0 * r['frac_within']:.5f}% worst_rel={r['worst']:.3e} "
             f"worst_abs={r['worst_abs']:.3e} max|ref|={r['max_ref']:.3e}")
     print(line)
     if log is not None:
         log.append(dict(name=name, **r))
-    assert r["frac_within"] >= min_fraction, "element-wise criterion: " + line
+    n_out = int(round((1.0 - r["frac_within"]) * r["n"]))
+    assert r["frac_within"] >= min_fraction or n_out <= allow_outliers, "element-wise criterion: " + line
     assert r["worst"] <= worst_bound, f"worst element above {worst_bound:g}: " + line
     return r

@@ -699,6 +699,36 @@ def test_live_row_counts_reach_the_host_without_a_sync(hip):
     assert L.olsr_live_rows(tok, 1) == -1
 
 
+@pytest.mark.parametrize("wh", [(10, 10), (20, 20), (40, 31), (130, 100)])
+def test_live_row_counts_with_few_tiles(hip, wh):
+    """The counts are summed by the first block of each of the eight tile chunks; images with 1, 4, 9 and 63 tiles leave
+    chunks empty or one tile long."""
+    from online_lang_splatting_amd._lib import lib
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    dev = torch.device(DEV)
+    W, H = wh
+    sc = make_scene(300, W, H, 15, seed=11)
+    cam = sc.camera
+    kw = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+              rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev),
+              viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+              projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+              tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+    dc, dl, dd = (t.to(dev) for t in sc.cotangents(5))
+    want = {}
+    for mode in (_abi.BWD_REFERENCE, _abi.BWD_EXACT):
+        ws = RasterWorkspace(sc.P, W, H, 15, sc.shs.shape[1], 100000, dev, bwd_mode=mode)
+        ws.set_scene(**kw)
+        ws.forward()
+        ws.backward(dc, dl, dd)
+        want[mode] = ws.backward_status()[0]
+    run_fwd_only(hip, sc, dev)
+    tok = hip.last_forward_token()
+    torch.cuda.synchronize()
+    assert lib().olsr_live_rows(tok, 1) == want[_abi.BWD_REFERENCE] > 0
+    assert lib().olsr_live_rows(tok, 0) == want[_abi.BWD_EXACT] >= want[_abi.BWD_REFERENCE]
+
+
 def run_fwd_only(hip, sc, dev):
     from parity_common import fwd_args
     return hip.rasterize_language_gaussians(*fwd_args(sc, dev))

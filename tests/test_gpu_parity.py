@@ -14,7 +14,7 @@ import torch
 
 from online_lang_splatting_amd import _abi
 from online_lang_splatting_amd.scene import default_camera, make_scene
-from parity_common import assert_elementwise, fwd_args, rel_err, run_backend
+from parity_common import ELEM_MIN_FRACTION, assert_elementwise, fwd_args, rel_err, run_backend
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
@@ -42,15 +42,25 @@ def _tile_pairs(hip, f, sc, tile):
 COMPOSITE_GRADS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dlanguage", "dL_ddepths")
 
 
+COMPOSITE_KEYS = COMPOSITE_GRADS
+
+
 def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise=False, worst_bound=1e-2, log=None,
-           **kw):
+           chain=True, chain_worst_bound=3e-4, chain_min_fraction=ELEM_MIN_FRACTION, **kw):
     """Oracle vs the HIP library in both binning modes.
     RECT: images, counters AND the instance lists equal the reference's bit for bit.
     ELLIPSE (the product's default): identical images / radii / n_touched / final_T, gradients to RTOL,
     and every tile list is the RECT list minus instances that blend nothing, in the same order.
     elementwise: additionally assert, per gradient tensor, the north-star criterion per ELEMENT (>= 99.99 % of the
     elements within 1e-4 relative + 1e-6 of the tensor's largest magnitude, and the worst element within
-    `worst_bound`, both printed) instead of only the max-norm."""
+    `worst_bound`, both printed) instead of only the max-norm.
+    chain (on by default, every scene of the suite): additionally replay the reference's per-Gaussian chain (computeCov2DCUDA + preprocessCUDA backward) in the
+    oracle on the PRODUCT's composite-level gradients and hold the product's per-Gaussian outputs to it per element:
+    same inputs on both sides, so what is compared is the chain's arithmetic and not its sensitivity to summation-order
+    noise in dL_dconic / dL_dmean2D (which the reference's own float atomics have from run to run).  Criterion: the
+    north-star one per element (two elements may leave the band in tensors too small for 99.99 % to allow any), worst
+    element within chain_worst_bound = 3e-4 (the 1 500-scene campaign of round 3: every element of every tensor within
+    1e-4, worst 8e-5; the suite's own scenes: one element of 9 308 at 1.5e-4)."""
     fo, go = run_backend(oracle, sc, None, seed, tile, mode, **kw)
     fr, gr = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, binning=_abi.BINNING_RECT, **kw)
     fg, gg = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, binning=_abi.BINNING_ELLIPSE, **kw)
@@ -79,6 +89,13 @@ def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise
                 else:
                     r, e = rel_err(g_[k], go[k])
                     assert r <= RTOL, f"{name}: {k}: rel {r:.2e} abs {e:.2e}"
+        if chain and P:
+            gc = oracle.backward_chain(max(F, 0), {k: g_[k] for k in ("dL_dmeans2D", "dL_dconic", "dL_dcolors",
+                                                                      "dL_ddepths")}, *fo["bwd_args"])
+            for k in oracle.CHAIN_KEYS:
+                if gc[k].numel():
+                    assert_elementwise(g_[k], gc[k], f"{name}:chain:{k}", chain_worst_bound, log, allow_outliers=2,
+                                       min_fraction=chain_min_fraction)
         if P and grad_keys is None:
             tau_sum = go["dL_dtau"].double().sum(0).float()
             # six sums over all P Gaussians (millions of cancelling terms at the full configs): held to 1e-4 of the
@@ -185,11 +202,14 @@ def test_needles_and_faint_splats_exact_binning(hip, oracle):
     For the needles only the composite's own gradients are compared: behind them the backward of the 2D
     covariance inverse (CR/backward.cu:213-236) cancels terms of order 1e8 down to order 1e3, which turns
     the 1e-7 summation-order noise of ANY implementation (the reference's float atomics included) into
-    errors of tens of percent in dL_dmeans3D / dL_dscales — there is no reproducible value to match."""
+    errors of tens of percent in dL_dmeans3D / dL_dscales — there is no reproducible value to match.
+    What CAN be matched is the chain on identical inputs (chain=True): even at 1000:1 two fp32 evaluation orders of it
+    agree in 99.9 % of the elements to 1e-4, the worst one to 1.4e-3 (bounds below: 99.5 % / 2e-2)."""
+    needle = dict(grad_keys=COMPOSITE_GRADS, chain_worst_bound=2e-2, chain_min_fraction=0.995)
     sc = make_scene(4000, 240, 165, 15, seed=64)
     sc.scales[:, 0] *= 25.0
     sc.scales[:, 1] *= 0.04
-    _check(hip, oracle, sc, seed=10, grad_keys=COMPOSITE_GRADS)
+    _check(hip, oracle, sc, seed=10, **needle)
     sc = make_scene(4000, 240, 165, 15, seed=65, scale_mult=3.0)
     g = torch.Generator().manual_seed(65)
     sc.opacities[:] = (torch.rand(sc.P, 1, generator=g) * 0.02).reshape(sc.opacities.shape)  # 0 .. 5/255
@@ -197,7 +217,7 @@ def test_needles_and_faint_splats_exact_binning(hip, oracle):
     cam = default_camera(240, 165, yaw_deg=-14.0, tx=-0.3)
     sc = make_scene(3000, 240, 165, 15, seed=66, camera=cam, scale_mult=6.0)
     sc.scales[:, 2] *= 0.02
-    _check(hip, oracle, sc, seed=12, tile=16, grad_keys=COMPOSITE_GRADS)
+    _check(hip, oracle, sc, seed=12, tile=16, **needle)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("OLSR_STRESS_SEEDS", "256"))))

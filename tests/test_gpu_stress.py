@@ -28,12 +28,16 @@ def test_random_scene_against_the_oracle(hip, oracle, generation, k):
         try:
             _check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2, **kw)
         except AssertionError as e2:
-            # ~2.5 % of the campaign's scenes (screen-filling splats, random precomputed covariances): a few elements per
+            # ~2 % of the campaign's scenes (screen-filling splats, random precomputed covariances): a few elements per
             # 10^4 of the gradients behind the inverse of the 2D covariance leave the band — three terms of order 1e8 cancel
-            # there, and two roundings of the reference's own source differ by as much.  What must
-            # still hold to the element: everything the composite produces.
+            # there, so the chain amplifies the summation-order noise of its INPUTS (the reference's own float atomics
+            # have the same noise from run to run).  What must still hold to the element:
+            # everything the composite produces ...
             if "forward" in str(e2) or "bit-identical" in str(e2):
                 raise
             print("per-element breach in the covariance chain:", desc, str(e2)[:200])
+            # ... and the per-Gaussian chain itself once both sides start from the same composite-level gradients (chain=True,
+            # the default of _check: the oracle replays the reference's chain on the product's dL_dconic / dL_dmean2D).
+            from test_gpu_parity import COMPOSITE_KEYS
             _check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2,
-                   grad_keys=("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dlanguage", "dL_ddepths"), **kw)
+                   grad_keys=COMPOSITE_KEYS, chain=True, **kw)
