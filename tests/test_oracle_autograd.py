@@ -89,3 +89,22 @@ def test_reference_mode_differs_only_where_documented(oracle):
     assert torch.equal(fr16["color"], fe16["color"])
     for f in (fr, fe, fr16, fe16):
         oracle.release(f["geom"])
+
+
+@pytest.mark.parametrize("F,mode", [(15, _abi.BWD_REFERENCE), (0, _abi.BWD_EXACT)])
+def test_chain_replay_reproduces_the_full_backward(oracle, F, mode):
+    """oracle_backward_chain (the per-Gaussian half alone, on caller-provided composite-level gradients) fed with the
+    oracle's own composite-level gradients gives the full backward's outputs bit for bit; fed with perturbed ones it
+    moves — the GPU suite replays it on the product's gradients (tests/test_gpu_parity.py::_check, chain=True)."""
+    sc = make_scene(900, 96, 64, F, seed=5)
+    fo, go = run_backend(oracle, sc, None, 2, 15, mode)
+    comp = {k: go[k] for k in ("dL_dmeans2D", "dL_dconic", "dL_dcolors", "dL_ddepths")}
+    ch = oracle.backward_chain(F, comp, *fo["bwd_args"])
+    assert set(ch) == set(oracle.CHAIN_KEYS)
+    for k in oracle.CHAIN_KEYS:
+        assert torch.equal(ch[k], go[k]), k
+    comp["dL_dconic"] = comp["dL_dconic"] * 1.01
+    ch2 = oracle.backward_chain(F, comp, *fo["bwd_args"])
+    assert not torch.equal(ch2["dL_dcov3D"], go["dL_dcov3D"])
+    assert torch.equal(ch2["dL_dsh"], go["dL_dsh"])  # (colour path: untouched by the conic)
+    oracle.release(fo["geom"])
