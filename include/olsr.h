@@ -423,6 +423,13 @@ void olsr_debug_sort_timing(unsigned long long *device_buffer, int max_blocks, i
  * whether n is sorted by the one-kernel passes at all (return value: 1) or by the multi-kernel fallback (0). */
 int olsr_debug_sort_plan(int64_t n, int n_is_capacity, int32_t *keys_per_thread, int32_t *blocks);
 
+/* Tuning / test knobs of the radix passes, process-wide.  keys_per_thread in {2, 4, 8, 12, 16} pins the instantiation (0:
+ * chosen from the input size); resident_blocks > 0 replaces the 256 blocks a round is planned for; legacy != 0 forces the
+ * multi-kernel passes at any size.  A negative argument leaves that knob as it is.  The library reads the environment
+ * (OLSR_SORT_KPT, OLSR_SORT_RESIDENT, OLSR_SORT_LEGACY) ONCE, when it is loaded, to seed them; nothing on a call path
+ * touches getenv.  Not for use while frames are in flight (a forward and its backward must see the same plan). */
+void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy);
+
 const char *olsr_last_error(void);
 const char *olsr_version(void);
 

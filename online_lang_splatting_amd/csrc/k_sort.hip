@@ -491,8 +491,8 @@ static void launch_pass_t(const PassArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  static bool printed = false;
-  if (!printed && std::getenv("OLSR_SORT_DEBUG")) {
+  static bool printed = std::getenv("OLSR_SORT_DEBUG") == nullptr;  // (read once per instantiation)
+  if (!printed) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sort_pass_kernel<DB, KPT>, FS_T, smem);
     std::fprintf(stderr, "[olsr] sort_pass_kernel<%d,%d>: %zu B dynamic LDS, occupancy API: %d blocks/CU, grid %d\n", DB, KPT,

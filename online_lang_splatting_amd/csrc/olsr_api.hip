@@ -139,12 +139,9 @@ struct BinningProvider {
   int64_t capacity = -1;  // async mode when >= 0
 };
 
-// OLSR_SORT_LEGACY=1 forces the multi-kernel radix passes (the fallback of sorts too large for the fused ones), so
-// that both paths can be tested at any size
-bool force_legacy_sort() {
-  const char* e = std::getenv("OLSR_SORT_LEGACY");
-  return e && e[0] == '1';
-}
+// forces the multi-kernel radix passes (the fallback of sorts too large for the fused ones), so that both paths can be
+// tested at any size
+bool force_legacy_sort() { return sort_knobs().legacy.load(std::memory_order_relaxed) != 0; }
 
 // The drop-in (synchronising) entry needs the instance count on the host (the reference's blocking D2H,
 // CR/rasterizer_impl.cu:454-455).  No copy, no event: block 0 of the histogram kernel stores the count and then a
@@ -332,7 +329,26 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
 
 namespace olsr {
 RowsMailbox& rows_mailbox_of_this_call() { return g_rows_call; }
+// The radix passes' knobs (olsr_state.h): seeded from the environment once, when the library is loaded
+SortKnobs& sort_knobs() {
+  static SortKnobs k;
+  return k;
+}
 }  // namespace olsr
+
+namespace {
+struct SortKnobsFromEnv {
+  SortKnobsFromEnv() {
+    auto num = [](const char* name) {
+      const char* e = std::getenv(name);
+      return e ? std::atoi(e) : 0;
+    };
+    sort_knobs().kpt = num("OLSR_SORT_KPT");
+    sort_knobs().resident = num("OLSR_SORT_RESIDENT");
+    sort_knobs().legacy = num("OLSR_SORT_LEGACY") == 1 ? 1 : 0;
+  }
+} g_sort_knobs_from_env;
+}  // namespace
 
 extern "C" {
 
@@ -665,6 +681,12 @@ int olsr_get_stage_times(const char** names, float* ms, int max) {
 
 void olsr_debug_sort_timing(unsigned long long* device_buffer, int max_blocks, int max_launches) {
   debug_set_sort_timing(device_buffer, max_blocks, max_launches);
+}
+
+void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy) {
+  if (keys_per_thread >= 0) sort_knobs().kpt = keys_per_thread;
+  if (resident_blocks >= 0) sort_knobs().resident = resident_blocks;
+  if (legacy >= 0) sort_knobs().legacy = legacy ? 1 : 0;
 }
 
 int olsr_debug_sort_plan(int64_t n, int n_is_capacity, int32_t* keys_per_thread, int32_t* blocks) {

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <cstdlib>
 
 namespace olsr {
@@ -40,16 +41,19 @@ struct SortPlan {
 };
 constexpr int FUSED_SORT_THREADS = 1024;
 constexpr int FUSED_SORT_MAX_BLOCKS = 4096;  // beyond: the multi-kernel passes (histogram, device-wide scan, scatter)
-// (the two environment knobs exist for tuning experiments and for the tests that walk every kernel instantiation and
-//  the multi-round ticket order on small inputs; they are read at every call, a forward and its backward see the same)
+// (tuning / test knobs, process-wide: seeded from OLSR_SORT_KPT / OLSR_SORT_RESIDENT / OLSR_SORT_LEGACY once at load and
+//  set by olsr_debug_sort_knobs — the tests that walk every kernel instantiation and the multi-round ticket order on small
+//  inputs; no getenv on a call path)
+struct SortKnobs {
+  std::atomic<int> kpt{0}, resident{0}, legacy{0};
+};
+SortKnobs& sort_knobs();  // olsr_api.hip
 inline int sort_plan_resident_blocks() {
-  const char* e = std::getenv("OLSR_SORT_RESIDENT");
-  const int x = e ? std::atoi(e) : 0;
+  const int x = sort_knobs().resident.load(std::memory_order_relaxed);
   return x > 0 ? x : 256;
 }
 inline int sort_plan_forced_kpt() {
-  const char* e = std::getenv("OLSR_SORT_KPT");
-  const int x = e ? std::atoi(e) : 0;
+  const int x = sort_knobs().kpt.load(std::memory_order_relaxed);
   return (x == 2 || x == 4 || x == 8 || x == 12 || x == 16) ? x : 0;
 }
 // n_is_capacity: n bounds a count that is only known on the device (olsr_forward_async); the rounds are then estimated

@@ -160,8 +160,7 @@ def test_sort_plan_host_logic(L, monkeypatch):
     """Keys per thread / block count of the one-kernel radix passes (csrc/olsr_state.h: sort_plan): a round of at most
     256 resident blocks costs about (kpt + 11) us; status rows are reserved for the smallest chunk; 4096 blocks at
     most, beyond that the multi-kernel fallback."""
-    monkeypatch.delenv("OLSR_SORT_KPT", raising=False)
-    monkeypatch.delenv("OLSR_SORT_RESIDENT", raising=False)
+    L.olsr_debug_sort_knobs(0, 0, 0)
     kpt, nblk = ctypes.c_int32(), ctypes.c_int32()
 
     def plan(n, cap=0):
@@ -177,8 +176,19 @@ def test_sort_plan_host_logic(L, monkeypatch):
         ok, k, b = plan(n)
         assert ok == 1 and k in (2, 4, 8, 12, 16) and b == -(-n // (1024 * k)) and b <= 4096
     assert plan(4096 * 16384 + 1)[0] == 0          # more than 4096 blocks even at kpt 16: the multi-kernel passes
-    monkeypatch.setenv("OLSR_SORT_KPT", "4")
-    assert plan(500_000)[1:] == (4, 123)
+    # the tuning knobs: set through the library (the environment is read once, at load), a forced value that would
+    # overrun the status rows is ignored, a negative argument leaves a knob alone
+    try:
+        L.olsr_debug_sort_knobs(4, -1, -1)
+        assert plan(500_000)[1:] == (4, 123)
+        assert plan(40_000_000)[1] != 4 and plan(40_000_000)[2] <= 4096
+        L.olsr_debug_sort_knobs(-1, 64, -1)
+        assert plan(500_000)[1:] == (4, 123)
+        L.olsr_debug_sort_knobs(0, -1, -1)
+        assert plan(500_000)[1] != 2  # 64 resident blocks per round: fatter blocks win
+    finally:
+        L.olsr_debug_sort_knobs(0, 0, 0)
+    assert plan(500_000) == (1, 2, 245)
 
 
 def test_usable_cpus_respects_affinity_and_quota(monkeypatch, tmp_path):

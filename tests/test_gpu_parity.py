@@ -285,13 +285,17 @@ def test_transparent_scene_walks_whole_lists(hip, oracle):
     _check(hip, oracle, sc, seed=9, mode=_abi.BWD_EXACT)
 
 
-def test_multi_kernel_sort_fallback(hip, oracle, monkeypatch):
+def test_multi_kernel_sort_fallback(hip, oracle):
     """Sorts too large for the one-kernel-per-pass radix passes (> 33 M keys) fall back to histogram -> device-wide
-    scan -> scatter launches; OLSR_SORT_LEGACY=1 forces that path at any size so it keeps meeting the oracle."""
-    monkeypatch.setenv("OLSR_SORT_LEGACY", "1")
-    _check(hip, oracle, make_scene(6000, 200, 150, 15, seed=73), seed=4)
-    _check(hip, oracle, make_scene(3000, 157, 101, 0, seed=74), seed=5, tile=16, mode=_abi.BWD_EXACT)
-    monkeypatch.delenv("OLSR_SORT_LEGACY")
+    scan -> scatter launches; olsr_debug_sort_knobs(legacy=1) forces that path at any size so it keeps meeting the
+    oracle."""
+    from online_lang_splatting_amd._lib import lib
+    try:
+        lib().olsr_debug_sort_knobs(-1, -1, 1)
+        _check(hip, oracle, make_scene(6000, 200, 150, 15, seed=73), seed=4)
+        _check(hip, oracle, make_scene(3000, 157, 101, 0, seed=74), seed=5, tile=16, mode=_abi.BWD_EXACT)
+    finally:
+        lib().olsr_debug_sort_knobs(-1, -1, 0)
     _check(hip, oracle, make_scene(6000, 200, 150, 15, seed=73), seed=4)
 
 
@@ -330,15 +334,19 @@ def test_rect_upper_bound_in_the_references_operation_order(hip, oracle):
 
 
 @pytest.mark.parametrize("kpt", [2, 4, 8, 12, 16])
-def test_every_sort_pass_instantiation(hip, oracle, monkeypatch, kpt):
-    """The radix passes pick their keys-per-thread from the input size (olsr_state.h: sort_plan); OLSR_SORT_KPT pins it,
-    so that every instantiation sorts the same frame — at kpt = 2 its 0.6 M instances need more than 256 blocks, which
-    also exercises the ticket order of a pass that is not resident at once."""
-    monkeypatch.setenv("OLSR_SORT_KPT", str(kpt))
-    sc = make_scene(60000, 640, 480, 15, seed=76)
-    _check(hip, oracle, sc, seed=6)
-    if kpt in (2, 16):
-        _check(hip, oracle, make_scene(2500, 160, 120, 0, seed=77), seed=7, tile=16)
+def test_every_sort_pass_instantiation(hip, oracle, kpt):
+    """The radix passes pick their keys-per-thread from the input size (olsr_state.h: sort_plan);
+    olsr_debug_sort_knobs pins it, so that every instantiation sorts the same frame — at kpt = 2 its 0.6 M instances
+    need more than 256 blocks, which also exercises the ticket order of a pass that is not resident at once."""
+    from online_lang_splatting_amd._lib import lib
+    try:
+        lib().olsr_debug_sort_knobs(kpt, -1, -1)
+        sc = make_scene(60000, 640, 480, 15, seed=76)
+        _check(hip, oracle, sc, seed=6)
+        if kpt in (2, 16):
+            _check(hip, oracle, make_scene(2500, 160, 120, 0, seed=77), seed=7, tile=16)
+    finally:
+        lib().olsr_debug_sort_knobs(0, -1, -1)
 
 
 def test_repeated_backward_on_one_forward(hip):
