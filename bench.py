@@ -243,6 +243,10 @@ def dropin_leg(sc, dev, steps, warmup):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
+    for t in leaves:
+        t.grad = None
+    torch.cuda.reset_peak_memory_stats(dev)
+    mem0 = torch.cuda.memory_allocated(dev)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     evs[0].record()
     t0 = time.perf_counter()
@@ -254,7 +258,8 @@ def dropin_leg(sc, dev, steps, warmup):
     gaps = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
     return {"path": "diff_gaussian_rasterization autograd API (forward + backward, torch allocations, 1 host sync)",
             "value": round(steps / dt, 3), "unit": "frames/s", "ms_per_frame": round(1e3 * dt / steps, 4), "steps": steps,
-            "frame_interval_ms": percentiles(gaps)}
+            "frame_interval_ms": percentiles(gaps),
+            "peak_allocated_MB_per_frame": round((torch.cuda.max_memory_allocated(dev) - mem0) / 2**20, 1)}
 
 
 

@@ -241,6 +241,14 @@ size_t olsr_backward_scratch_bytes(int64_t rows, int32_t F);
  * (2 resp. 4 rows per instance) then.  No reference counterpart (its backward accumulates with atomics). */
 int32_t olsr_last_forward_token(void);
 int64_t olsr_live_rows(int32_t token, int32_t packed_survivor_waves);
+/* The same, for a caller that runs ahead of the GPU (a training loop reaches its backward while the forward is still
+ * executing): waits — polling the mapped word, the GPU is busy with the forward meanwhile — until the forward has posted
+ * its counts, at most timeout_us microseconds, and not at all when the slot already belongs to a later forward.
+ * Returns the row count or -1 (then size by the bound).  The drop-in bindings call it when the bound would cost more than
+ * 64 MB of scratch (OLSR_ROWS_WAIT_US, read once at load, default 5000; 0: never wait). */
+int64_t olsr_live_rows_wait(int32_t token, int32_t packed_survivor_waves, int32_t timeout_us);
+/* The bindings' policy in one call: rows to size the backward scratch of (token, R instances, F) with. */
+int64_t olsr_backward_rows(int32_t token, int32_t packed_survivor_waves, int64_t num_rendered, int32_t F);
 int olsr_backward(const olsr_scene *scene, const int32_t *radii,
                   void *geometry_buffer, int32_t num_rendered,
                   void *binning_buffer, const void *image_buffer,

@@ -247,14 +247,13 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
         def p(name):
             t = g.get(name)
             return t.data_ptr() if t is not None and t.numel() > 0 else None
-        # Row scratch: one partial-gradient row per live (instance, 64-pixel slot) pair.  Their number L is only known
-        # on the device; instead of a host sync for it, the scratch is sized by the bound L <= slots * R (two packed
-        # survivor waves per instance in the reference mode of 15x15 tiles, else four slots).  The caching allocator
-        # hands the same block back call after call, and a backward without a sync keeps the GPU fed.
+        # Row scratch: one partial-gradient row per live (instance, 64-pixel slot) pair.  The forward posts their exact
+        # number to the host; olsr_backward_rows waits for it when this thread is ahead of the GPU and the bound
+        # L <= slots * R (two packed survivor waves per instance in the reference mode of 15x15 tiles, else four slots)
+        # would cost more than 64 MB — the GPU is busy with the forward meanwhile.
         tile, bwd_mode, _binning = cfg if cfg is not None else current_config()
         packed = bwd_mode == _abi.BWD_REFERENCE and tile == 15
-        exact = lib().olsr_live_rows(int(rows_token), 1 if packed else 0)
-        rows = exact if exact >= 0 else max(int(R), 0) * (2 if packed else 4)
+        rows = lib().olsr_backward_rows(int(rows_token), 1 if packed else 0, int(R), int(F))
         scratch = torch.empty(lib().olsr_backward_scratch_bytes(rows, F), dtype=torch.uint8, device=dev)
         check(lib().olsr_backward(
             C.byref(s), rad.data_ptr() if P else None, geomBuffer.data_ptr(), int(R), binningBuffer.data_ptr(),

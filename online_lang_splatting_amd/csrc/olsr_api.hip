@@ -363,6 +363,36 @@ int64_t olsr_live_rows(int32_t token, int32_t packed_survivor_waves) {
   return (__atomic_load_n(&slot[2], __ATOMIC_ACQUIRE) == token) ? v : -1;  // (not overwritten meanwhile)
 }
 
+int64_t olsr_live_rows_wait(int32_t token, int32_t packed_survivor_waves, int32_t timeout_us) {
+  int64_t v = olsr_live_rows(token, packed_survivor_waves);
+  int32_t* ring = g_rows.p.load(std::memory_order_acquire);
+  if (v >= 0 || timeout_us <= 0 || token <= 0 || !ring) return v;
+  const volatile int32_t* slot = ring + 4 * (token % ROWS_RING);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; ++spin) {
+    const int32_t seen = __atomic_load_n(&slot[2], __ATOMIC_ACQUIRE);
+    if (seen == token) return olsr_live_rows(token, packed_survivor_waves);
+    // tokens grow by one per forward (wrapping to 1 at INT32_MAX): a larger one in the slot means ours was overwritten
+    if (seen > token && seen - token < (1 << 30)) return -1;
+    __builtin_ia32_pause();
+    if ((spin & 0xFFu) == 0xFFu &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(timeout_us))
+      return -1;
+  }
+}
+
+int64_t olsr_backward_rows(int32_t token, int32_t packed_survivor_waves, int64_t num_rendered, int32_t F) {
+  static const int32_t wait_us = [] {
+    const char* e = std::getenv("OLSR_ROWS_WAIT_US");
+    return e ? std::atoi(e) : 5000;
+  }();
+  const int64_t bound = (num_rendered > 0 ? num_rendered : 0) * (packed_survivor_waves ? 2 : 4);
+  int64_t v = olsr_live_rows(token, packed_survivor_waves);
+  if (v < 0 && olsr_backward_scratch_bytes(bound, F) > ((size_t)64 << 20))
+    v = olsr_live_rows_wait(token, packed_survivor_waves, wait_us);
+  return (v >= 0 && v <= bound) ? v : bound;
+}
+
 size_t olsr_geometry_bytes(int32_t P, int32_t F) {
   size_t bytes = 0;
   GeometryState::carve(nullptr, (size_t)(P > 0 ? P : 0), grad_row(supported_F(F) ? F : 0), bytes);

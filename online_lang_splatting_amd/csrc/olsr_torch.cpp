@@ -174,12 +174,14 @@ std::vector<Tensor> backward(int F, const Tensor &bg, const Tensor &means3D, con
   Tensor rad = radii.contiguous();
   // Row scratch: one partial-gradient row per live (instance, 64-pixel slot) pair (reference mode of 15x15 tiles: per
   // packed survivor wave).  The caching allocator reuses blocks stream-ordered, so the tensor may die at return.
-  // The forward posted the frame's exact row count to the host (olsr_live_rows); only when that has not arrived (or its
-  // slot was reused) the bound L <= slots * R stands in.
+  // The forward posts the frame's exact row count to the host; a caller that is ahead of the GPU waits for it (the GPU is
+  // busy with the forward meanwhile) when the bound L <= slots * R would cost more than 64 MB (olsr_backward_rows).
   const bool packed = (bwd_mode == OLSR_BWD_REFERENCE && tile == 15);
-  const int64_t slots = packed ? 2 : 4;
-  const int64_t exact = olsr_live_rows(rows_token, packed ? 1 : 0);
-  const int64_t rows = exact >= 0 ? exact : static_cast<int64_t>(R > 0 ? R : 0) * slots;
+  int64_t rows;
+  {
+    pybind11::gil_scoped_release nogil;
+    rows = olsr_backward_rows(rows_token, packed ? 1 : 0, R, F);
+  }
   Tensor scratch = torch::empty({static_cast<int64_t>(olsr_backward_scratch_bytes(rows, F))},
                                 means3D.options().dtype(torch::kUInt8));
   int rc;

@@ -729,6 +729,48 @@ def test_live_row_counts_with_few_tiles(hip, wh):
     assert lib().olsr_live_rows(tok, 0) == want[_abi.BWD_EXACT] >= want[_abi.BWD_REFERENCE]
 
 
+def test_backward_scratch_is_exact_when_the_host_runs_ahead(hip):
+    """A training loop reaches its backward while the forward is still executing: the binding then waits for the forward's
+    posted row count (olsr_backward_rows; the GPU is busy meanwhile) instead of allocating the bound of two rows per
+    instance — seen here as the peak of the allocator over un-synchronised forward + backward pairs."""
+    from online_lang_splatting_amd._lib import lib
+    from parity_common import fwd_args
+    dev = torch.device(DEV)
+    sc = make_scene(150000, 800, 600, 15, seed=21)
+    a = fwd_args(sc, dev)
+    cots = [t.to(dev) for t in sc.cotangents(3)]
+
+    def pair():
+        R, color, lang, radii, geom, binb, img, depth, opac, nt = hip.rasterize_language_gaussians(*a)
+        tok = hip.last_forward_token()
+        fwd = dict(R=R, radii=radii, geom=geom, binning=binb, img=img)
+        args = [a[0], a[1], radii, a[2], a[3], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], *cots,
+                a[16], a[17], a[18], geom, R, binb, img, False]
+        g = hip.backward_all(15, *args, rows_token=tok)
+        return R, tok, g
+
+    R, tok, g = pair()
+    torch.cuda.synchronize()
+    bound_bytes = lib().olsr_backward_scratch_bytes(2 * R, 15)
+    exact = lib().olsr_live_rows(tok, 1)
+    exact_bytes = lib().olsr_backward_scratch_bytes(exact, 15)
+    assert bound_bytes > (64 << 20) and exact_bytes < bound_bytes // 3
+    del g
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    for _ in range(3):
+        R, tok, g = pair()  # no synchronisation between the forward and its backward
+        del g
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated(dev) - base
+    assert peak < bound_bytes, (peak, bound_bytes, exact_bytes)  # the bound alone would exceed this
+    # the policy call itself: exact once posted, the bound for an unknown token
+    assert lib().olsr_backward_rows(tok, 1, R, 15) == lib().olsr_live_rows(tok, 1)
+    assert lib().olsr_backward_rows(0, 1, R, 15) == 2 * R
+    assert lib().olsr_live_rows_wait(tok + 7, 1, 1000) == -1  # never issued: times out
+
+
 def run_fwd_only(hip, sc, dev):
     from parity_common import fwd_args
     return hip.rasterize_language_gaussians(*fwd_args(sc, dev))
