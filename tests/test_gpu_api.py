@@ -729,6 +729,34 @@ def test_live_row_counts_with_few_tiles(hip, wh):
     assert lib().olsr_live_rows(tok, 0) == want[_abi.BWD_EXACT] >= want[_abi.BWD_REFERENCE]
 
 
+def test_dropin_launch_order_hint_is_invisible(hip):
+    """olsr_forward keeps, per stream and tile count, the heaviest-first tile order of the previous frame issued on that
+    stream (the forward composite finishes sooner with it).  It must never show in a result: the same scene after a
+    different scene of the same image size, on the default stream and on two side streams interleaved, gives the same bits
+    as a first frame."""
+    dev = torch.device(DEV)
+    a = make_scene(9000, 250, 190, 15, seed=31)
+    b = make_scene(7000, 250, 190, 15, seed=32, scale_mult=3.0)
+    first, g_first = run_backend(hip, a, dev, 1, 15, 0)   # (whatever earlier tests left behind for 17 x 13 tiles)
+    run_backend(hip, b, dev, 2, 15, 0)                    # another scene leaves its order behind
+    again, g_again = run_backend(hip, a, dev, 1, 15, 0)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    side = []
+    for st, sc_ in ((s1, b), (s2, a), (s1, a), (s2, b), (s2, a)):
+        with torch.cuda.stream(st):
+            side.append((sc_ is a, run_backend(hip, sc_, dev, 1, 15, 0)))
+    torch.cuda.synchronize()
+    for is_a, (f, g) in [(True, (again, g_again))] + side:
+        if not is_a:
+            continue
+        assert f["R"] == first["R"]
+        for k in ("color", "language", "depth", "opacity", "radii", "n_touched"):
+            assert torch.equal(f[k], first[k]), k
+        for k in g_first:
+            assert torch.equal(g[k], g_first[k]), k
+
+
 def test_backward_scratch_is_exact_when_the_host_runs_ahead(hip):
     """A training loop reaches its backward while the forward is still executing: the binding then waits for the forward's
     posted row count (olsr_backward_rows; the GPU is busy meanwhile) instead of allocating the bound of two rows per
