@@ -397,6 +397,21 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
         torch.cuda.synchronize(dev)
         trk["rgb_rasterizer_render"] = round(1e3 * (time.perf_counter() - t0) / tracking_iters, 4)
         del ws_rgb
+    # the same iteration recorded once into a HIP graph and replayed (one launch from the host per iteration; the Adam
+    # step number lives on the device)
+    pose_g = PoseState(T0, proj, cam.tanfovx, cam.tanfovy, device_step_count=True)
+    loop = TrackingLoop(ws, g_dev, sc.sh_degree, pose_g, gt_image, gt_depth, language_cotangent="null")
+    graph = loop.capture()
+    pose_g.reset(T0)
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(tracking_iters):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    trk["no_language_cotangent_hip_graph_replay"] = round(1e3 * (time.perf_counter() - t0) / tracking_iters, 4)
+    del graph
     out["tracking_iteration_ms"] = trk["no_language_cotangent"]
     out["tracking"] = {"ms_per_iteration": trk, "iterations": tracking_iters,
                        "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) + "

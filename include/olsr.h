@@ -365,7 +365,8 @@ int olsr_tracking_loss(const olsr_loss_params *params, const float *image, const
  *                 [48,51) camera_center | [52,58) exp_avg of tau | [58,64) exp_avg_sq | [64,70) tau this step applied |
  *                 [70,72) exposure a, b (in/out) | [72,74) their exp_avg | [74,76) exp_avg_sq
  *   status        device int32[2]: {converged flag of this step, steps done}
- * params->step is the 1-based Adam step count of this call. */
+ * params->step is the 1-based Adam step count of this call; step <= 0: the count is status[1] + 1, kept on the device (the
+ * launch is then the same every iteration and can be replayed from a HIP graph; reset status to restart the optimiser). */
 typedef struct olsr_pose_params {
   double lr_rot, lr_trans, lr_exposure;
   double beta1, beta2, eps;  /* torch.optim.Adam defaults in the reference: 0.9, 0.999, 1e-8 */

@@ -27,6 +27,10 @@ struct PoseScalars {
   float one_minus_beta1, beta2, one_minus_beta2, bias_correction2_sqrt, eps;
   float neg_step_rot, neg_step_trans, neg_step_exposure, converged_threshold;
   int has_grad, has_exposure;
+  // step_on_device: the Adam step count is status[1] + 1 (params->step <= 0), so that the same launch can be replayed
+  // from a HIP graph; the bias corrections are then formed here, in double like launch_pose_step forms them on the host
+  int step_on_device;
+  double beta1_d, beta2_d, lr_rot_d, lr_trans_d, lr_exposure_d;
 };
 
 // state (floats): [0,16) T_w2c row-major | [16,32) world_view_transform = W2C^T | [32,48) full_proj_transform |
@@ -41,6 +45,15 @@ __global__ __launch_bounds__(64) void pose_step_kernel(PoseScalars hp, const flo
 #pragma unroll
   for (int i = 0; i < 16; ++i) T[i] = state[i];
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (hp.has_grad && hp.step_on_device) {
+    const double step = (double)(status[1] + 1);
+    const double bc1 = 1.0 - pow(hp.beta1_d, step);
+    const double bc2 = 1.0 - pow(hp.beta2_d, step);
+    hp.bias_correction2_sqrt = (float)sqrt(bc2);
+    hp.neg_step_rot = (float)(-(hp.lr_rot_d / bc1));
+    hp.neg_step_trans = (float)(-(hp.lr_trans_d / bc1));
+    hp.neg_step_exposure = (float)(-(hp.lr_exposure_d / bc1));
+  }
   if (hp.has_grad) {
     // the rasterizer's dL_dtau is [rho | theta] (DGR/diff_gaussian_rasterization/__init__.py:383-385): rho is the
     // gradient of cam_trans_delta, theta of cam_rot_delta
@@ -176,6 +189,12 @@ void launch_pose_step(const olsr_pose_params& p, const float* dL_dtau_sum, const
   k.converged_threshold = (float)p.converged_threshold;
   k.has_grad = dL_dtau_sum != nullptr;
   k.has_exposure = dL_dexposure != nullptr;
+  k.step_on_device = (p.step <= 0) ? 1 : 0;
+  k.beta1_d = p.beta1;
+  k.beta2_d = p.beta2;
+  k.lr_rot_d = p.lr_rot;
+  k.lr_trans_d = p.lr_trans;
+  k.lr_exposure_d = p.lr_exposure;
   pose_step_kernel<<<1, 64, 0, st>>>(k, dL_dtau_sum, dL_dexposure, proj, state, status);
 }
 

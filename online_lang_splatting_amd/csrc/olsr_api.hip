@@ -604,7 +604,7 @@ int olsr_pose_step(const olsr_pose_params* params, const float* dL_dtau_sum, con
                    const float* projection_matrix, float* state, int32_t* status, void* hip_stream) {
   if (!params || !projection_matrix || !state || !status)
     return fail(OLSR_ERR_ARG, "pose params, projection_matrix, state and status are required");
-  if (dL_dtau_sum && params->step < 1) return fail(OLSR_ERR_ARG, "step must be >= 1 when a gradient is given");
+  // (step <= 0 with a gradient: the step count is status[1] + 1, kept on the device — see include/olsr.h)
   if (!dL_dtau_sum && dL_dexposure) return fail(OLSR_ERR_ARG, "an exposure gradient needs a pose gradient (one optimiser step)");
   launch_pose_step(*params, dL_dtau_sum, dL_dexposure, projection_matrix, state, status, (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();

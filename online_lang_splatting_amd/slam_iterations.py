@@ -32,7 +32,9 @@ class PoseState:
 
     def __init__(self, T_w2c: torch.Tensor, projection_matrix: torch.Tensor, tanfovx: float, tanfovy: float,
                  lr_rot=0.003, lr_trans=0.001, lr_exposure=0.01, betas=(0.9, 0.999), eps=1e-8,
-                 converged_threshold=1e-4, optimise_exposure=True):
+                 converged_threshold=1e-4, optimise_exposure=True, device_step_count=False):
+        """device_step_count: the Adam step number lives on the device (status[1]) instead of in the launch arguments —
+        every iteration is then the same sequence of launches and can be replayed from a HIP graph (TrackingLoop.capture)."""
         dev = T_w2c.device
         f32 = dict(dtype=torch.float32, device=dev)
         self.device = dev
@@ -47,6 +49,7 @@ class PoseState:
         self.exposure = self.state[70:72]
         self.status = torch.zeros(2, dtype=torch.int32, device=dev)  # {converged flag, steps done}
         self.optimise_exposure = optimise_exposure
+        self.device_step_count = device_step_count
         self.hp = _abi.OlsrPoseParams(lr_rot=lr_rot, lr_trans=lr_trans, lr_exposure=lr_exposure, beta1=betas[0],
                                       beta2=betas[1], eps=eps, converged_threshold=converged_threshold, step=0)
         self.reset(T_w2c)
@@ -70,7 +73,8 @@ class PoseState:
     def step(self, dL_dtau_sum: torch.Tensor, dL_dexposure: Optional[torch.Tensor] = None):
         """dL_dtau_sum: device float[6] = [rho | theta] as olsr_backward leaves it; dL_dexposure: device float[2] from
         olsr_tracking_loss (ignored unless optimise_exposure)."""
-        self.hp.step += 1
+        if not self.device_step_count:
+            self.hp.step += 1
         self._call(dL_dtau_sum, dL_dexposure if self.optimise_exposure else None)
 
     def camera(self) -> Dict:
@@ -96,6 +100,24 @@ class TrackingLoop:
         self.zero_lang = (torch.zeros(workspace.F, workspace.H, workspace.W, device=dev)
                           if (language_cotangent == "zeros" and workspace.F > 0) else None)
         self.loss = None
+
+    def capture(self, warmup=3):
+        """Records one iteration into a HIP graph (torch.cuda.CUDAGraph) and returns it: graph.replay() is then one
+        tracking iteration — same kernels, same results, one launch from the host.  Needs a pose with
+        device_step_count=True (the step number must not be a launch argument) and leaves the pose `warmup` + 1
+        iterations further (reset it before the frame's first replay)."""
+        assert self.pose.device_step_count, "PoseState(device_step_count=True) is required for graph replay"
+        dev = self.ws.device
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # (warm-up off the default stream, as torch's graph capture wants it)
+            for _ in range(warmup):
+                self.iteration()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.iteration()
+        return graph
 
     def iteration(self, read_convergence=False) -> bool:
         ws = self.ws

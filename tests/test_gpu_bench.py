@@ -60,7 +60,8 @@ def test_config3_line_carries_the_config4_substitute():
     trk = c4["tracking"]["ms_per_iteration"]
     assert set(trk) == {"no_language_cotangent", "no_language_cotangent_with_convergence_readback",
                         "zero_language_cotangent", "zero_language_cotangent_with_convergence_readback",
-                        "rgb_rasterizer_render"}
+                        "rgb_rasterizer_render", "no_language_cotangent_hip_graph_replay"}
+    assert trk["no_language_cotangent_hip_graph_replay"] < 1.15 * trk["no_language_cotangent"]
     assert c4["tracking"]["pose_error_after"] < c4["tracking"]["pose_error_start"]  # it moved towards the target pose
     assert not c4["mapping"]["capacity_overflow"] and c4["mapping"]["views"] == 12
     assert c4["mapping"]["loss_last_view_final_iteration"] < c4["mapping"]["loss_last_view_first_iteration"]

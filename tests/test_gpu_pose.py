@@ -89,3 +89,45 @@ def test_tracking_loop_recovers_a_perturbed_pose(hip):
         assert errs[-1] < 0.8 * errs[0], (variant, errs[0], errs[-1])
         traj[variant] = ps.T_w2c.clone()
     assert torch.equal(traj["null"], traj["zeros"])
+
+
+def test_tracking_iteration_replays_from_a_hip_graph(hip):
+    """The whole iteration — sync-free forward, tracking loss, pose-only backward, pose step — is a fixed sequence of
+    launches on device-resident state (the Adam step number included: PoseState(device_step_count=True)), so it can be
+    recorded into a HIP graph once and replayed: same pose, same optimiser state, bit for bit, as issuing it eagerly.
+    The device-side step count itself gives what the host-side count gives."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    from online_lang_splatting_amd.slam_iterations import PoseState, TrackingLoop
+    from oracle.pose_oracle import se3_exp
+    dev = torch.device(DEV)
+    W, H, F = 320, 240, 15
+    sc = make_scene(20000, W, H, F, seed=22)
+    cam = default_camera(W, H)
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    proj = cam.projection_matrix.to(dev)
+    ws = RasterWorkspace(sc.P, W, H, F, sc.shs.shape[1], 2_000_000, dev)
+    T_gt = torch.eye(4, device=dev)
+    ref = PoseState(T_gt, proj, cam.tanfovx, cam.tanfovy)
+    ws.set_scene(sh_degree=sc.sh_degree, **ref.camera(), **g)
+    out = ws.forward()
+    gt_image, gt_depth = out["color"].clone(), out["depth"][0].clone()
+    T0 = torch.from_numpy(se3_exp(np.array([0.02, -0.015, 0.01, 0.004, -0.006, 0.003], dtype=np.float32))).to(dev) @ T_gt
+    states = {}
+    for name, on_device in (("host_count", False), ("device_count", True), ("graph", True)):
+        ps = PoseState(T0, proj, cam.tanfovx, cam.tanfovy, device_step_count=on_device)
+        loop = TrackingLoop(ws, g, sc.sh_degree, ps, gt_image, gt_depth)
+        graph = loop.capture() if name == "graph" else None
+        ps.reset(T0)
+        for _ in range(25):
+            if graph is not None:
+                graph.replay()
+            else:
+                loop.iteration()
+        torch.cuda.synchronize()
+        assert ps.status.tolist()[1] == 25
+        states[name] = ps.state.clone()
+    assert torch.equal(states["graph"], states["device_count"])
+    # host- and device-side bias corrections: the same doubles up to the last bit of pow(), cast to float
+    assert torch.allclose(states["device_count"], states["host_count"], rtol=1e-6, atol=1e-9)
+    assert not torch.equal(states["graph"][:16].view(4, 4), T0)  # (convergence itself: the test above)
