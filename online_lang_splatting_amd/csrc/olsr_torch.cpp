@@ -120,11 +120,17 @@ std::tuple<int, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, 
   Tensor radii = torch::empty({P}, i32), n_touched = torch::empty({P}, i32);
   Tensor geom = torch::empty({0}, u8), binb = torch::empty({0}, u8), img = torch::empty({0}, u8);
   int32_t R = 0;
-  // (the GIL stays held: the allocation callbacks resize torch tensors, and the host only waits while the instance
-  //  count travels — microseconds behind the depth sort)
-  check(olsr_forward(&sc.s, resize, &geom, resize, &binb, resize, &img, out_color.data_ptr<float>(), fpw(out_lang),
-                     out_depth.data_ptr<float>(), out_opacity.data_ptr<float>(), P ? radii.data_ptr<int32_t>() : nullptr,
-                     P ? n_touched.data_ptr<int32_t>() : nullptr, &R, stream_of(means3D)));
+  // The GIL is released for the call: the host waits inside until the GPU has reached this frame's instance count (behind
+  // whatever the stream still holds), and other Python threads should run meanwhile.  The allocation callbacks resize C++
+  // tensors that no Python object refers to yet (plain ATen calls: no interpreter state involved).
+  int rc;
+  {
+    pybind11::gil_scoped_release nogil;
+    rc = olsr_forward(&sc.s, resize, &geom, resize, &binb, resize, &img, out_color.data_ptr<float>(), fpw(out_lang),
+                      out_depth.data_ptr<float>(), out_opacity.data_ptr<float>(), P ? radii.data_ptr<int32_t>() : nullptr,
+                      P ? n_touched.data_ptr<int32_t>() : nullptr, &R, stream_of(means3D));
+  }
+  check(rc);
   return std::make_tuple(static_cast<int>(R), out_color, out_lang, radii, geom, binb, img, out_depth, out_opacity,
                          n_touched);
 }
