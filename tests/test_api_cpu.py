@@ -191,6 +191,21 @@ def test_sort_plan_host_logic(L, monkeypatch):
     assert plan(500_000) == (1, 2, 245)
 
 
+def test_backward_row_policy_without_a_posted_count(L):
+    """Host logic of the drop-in backward's scratch sizing (no GPU involved): with nothing posted for a token the bound of
+    two rows per instance (packed survivor waves) or four (64-pixel slots) stands in, and waiting for a token that no
+    forward ever issued times out."""
+    import time
+    assert L.olsr_backward_rows(0, 1, 1000, 15) == 2000
+    assert L.olsr_backward_rows(0, 0, 1000, 15) == 4000
+    assert L.olsr_backward_rows(0, 1, 0, 15) == 0 and L.olsr_backward_rows(0, 1, -5, 15) == 0
+    assert L.olsr_live_rows(123, 1) == -1
+    t0 = time.perf_counter()
+    assert L.olsr_live_rows_wait(123, 1, 2000) == -1
+    assert time.perf_counter() - t0 < 0.5
+    assert L.olsr_last_forward_token() == 0  # (this thread issued no forward)
+
+
 def test_usable_cpus_respects_affinity_and_quota(monkeypatch, tmp_path):
     """The oracle's thread pool (and bench.py's cpu_baseline `cores`) is sized by the CPUs the container may use — the
     GPU box shows 256 hardware threads and grants 16 — not by os.cpu_count()."""
