@@ -51,6 +51,9 @@ __device__ __forceinline__ bool ref_survives(int rank) {
 }
 
 constexpr int BWD_BATCH = 128;
+#ifndef OLSR_BWD_LDS_REDUCE
+#define OLSR_BWD_LDS_REDUCE 1  // fold the lanes of the per-splat sums through LDS (olsr_device.h) instead of permlane swaps
+#endif
 
 // PACKED (reference mode, 15x15 tiles): the workgroup is the 128 survivors of the reference's reduction
 // tree in two full waves (ref15_rank_of_packed); the 97 other pixels of the tile are not evaluated at all —
@@ -86,8 +89,13 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   __shared__ float4 s_co[B];
   __shared__ __attribute__((aligned(16))) float s_feat[B * FR];
   __shared__ u32 s_row[B];   // first compact row of the instance
-  __shared__ u32 s_flag[B];
+  __shared__ uint8_t s_flag[B];
   __shared__ int s_kmax[NWV];
+  // Where the lanes of the per-splat sums are folded through LDS (olsr_device.h): the reference mode's ten values with at
+  // most 16 language channels.  Measured at the other instantiations, the extra LDS costs a resident workgroup (F = 32:
+  // 0.567 -> 0.602 ms) or the seven exchanges of the exact mode's 25 values cost more than the swaps (-1.7 %).
+  constexpr bool LDSR = (OLSR_BWD_LDS_REDUCE != 0) && REF && (F <= 16);
+  __shared__ __attribute__((aligned(16))) float s_red[LDSR ? NWV * 256 : 4];  // 1 KB per wave: the exchange
 
   // workgroup b runs on XCD b % 8 and takes the (b / 8)-th heaviest tile of that XCD's chunk
   const int tile_id = (int)tile_order[xcd_remap((int)blockIdx.x, ntiles)];
@@ -360,14 +368,27 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
       // Wave reduction (olsr_device.h): four values per permlane-swap tree, the 1-2 left over in a
       // two-value tree.  Total j ends up in the lanes whose role is j (role_of below); that lane stores it.
       float rowval = 0.f;
+      if constexpr (LDSR) {
+        float* wl = &s_red[w * 256];
 #pragma unroll
-      for (int g = 0; g < NG4; ++g) {
-        const float red = wave_reduce4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
-        rowval = (lg == g) ? red : rowval;
-      }
-      if constexpr (REM > 0) {
-        const float red = wave_reduce2(sum[4 * NG4], REM > 1 ? sum[4 * NG4 + 1] : 0.f);
-        rowval = (lg == NG4) ? red : rowval;
+        for (int g = 0; g < NG4; ++g) {
+          const float red = wave_reduce4_lds(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3], wl);
+          rowval = (lg == g) ? red : rowval;
+        }
+        if constexpr (REM > 0) {
+          const float red = wave_reduce2_lds(sum[4 * NG4], REM > 1 ? sum[4 * NG4 + 1] : 0.f, wl);
+          rowval = (lg == NG4) ? red : rowval;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < NG4; ++g) {
+          const float red = wave_reduce4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
+          rowval = (lg == g) ? red : rowval;
+        }
+        if constexpr (REM > 0) {
+          const float red = wave_reduce2(sum[4 * NG4], REM > 1 ? sum[4 * NG4 + 1] : 0.f);
+          rowval = (lg == NG4) ? red : rowval;
+        }
       }
       if constexpr (REF && F > 0) {
         // language gradients come from tile rank 0 only (lane 0 of wave 0): one broadcast, times the

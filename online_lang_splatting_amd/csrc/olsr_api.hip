@@ -726,6 +726,8 @@ const void* olsr_image_field(const void* image_buffer, int32_t width, int32_t he
   if (!std::strcmp(name, "final_T")) return im.final_T;
   if (!std::strcmp(name, "n_contrib")) return im.n_contrib;
   if (!std::strcmp(name, "ranges")) return im.ranges;
+  if (!std::strcmp(name, "tile_work")) return im.tile_work;    // [2][tiles]
+  if (!std::strcmp(name, "tile_order")) return im.tile_order;  // [tiles]
   return nullptr;
 }
 

@@ -96,6 +96,45 @@ __device__ __forceinline__ float wave_reduce2(float a, float b) {
   t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x142, 0xa, 0xf, false));
   return t;
 }
+// The same two reductions with the lane folding done through LDS instead of the permlane swaps.  The swaps are quarter-rate
+// VALU operations (8.2 cycles of the SIMD's vector pipe each, profiles/r3_valu_ubench.json) in kernels that are bound by
+// that pipe; an LDS exchange costs the pipe nothing: one 16-byte write per lane, then every lane of row r reads the four
+// lanes of its column (one per row of 16: ds_read2st64_b32 twice) for the value its row is responsible for.  `wl` is 1 KB
+// of LDS private to the wave (a wave's LDS operations execute in order: no barrier, only the compiler is fenced).
+// Same result layout as above (rows a, c, b, d), different summation order.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float wave_reduce4_lds(float a, float b, float c, float d, float* wl) {
+  const int l = lane_id();
+  reinterpret_cast<float4*>(wl)[l] = make_float4(a, b, c, d);
+  wave_lds_fence();
+  const int r = l >> 4, col = l & 15;
+  const float* p = wl + 4 * col + (((r & 1) << 1) | (r >> 1));  // row 0 -> a, 1 -> c, 2 -> b, 3 -> d
+  float t = (p[0] + p[64]) + (p[128] + p[192]);                  // lanes col, col + 16, col + 32, col + 48
+  wave_lds_fence();
+  t += dpp_mov<0x128>(t);  // row_ror:8
+  t += dpp_mov<0x124>(t);  // row_ror:4
+  t += dpp_mov<0x122>(t);  // row_ror:2
+  t += dpp_mov<0x121>(t);  // row_ror:1
+  return t;
+}
+// rows 0 and 1 hold sum(a), rows 2 and 3 sum(b) (wave_reduce2's contract — row 1: a, row 3: b — is contained)
+__device__ __forceinline__ float wave_reduce2_lds(float a, float b, float* wl) {
+  const int l = lane_id();
+  reinterpret_cast<float2*>(wl)[l] = make_float2(a, b);
+  wave_lds_fence();
+  const int r = l >> 4, col = l & 15;
+  const float* p = wl + 2 * col + (r >> 1);
+  float t = (p[0] + p[32]) + (p[64] + p[96]);
+  wave_lds_fence();
+  t += dpp_mov<0x128>(t);
+  t += dpp_mov<0x124>(t);
+  t += dpp_mov<0x122>(t);
+  t += dpp_mov<0x121>(t);
+  return t;
+}
 typedef float v2f __attribute__((ext_vector_type(2)));
 // lane that holds value i (0..3) of a wave_reduce4 result: rows are ordered a, c, b, d
 __device__ __forceinline__ int reduce4_lane(int i) { return 16 * (((i & 1) << 1) | ((i >> 1) & 1)); }
