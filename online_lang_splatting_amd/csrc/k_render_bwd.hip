@@ -95,6 +95,9 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   // most 16 language channels.  Measured at the other instantiations, the extra LDS costs a resident workgroup (F = 32:
   // 0.567 -> 0.602 ms) or the seven exchanges of the exact mode's 25 values cost more than the swaps (-1.7 %).
   constexpr bool LDSR = (OLSR_BWD_LDS_REDUCE != 0) && REF && (F <= 16);
+  // The reference mode's three folded registers (two groups of four values + the pair) share one in-row reduction
+  // (row_sums3: 7 DPP operations instead of 12), whichever way they were folded
+  constexpr bool MERGED = REF && NG4 == 2 && REM == 2;
   __shared__ __attribute__((aligned(16))) float s_red[LDSR ? NWV * 256 : 4];  // 1 KB per wave: the exchange
 
   // workgroup b runs on XCD b % 8 and takes the (b / 8)-th heaviest tile of that XCD's chunk
@@ -162,9 +165,18 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   // to the free lanes in ascending order.
   const int lg = lane & 15, lr = lane >> 4;
   int role = -1;
-  if (lg < NG4) role = 4 * lg + (((lr & 1) << 1) | (lr >> 1));
-  if (REM > 0 && lg == NG4 && (lr & 1)) role = 4 * NG4 + (lr >> 1);
+  if constexpr (MERGED) {
+    // row_sums3: (lane & 15) == 4 -> group 0, == 12 -> group 1, == 0 -> the pair (rows 1 and 3 store it)
+    if (lg == 4) role = (((lr & 1) << 1) | (lr >> 1));
+    if (lg == 12) role = 4 + (((lr & 1) << 1) | (lr >> 1));
+    // (the pair: the LDS fold leaves a in rows 0-1 and b in rows 2-3, the swap fold a in row 0 and b in row 2)
+    if (lg == 0 && (lr & 1) == (LDSR ? 1 : 0)) role = 8 + (lr >> 1);
+  } else {
+    if (lg < NG4) role = 4 * lg + (((lr & 1) << 1) | (lr >> 1));
+    if (REM > 0 && lg == NG4 && (lr & 1)) role = 4 * NG4 + (lr >> 1);
+  }
   if (role >= NV) role = -1;
+  const bool in_hi8 = (lane & 8) != 0, in_0to3 = (lane & 12) == 0;
   bool lang_lane = false;
   float dLf0_lane = 0.f;
   if constexpr (REF && F > 0) {
@@ -368,7 +380,18 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
       // Wave reduction (olsr_device.h): four values per permlane-swap tree, the 1-2 left over in a
       // two-value tree.  Total j ends up in the lanes whose role is j (role_of below); that lane stores it.
       float rowval = 0.f;
-      if constexpr (LDSR) {
+      if constexpr (MERGED && LDSR) {
+        float* wl = &s_red[w * 256];
+        const float t0 = wave_fold4_lds(sum[0], sum[1], sum[2], sum[3], wl);
+        const float t1 = wave_fold4_lds(sum[4], sum[5], sum[6], sum[7], wl);
+        const float t2 = wave_fold2_lds(sum[8], sum[9], wl);
+        rowval = row_sums3(t0, t1, t2, in_hi8, in_0to3);
+      } else if constexpr (MERGED) {
+        const float t0 = wave_fold4(sum[0], sum[1], sum[2], sum[3]);
+        const float t1 = wave_fold4(sum[4], sum[5], sum[6], sum[7]);
+        const float t2 = wave_fold2(sum[8], sum[9]);
+        rowval = row_sums3(t0, t1, t2, in_hi8, in_0to3);
+      } else if constexpr (LDSR) {
         float* wl = &s_red[w * 256];
 #pragma unroll
         for (int g = 0; g < NG4; ++g) {

@@ -76,6 +76,12 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
   const unsigned x = r[0], y = r[1];
   return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
 }
+// (the folds alone, for row_sums3 below: sixteen partial sums per value are left in each row — rows a, c, b, d, and for the
+//  pair a in row 0, b in row 2, zeros in rows 1 and 3)
+__device__ __forceinline__ float wave_fold4(float a, float b, float c, float d) {
+  return swap16_add(swap32_add(a, b), swap32_add(c, d));
+}
+__device__ __forceinline__ float wave_fold2(float a, float b) { return swap16_add(swap32_add(a, b), 0.0f); }
 __device__ __forceinline__ float wave_reduce4(float a, float b, float c, float d) {
   float t = swap16_add(swap32_add(a, b), swap32_add(c, d));
   t += dpp_mov<0x128>(t);  // row_ror:8
@@ -106,14 +112,51 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ float wave_reduce4_lds(float a, float b, float c, float d, float* wl) {
+// (the fold alone: on return lane (row r, column c) holds the sum over the four rows of column c, of the value row r is
+//  responsible for — sixteen partial sums per value are left to add up inside the row)
+__device__ __forceinline__ float wave_fold4_lds(float a, float b, float c, float d, float* wl) {
   const int l = lane_id();
   reinterpret_cast<float4*>(wl)[l] = make_float4(a, b, c, d);
   wave_lds_fence();
   const int r = l >> 4, col = l & 15;
   const float* p = wl + 4 * col + (((r & 1) << 1) | (r >> 1));  // row 0 -> a, 1 -> c, 2 -> b, 3 -> d
-  float t = (p[0] + p[64]) + (p[128] + p[192]);                  // lanes col, col + 16, col + 32, col + 48
+  const float t = (p[0] + p[64]) + (p[128] + p[192]);            // lanes col, col + 16, col + 32, col + 48
   wave_lds_fence();
+  return t;
+}
+__device__ __forceinline__ float wave_fold2_lds(float a, float b, float* wl) {  // rows 0, 1 -> a; rows 2, 3 -> b
+  const int l = lane_id();
+  reinterpret_cast<float2*>(wl)[l] = make_float2(a, b);
+  wave_lds_fence();
+  const int r = l >> 4, col = l & 15;
+  const float* p = wl + 2 * col + (r >> 1);
+  const float t = (p[0] + p[32]) + (p[64] + p[96]);
+  wave_lds_fence();
+  return t;
+}
+// In-row sums of THREE folded registers in 7 DPP operations instead of 12: after the first halving (row_ror:8) a register
+// only needs eight lanes of each row, after the second four — the free lanes take the next register.  row_ror:n moves data
+// towards higher lanes (lane i receives lane i - n of its row, like row_shr), so after `m += row_ror:4(m)` the lanes 4-7
+// of a row hold t0's four partial sums and the lanes 12-15 t1's; t2 goes into the lanes 0-3; two quad permutes finish.
+// On return the lanes with (lane & 12) == 4 hold the row sum of t0, == 12 that of t1, == 0 that of t2.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {  // quad_perm, all lanes
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sums3(float t0, float t1, float t2, bool in_hi8, bool in_0to3) {
+  const float u0 = t0 + dpp_mov<0x128>(t0);  // row_ror:8: period 8 inside the row from here on
+  const float u1 = t1 + dpp_mov<0x128>(t1);
+  const float u2 = t2 + dpp_mov<0x128>(t2);
+  float m = in_hi8 ? u1 : u0;                // lanes 0-7: t0, lanes 8-15: t1
+  m += dpp_mov<0x124>(m);                    // row_ror:4: complete in lanes 4-7 (t0) and 12-15 (t1)
+  const float v2 = u2 + dpp_mov<0x124>(u2);  // period 4: complete everywhere
+  m = in_0to3 ? v2 : m;                      // lanes 0-3: t2
+  m += dpp_quad<0x4E>(m);                    // quad_perm [2,3,0,1]
+  m += dpp_quad<0xB1>(m);                    // quad_perm [1,0,3,2]
+  return m;
+}
+__device__ __forceinline__ float wave_reduce4_lds(float a, float b, float c, float d, float* wl) {
+  float t = wave_fold4_lds(a, b, c, d, wl);
   t += dpp_mov<0x128>(t);  // row_ror:8
   t += dpp_mov<0x124>(t);  // row_ror:4
   t += dpp_mov<0x122>(t);  // row_ror:2
@@ -122,13 +165,7 @@ __device__ __forceinline__ float wave_reduce4_lds(float a, float b, float c, flo
 }
 // rows 0 and 1 hold sum(a), rows 2 and 3 sum(b) (wave_reduce2's contract — row 1: a, row 3: b — is contained)
 __device__ __forceinline__ float wave_reduce2_lds(float a, float b, float* wl) {
-  const int l = lane_id();
-  reinterpret_cast<float2*>(wl)[l] = make_float2(a, b);
-  wave_lds_fence();
-  const int r = l >> 4, col = l & 15;
-  const float* p = wl + 2 * col + (r >> 1);
-  float t = (p[0] + p[32]) + (p[64] + p[96]);
-  wave_lds_fence();
+  float t = wave_fold2_lds(a, b, wl);
   t += dpp_mov<0x128>(t);
   t += dpp_mov<0x124>(t);
   t += dpp_mov<0x122>(t);
