@@ -50,6 +50,17 @@ __device__ __forceinline__ bool ref_survives(int rank) {
   }
 }
 
+// lanes (lane & 15) that hold a total of one of the first `ntri` merged triples of groups (row_sums3, see the kernel)
+__device__ __forceinline__ constexpr bool triple_lane(int lg, int ntri) {
+  return ((lg & 12) == 4 || (lg & 12) == 12 || (lg & 12) == 0) && (lg & 3) < ntri;
+}
+
+__device__ __forceinline__ constexpr bool own_lanes_clear(int first, int end, int ntri) {
+  for (int lg = first; lg < end; ++lg)
+    if (triple_lane(lg, ntri)) return false;
+  return true;
+}
+
 constexpr int BWD_BATCH = 128;
 #ifndef OLSR_BWD_LDS_REDUCE
 #define OLSR_BWD_LDS_REDUCE 1  // fold the lanes of the per-splat sums through LDS (olsr_device.h) instead of permlane swaps
@@ -96,8 +107,13 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   // 0.567 -> 0.602 ms) or the seven exchanges of the exact mode's 25 values cost more than the swaps (-1.7 %).
   constexpr bool LDSR = (OLSR_BWD_LDS_REDUCE != 0) && REF && (F <= 16);
   // The reference mode's three folded registers (two groups of four values + the pair) share one in-row reduction
-  // (row_sums3: 7 DPP operations instead of 12), whichever way they were folded
-  constexpr bool MERGED = REF && NG4 == 2 && REM == 2;
+  // (row_sums3: 7 DPP operations instead of 12), whichever way they were folded ...
+  constexpr bool MERGED = NG4 == 2 && REM == 2;  // (NV = 10: the reference mode, and the exact mode without language)
+  // ... and so do, three at a time, the groups of four of the other instantiations (exact mode, F = 15: six groups = two
+  // triples + one value on its own).  Triple j leaves its totals in the lanes (lane & 15) == 4 + j, 12 + j and j.
+  constexpr int NTRI = MERGED ? 0 : NG4 / 3;
+  static_assert(NTRI <= 4 && NG4 + 1 <= 16 && own_lanes_clear(3 * NTRI, NG4 + (REM ? 1 : 0), NTRI),
+                "the lanes of the groups reduced on their own must stay clear of the triples' lanes");
   __shared__ __attribute__((aligned(16))) float s_red[LDSR ? NWV * 256 : 4];  // 1 KB per wave: the exchange
 
   // workgroup b runs on XCD b % 8 and takes the (b / 8)-th heaviest tile of that XCD's chunk
@@ -172,7 +188,15 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
     // (the pair: the LDS fold leaves a in rows 0-1 and b in rows 2-3, the swap fold a in row 0 and b in row 2)
     if (lg == 0 && (lr & 1) == (LDSR ? 1 : 0)) role = 8 + (lr >> 1);
   } else {
-    if (lg < NG4) role = 4 * lg + (((lr & 1) << 1) | (lr >> 1));
+    const int perm = ((lr & 1) << 1) | (lr >> 1);
+#pragma unroll
+    for (int j = 0; j < NTRI; ++j) {
+      if (lg == 4 + j) role = 4 * (3 * j) + perm;
+      if (lg == 12 + j) role = 4 * (3 * j + 1) + perm;
+      if (lg == j) role = 4 * (3 * j + 2) + perm;
+    }
+    // groups on their own and the left-over pair: the lanes 3 NTRI .. (clear of 0..NTRI-1, 4.., 12.. — checked below)
+    if (lg >= 3 * NTRI && lg < NG4 && !triple_lane(lg, NTRI)) role = 4 * lg + perm;
     if (REM > 0 && lg == NG4 && (lr & 1)) role = 4 * NG4 + (lr >> 1);
   }
   if (role >= NV) role = -1;
@@ -404,7 +428,16 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
         }
       } else {
 #pragma unroll
-        for (int g = 0; g < NG4; ++g) {
+        for (int j = 0; j < NTRI; ++j) {
+          const int g = 3 * j;
+          const float t0 = wave_fold4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
+          const float t1 = wave_fold4(sum[4 * g + 4], sum[4 * g + 5], sum[4 * g + 6], sum[4 * g + 7]);
+          const float t2 = wave_fold4(sum[4 * g + 8], sum[4 * g + 9], sum[4 * g + 10], sum[4 * g + 11]);
+          const float red = row_sums3(t0, t1, t2, in_hi8, in_0to3);
+          rowval = ((lg & 3) == j) ? red : rowval;  // (own-group lanes below overwrite theirs)
+        }
+#pragma unroll
+        for (int g = 3 * NTRI; g < NG4; ++g) {
           const float red = wave_reduce4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
           rowval = (lg == g) ? red : rowval;
         }
