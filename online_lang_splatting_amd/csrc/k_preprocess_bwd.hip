@@ -293,6 +293,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
   const int width = 11 + 3 * M + F_out;  // floats per Gaussian in the gradient bucket
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bool has_rows = false;  // this Gaussian has at least one partial-gradient row (else every gradient of it is an exact zero)
   if (r < P) {
     const u32 idx = (u32)r;
     const bool vis = radii[idx] > 0;
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     for (int v = 0; v < NVAL; ++v) acc[v] = 0.f;
     const u32 ntiles_g = vis ? tiles_touched[idx] : 0u;  // (a Gaussian listed in no tile has no rows: all zeros)
     if (ntiles_g > OLSR_MID_FOOTPRINT) {
+      has_rows = true;  // (not looked up: listed Gaussians are few)
       if (counters[7] == 0) {  // summed by row_reduce_big_kernel
         const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
       const u32 u0 = inst_start[idx];
       const u32 first = rowbase[u0], nrows = rowbase[u0 + ntiles_g] - first;
       for (u32 t = 0; t < nrows; ++t) add_row<F, NVAL>(rows, first + t, acc);
+      has_rows = nrows > 0;
     }
     // bucket row of this Gaussian, staged in LDS: a lane's 116-byte row would be 29 scattered 4-byte stores,
     // the block's rows together are one contiguous span that is written (or added) coalesced at the end
@@ -593,10 +596,29 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     const int g0 = blockIdx.x * PB_THREADS;
     const int count = min(PB_THREADS, P - g0) * width;
     float* out = bucket_flat + (size_t)g0 * width;
-    if (bucket_assign)
+    if (bucket_assign) {
       for (int e = threadIdx.x; e < count; e += PB_THREADS) out[e] = s_bucket[e];
-    else
-      for (int e = threadIdx.x; e < count; e += PB_THREADS) out[e] += s_bucket[e];
+    } else {
+      // Adding a later view of the step.  Saturation leaves most Gaussians of a view without a single gradient row
+      // (config 3: 98 % of the visible ones), and adding their zero rows would read and write the whole bucket for
+      // nothing: where at most a quarter of the block's Gaussians have rows, each of those adds its own row (a lane per
+      // row: uncoalesced, but few); denser blocks keep the coalesced pass over all rows.
+      __shared__ u32 s_nrows_blk;
+      if (threadIdx.x == 0) s_nrows_blk = 0;
+      __syncthreads();
+      const u64 hm = ballot(has_rows);
+      if (lane_id() == 0 && hm != 0ull) atomicAdd(&s_nrows_blk, (u32)__popcll(hm));
+      __syncthreads();
+      if (4u * s_nrows_blk <= (u32)PB_THREADS) {
+        if (has_rows) {
+          float* o = out + (size_t)threadIdx.x * width;
+          const float* b = s_bucket + (size_t)threadIdx.x * width;
+          for (int k = 0; k < width; ++k) o[k] += b[k];
+        }
+      } else {
+        for (int e = threadIdx.x; e < count; e += PB_THREADS) out[e] += s_bucket[e];
+      }
+    }
   }
 
   // deterministic block partial of tau (fixed butterfly order, then waves in order)
