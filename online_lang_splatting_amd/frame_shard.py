@@ -154,39 +154,39 @@ class GradientBucket:
 
     # ---- sparse exchange (the parity-preserving half) ------------------------------
     def sparse_all_reduce(self, group=None):
-        """Exchange only the rows of Gaussians that at least one rank saw (densify[:, 1] > 0 somewhere): every other
-        row is zero on every rank, so its sum is the zero it already holds.  Step 1: all-reduce (MAX) of the per-rank
-        visibility BITMASKS (P / 8 bytes); step 2: all-reduce (SUM) of the packed [n_active, width + 2] rows
-        (gradients + the two densification statistics); step 3: unpack.  Same values as all_reduce().
+        """Exchange only the gradient rows that are non-zero on at least one rank: every other row is zero everywhere, so
+        its sum is the zero it already holds.  Saturation ends most tile lists early, so only the front layer of Gaussians
+        receives gradients at all (config 3: 2 % of the visible ones per view) — far fewer rows than the ones a rank merely
+        SAW, which is what round 2 exchanged.  Step 1: all-gather of the per-rank BITMASKS of non-zero rows (P / 8 bytes);
+        step 2: all-reduce (SUM) of the packed [n_active, width] rows; step 3: the small side buffers — the two
+        densification statistics (SUM, [P, 2]) and max_radii (MAX, [P]) — dense.  Same values as all_reduce().
         Returns dict(active_rows, bytes_dense, bytes_sparse) — the bytes each rank contributes to the wire."""
         import torch.distributed as dist
         P, width = self.flat.shape
         dense_bytes = self.sum_storage.numel() * 4 + self.max_radii.numel() * 4
+        nonzero = (self.flat != 0).any(dim=1)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-            return dict(active_rows=int((self.densify[:, 1] > 0).sum()), bytes_dense=dense_bytes, bytes_sparse=0)
+            return dict(active_rows=int(nonzero.sum()), bytes_dense=dense_bytes, bytes_sparse=0)
         world = dist.get_world_size(group)
-        seen = self.densify[:, 1] > 0
         nb = (P + 7) // 8
-        bits = torch.zeros(nb * 8, dtype=torch.uint8, device=seen.device)
-        bits[:P] = seen
-        weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=seen.device)
+        bits = torch.zeros(nb * 8, dtype=torch.uint8, device=nonzero.device)
+        bits[:P] = nonzero
+        weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=nonzero.device)
         mine = (bits.view(nb, 8).to(torch.int32) * weights).sum(dim=1).to(torch.uint8)       # P / 8 bytes
-        every = torch.empty(world * nb, dtype=torch.uint8, device=seen.device)
+        every = torch.empty(world * nb, dtype=torch.uint8, device=nonzero.device)
         dist.all_gather_into_tensor(every, mine, group=group)                                 # bitmasks of all ranks
         union = every.view(world, nb)[0].clone()
         for r in range(1, world):
             union |= every.view(world, nb)[r]
-        anyseen = ((union.view(nb, 1).to(torch.int32) // weights) % 2).reshape(-1)[:P]
-        idx = torch.nonzero(anyseen, as_tuple=False).reshape(-1)           # identical on every rank, ascending
-        packed = torch.cat([self.flat.index_select(0, idx), self.densify.index_select(0, idx)], dim=1)
+        anyrow = ((union.view(nb, 1).to(torch.int32) // weights) % 2).reshape(-1)[:P]
+        idx = torch.nonzero(anyrow, as_tuple=False).reshape(-1)            # identical on every rank, ascending
+        packed = self.flat.index_select(0, idx)
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-        self.flat.index_copy_(0, idx, packed[:, :width])
-        self.densify.index_copy_(0, idx, packed[:, width:])
-        radii = self.max_radii.index_select(0, idx)
-        dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
-        self.max_radii.index_copy_(0, idx, radii)
+        self.flat.index_copy_(0, idx, packed)
+        dist.all_reduce(self.densify, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
         return dict(active_rows=int(idx.numel()), bytes_dense=dense_bytes,
-                    bytes_sparse=int(nb + idx.numel() * ((width + 2) * 4 + 4)))
+                    bytes_sparse=int(nb + idx.numel() * width * 4 + P * 12))
 
 
 class FusedAdam:
@@ -386,7 +386,7 @@ class FrameShardedStep:
                         owns, steps Adam on those rows only (`optimizer_step`), and the updated parameter rows are
                         all-gathered — 2 x (G-1)/G of the PARAMETER bytes + (G-1)/G of the gradient bytes per GPU,
                         all of it spread over the G-1 direct xGMI links;
-      "sparse"          all-reduce of the rows of Gaussians some rank saw (GradientBucket.sparse_all_reduce).
+      "sparse"          all-reduce of the gradient rows that are non-zero on some rank (GradientBucket.sparse_all_reduce).
     A capacity overflow on ANY rank (instances or gradient rows: that view contributed zeros) is surfaced: the
     per-rank flag travels with the MAX all-reduce and `run` raises OverflowError on every rank, with the capacity
     that would have sufficed, so the caller can regrow its workspace and repeat the step."""

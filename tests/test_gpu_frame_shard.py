@@ -99,7 +99,9 @@ def test_two_ranks_equal_the_single_process_sum(hip):
             assert torch.equal(res[m][f"flat{r}"], flat), (m, r)
             assert torch.equal(res[m][f"densify{r}"], densify) and torch.equal(res[m][f"radii{r}"], radii), (m, r)
     w = res["sparse"]["wire0"]
-    assert w["active_rows"] == int((densify[:, 1] > 0).sum()) and w["bytes_sparse"] < w["bytes_dense"]
+    # the sparse exchange carries the gradient rows that are non-zero somewhere: a subset of the Gaussians some view saw
+    assert w["active_rows"] == int((flat != 0).any(1).sum()) <= int((densify[:, 1] > 0).sum())
+    assert w["bytes_sparse"] < w["bytes_dense"]
     for r in range(2):  # owner-applies: the rows a rank owns hold the total
         r0, r1 = res["reduce_scatter"][f"owned{r}"]
         assert torch.equal(res["reduce_scatter"][f"flat{r}"][r0:r1], flat[r0:r1])
