@@ -532,6 +532,30 @@ def views_mode(a, sc, dev, rank, world, dist):
                        "wire": step.wire}}), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this command under torch.distributed.run, one rank per
+    GPU on this node (rendezvous on 127.0.0.1, a free port), and pass its output through.  Over RCCL this needs N GPUs:
+    checked here, before anything is started, so that a SCALE run on too small a node fails instead of reporting one GPU."""
+    import socket
+    import subprocess
+    backend = os.environ.get("OLSR_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} over RCCL needs {n} GPUs, this node shows {have} (OLSR_BENCH_BACKEND=gloo lets ranks "
+              "share a device - a functional check only)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+          [x for x in sys.argv[1:] if x != "--self-launch"]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -551,21 +575,36 @@ def main():
                     help="mapping-iteration mode: every step renders this many viewpoints in total, view v on rank v mod N "
                          "(BackEnd.map renders 12, utils/slam_backend.py:510-670), then ONE exchange of the bucket; "
                          "0 (default): one view per rank per step, weak scaling")
-    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter", "sparse"],
-                    help="--views mode: how the shared-Gaussian gradients travel (frame_shard.FrameShardedStep)")
+    ap.add_argument("--exchange", default="sparse", choices=["all_reduce", "reduce_scatter", "sparse"],
+                    help="how the shared-Gaussian gradients travel when N > 1.  sparse (default): only the rows that are "
+                         "non-zero on some rank (2 %% of the rows of a config-3 view) - capacity-bound and sync-free in the "
+                         "default weak-scaling mode, exact in --views mode; all_reduce: the whole bucket; reduce_scatter: "
+                         "two direct phases over all xGMI links (with --views: owner-applies Adam in between)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (N > 1 does so by itself when "
+                         "WORLD_SIZE is not set)")
     ap.add_argument("--setup-steps", type=int, default=40, help="untimed frames before the W warm-up steps (steady state)")
     ap.add_argument("--isolated-steps", type=int, default=30, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.self_launch):
+        sys.exit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one process per GPU over RCCL ("nccl" on ROCm).  OLSR_BENCH_BACKEND=gloo exists only to exercise the N > 1
         # code path on a box with fewer GPUs than ranks (ranks then share devices; the numbers mean nothing).
         backend = os.environ.get("OLSR_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows "
+                             f"{torch.cuda.device_count()} (OLSR_BENCH_BACKEND=gloo lets ranks share a device - a functional "
+                             "check only)")
         if backend != "nccl":
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
@@ -615,6 +654,18 @@ def main():
 
     pending = {}  # bucket id -> outstanding all-reduce handles of that lane's previous frame
     step_done = []  # one event per step of the current timed region, recorded on the step's stream
+    sparse_cap = [0]  # rows of the capacity-bound sparse exchange (sized below, from the measured row sparsity)
+
+    def exchange(bucket):
+        """The step's one exchange of the shared-Gaussian gradients, enqueued on the lane's stream (no host sync)."""
+        if dist is None:
+            return
+        if a.exchange == "all_reduce":
+            pending[id(bucket)] = bucket.all_reduce(async_op=True)
+        elif a.exchange == "sparse":
+            bucket.sparse_all_reduce_capped(sparse_cap[0])
+        else:
+            bucket.reduce_scatter_all_gather(rank, world)
 
     def one_step(lane, record=False):
         # every rank renders exactly one view per step (weak scaling): its own
@@ -629,7 +680,7 @@ def main():
             # gradients go straight into the flat bucket (what a mapping step consumes): dL_dmeans3D, dL_dsh,
             # dL_dopacity, dL_dscales, dL_drotations, dL_dlanguage + densification statistics + dL_dtau_sum
             ws.backward(dc, dl, dd, bucket=bucket, first=True, bucket_only=True)
-            pending[id(bucket)] = bucket.all_reduce(async_op=True)
+            exchange(bucket)
             if record:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(stream)
@@ -682,6 +733,19 @@ def main():
     # Setup, untimed: every lane runs a few frames so that allocations, code objects, the tile-order hints and the clocks
     # are in their steady state before the contract's W warm-up and K timed steps (with K = 20 the timed region is ~10 ms,
     # and it used to swing by +-8 % with what happened to precede it)
+    active_rows = None
+    if dist is not None:
+        # row sparsity of this workload: saturation ends most tile lists early, so only the front layer of Gaussians
+        # receives any gradient.  One frame per rank, rows counted, MAX over the ranks -> capacity of the packed buffer
+        # (the union over the ranks holds at most world x that many rows; 25 % head-room)
+        ws_, bucket_, stream_ = lanes.lanes[0]
+        ws_.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
+        ws_.forward()
+        ws_.backward(dc, dl, dd, bucket=bucket_, first=True, bucket_only=True)
+        nz = (bucket_.flat != 0).any(dim=1).sum().to(torch.int64).reshape(1)
+        dist.all_reduce(nz, op=dist.ReduceOp.MAX)
+        active_rows = int(nz.item())
+        sparse_cap[0] = min(P, int(1.25 * world * active_rows) + 4096)
     for _ in range(a.setup_steps):
         one_step(lanes.next_lane())
     for lane_ in lanes.lanes:
@@ -696,6 +760,15 @@ def main():
         iso = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
         prof = timed(a.isolated_steps, 3, lambda: lanes.lanes[0], profile=True)
     ws0 = lanes.lanes[0][0]
+    exch_detail = None
+    if dist is not None:
+        b0 = lanes.lanes[0][1]
+        exch_detail = {"bucket_bytes": b0.sum_storage.numel() * 4 + P * 4, "gradient_rows": P,
+                       "rows_nonzero_per_view_max_over_ranks": active_rows}
+        if a.exchange == "sparse":
+            stt = torch.stack([lane_[1]._capped["status"] for lane_ in lanes.lanes if getattr(lane_[1], "_capped", None)])
+            exch_detail.update({"packed_capacity_rows": sparse_cap[0], "rows_in_union_last_step": int(stt[:, 0].max()),
+                                "overflow": bool(int(stt[:, 1].max()))})
     Rr, overflow = ws0.rendered()
     # the reference's num_rendered (bounding-square instances) of this view: the R of the byte model
     R_ref = int(_C.state_field("geometry", ws0.geom, "counters", P=P, F=F, dtype=torch.int32, count=8)[3])
@@ -761,6 +834,11 @@ def main():
                        "P": P, "width": W, "height": H, "F": F, "R": R_ref, "R_over_P": round(R_ref / max(P, 1), 3),
                        "binning": a.binning, "R_binned": Rr, "forward_accumulation": a.fwd_accum,
                        "views_per_step": world, "parallelism": f"frame-shard x{world}",
+                       "rccl_ranks": world if backend == "nccl" else 0, "backend": backend,
+                       "exchange": a.exchange if world > 1 else None,
+                       "exchange_bytes_per_step": None if world == 1 else
+                       lanes.lanes[0][1].exchange_bytes(a.exchange, sparse_cap[0]),
+                       "exchange_detail": exch_detail,
                        "frames_in_flight_per_gpu": len(lanes), "untimed_setup_steps": a.setup_steps,
                        "live_gradient_rows": L_rows,
                        "capacity_overflow": bool(overflow or row_overflow)},

@@ -58,13 +58,26 @@ class GradLayout:
 class GradientBucket:
     """Flat [P, width] fp32 gradient buffer + the side buffers of the densification bookkeeping."""
 
+    # True: issue the collectives also in a group of ONE rank (they are identities there).  Only tests set it: it lets a
+    # one-GPU box execute every RCCL call of the exchanges (dtype / op / shape support of the "nccl" backend).
+    exchange_single_rank = False
+
+    @classmethod
+    def _multi(cls, group=None):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(group) > 1 or cls.exchange_single_rank
+
     def __init__(self, P, layout: GradLayout, device):
         self.layout = layout
         # one storage for everything that is SUM-reduced, so the step's exchange is a single large all-reduce
         # (+ one small MAX all-reduce): [P x width gradients | P x 2 densification statistics]
-        off = (P * layout.width + 3) // 4 * 4  # keep the statistics 16-byte aligned
+        # (row P is a spare row that stays zero: the fill target of the capacity-bound sparse exchange)
+        off = ((P + 1) * layout.width + 3) // 4 * 4  # keep the statistics 16-byte aligned
         self.sum_storage = torch.zeros(off + 2 * P, dtype=torch.float32, device=device)
         self.flat = self.sum_storage[: P * layout.width].view(P, layout.width)
+        self.flat_ext = self.sum_storage[: (P + 1) * layout.width].view(P + 1, layout.width)
         # xyz_gradient_accum, denom (gaussian_model.py:965-969): sum-reducible once the norm is taken per view
         self.densify = self.sum_storage[off:off + 2 * P].view(P, 2)
         self.max_radii = torch.zeros(P, dtype=torch.int32, device=device)  # max-reducible
@@ -115,7 +128,7 @@ class GradientBucket:
         written again): the collective then overlaps whatever the issuing stream does next — e.g. the forward
         of this lane's next frame, which does not touch the bucket."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not self._multi(group):
             return []
         works = [dist.all_reduce(self.sum_storage, op=dist.ReduceOp.SUM, group=group, async_op=async_op),
                  dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group, async_op=async_op)]
@@ -136,7 +149,7 @@ class GradientBucket:
         import torch.distributed as dist
         P, width = self.flat.shape
         r0, r1 = self.owned_rows(P, rank, world)
-        if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        if not self._multi(group):
             return r0, r1
         if dist.get_backend(group) == "nccl":
             per = (P + world - 1) // world
@@ -152,6 +165,27 @@ class GradientBucket:
         dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
         return r0, r1
 
+    def reduce_scatter_all_gather(self, rank, world, group=None):
+        """The dense all-reduce in two direct phases: reduce-scatter of the gradient rows (rank r receives the total of
+        the rows it owns), then all-gather of those totals — every rank ends with the full sum, like all_reduce(), but each
+        phase sends 1/G of the buffer to every peer concurrently over the G-1 direct xGMI links instead of around rings.
+        (With an optimiser the second phase carries the updated PARAMETER rows instead: FrameShardedStep.optimizer_step.)"""
+        import torch.distributed as dist
+        P, width = self.flat.shape
+        r0, r1 = self.reduce_scatter(rank, world, group)
+        if not self._multi(group) or dist.get_backend(group) != "nccl":
+            return r0, r1  # (gloo: reduce_scatter() already all-reduced)
+        per = (P + world - 1) // world
+        if per * world == P:
+            dist.all_gather_into_tensor(self.flat, self.flat[r0:r1].clone(), group=group)
+        else:
+            mine = self.flat.new_zeros(per, width)
+            mine[: r1 - r0] = self.flat[r0:r1]
+            full = self.flat.new_empty(per * world, width)
+            dist.all_gather_into_tensor(full, mine, group=group)
+            self.flat.copy_(full[:P])
+        return r0, r1
+
     # ---- sparse exchange (SURVEY.md section 8(f) row 2, the parity-preserving half) ------------------------------
     def sparse_all_reduce(self, group=None):
         """Exchange only the gradient rows that are non-zero on at least one rank: every other row is zero everywhere, so
@@ -165,7 +199,7 @@ class GradientBucket:
         P, width = self.flat.shape
         dense_bytes = self.sum_storage.numel() * 4 + self.max_radii.numel() * 4
         nonzero = (self.flat != 0).any(dim=1)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not self._multi(group):
             return dict(active_rows=int(nonzero.sum()), bytes_dense=dense_bytes, bytes_sparse=0)
         world = dist.get_world_size(group)
         nb = (P + 7) // 8
@@ -187,6 +221,55 @@ class GradientBucket:
         dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
         return dict(active_rows=int(idx.numel()), bytes_dense=dense_bytes,
                     bytes_sparse=int(nb + idx.numel() * width * 4 + P * 12))
+
+    def sparse_all_reduce_capped(self, capacity, group=None):
+        """The sparse exchange WITHOUT a host synchronisation, for callers that keep several frames in flight
+        (bench.py's weak-scaling mode): the packed buffer has a fixed `capacity` of rows instead of the exact count.
+        Step 1: all-reduce (MAX) of the per-rank byte masks of non-zero rows (P bytes) - afterwards every rank holds the
+        same union; step 2: the union's rows are packed in ascending order into [capacity, width] (unused slots point at
+        the spare zero row P), all-reduced (SUM) and scattered back; step 3: the side buffers, dense.  Everything is
+        enqueued on the current stream.  Returns a device int32[2] {rows in the union, overflow flag}: with more than
+        `capacity` rows in the union only the first `capacity` of them were exchanged - the step's gradients are then
+        incomplete and the caller must repeat it with a larger capacity (or densely), the same contract as an instance
+        overflow of olsr_forward_async.  Same values as all_reduce() otherwise."""
+        import torch.distributed as dist
+        P, width = self.flat.shape
+        cap = int(capacity)
+        dev = self.flat.device
+        st = getattr(self, "_capped", None)
+        if st is None or st["cap"] != cap:
+            st = dict(cap=cap, idx=torch.empty(cap + 1, dtype=torch.int64, device=dev),
+                      packed=torch.empty(cap, width, dtype=torch.float32, device=dev),
+                      arange=torch.arange(P, dtype=torch.int64, device=dev),
+                      status=torch.zeros(2, dtype=torch.int32, device=dev))
+            self._capped = st
+        multi = self._multi(group)
+        mask = (self.flat != 0).any(dim=1).to(torch.uint8)
+        if multi:
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)       # the union, identical on every rank
+        pos = torch.cumsum(mask, 0, dtype=torch.int32)                     # 1-based rank of every row of the union
+        slot = torch.where((mask != 0) & (pos <= cap), pos - 1, cap).to(torch.int64)
+        st["idx"].fill_(P)
+        st["idx"].scatter_(0, slot, st["arange"])                          # (slot `cap` collects the rows left out)
+        idx = st["idx"][:cap]
+        torch.index_select(self.flat_ext, 0, idx, out=st["packed"])
+        if multi:
+            dist.all_reduce(st["packed"], op=dist.ReduceOp.SUM, group=group)
+            self.flat_ext.index_copy_(0, idx, st["packed"])                # (fill slots write zeros to the spare row)
+            dist.all_reduce(self.densify, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
+        st["status"][0:1] = pos[-1:]
+        st["status"][1:2] = (pos[-1:] > cap).to(torch.int32)
+        return st["status"]
+
+    def exchange_bytes(self, exchange, capacity=None):
+        """Payload bytes one rank hands to the collectives of one step, by exchange mode (the wire volume per GPU is
+        this times the algorithm's factor, e.g. 2 (G-1)/G for a ring all-reduce)."""
+        P, width = self.flat.shape
+        side = P * 8 + P * 4
+        if exchange == "sparse":
+            return P + int(capacity) * width * 4 + side
+        return self.sum_storage.numel() * 4 + P * 4
 
 
 class FusedAdam:
@@ -424,13 +507,15 @@ class FrameShardedStep:
         mine = views_of_rank(len(cameras), self.rank, self.world)
         L = len(self.lanes)
         used = []
+        # the overflow bookkeeping is cleared on the caller's stream, BEFORE the lanes are ordered behind it: the final fold
+        # below reads every lane's words on that stream, also those of lanes this step gives no view
+        for i in range(L):
+            self._need[i].zero_()
+            self._ovf[i].zero_()
         for i, (ws, bucket, stream) in enumerate(self.lanes):
             st = stream if stream is not None else main
             if st != main:
                 st.wait_stream(main)  # the parameters this step renders from were written on the caller's stream
-            with torch.cuda.stream(st):
-                self._need[i].zero_()
-                self._ovf[i].zero_()
         for n_done, v in enumerate(mine):
             i = n_done % L
             ws, bucket, stream = self.lanes[i]
@@ -467,7 +552,7 @@ class FrameShardedStep:
                 b = self.lanes[i][1]
                 total.sum_storage.add_(b.sum_storage)
                 torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
-        multi = self.world > 1 and dist.is_available() and dist.is_initialized()
+        multi = GradientBucket._multi(self.group)
         if self.exchange == "reduce_scatter":
             self.owned = total.reduce_scatter(self.rank, self.world, self.group)
         elif self.exchange == "sparse":
@@ -495,7 +580,7 @@ class FrameShardedStep:
         results everywhere).  reduce_scatter: this rank updates the rows it owns, then the parameter rows are
         all-gathered so that every rank renders the next step from identical Gaussians."""
         import torch.distributed as dist
-        if self.exchange != "reduce_scatter" or self.world == 1:
+        if self.exchange != "reduce_scatter" or not GradientBucket._multi(self.group):
             adam.step(self.bucket, params, lrs)
             return
         adam.step(self.bucket, params, lrs, rows=self.owned)

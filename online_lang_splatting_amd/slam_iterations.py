@@ -154,6 +154,10 @@ class MappingStep:
         lanes = self.lanes
         dev = lanes.device
         used = []
+        main = torch.cuda.current_stream(dev)
+        for _, _, st in lanes.lanes:  # the parameters (and, the first time, the targets) were written on the caller's stream
+            if st != main:
+                st.wait_stream(main)
         for v, cam in enumerate(self.cameras):
             ws, bucket, stream = lanes.next_lane()
             first = bucket not in used
@@ -166,7 +170,6 @@ class MappingStep:
                 ws.backward(lo["dL_dimage"], lo["dL_dlanguage"] if ws.F > 0 else None, lo["dL_ddepth"], bucket=bucket,
                             first=first, bucket_only=True)
                 self.last_loss = lo["loss"]
-        main = torch.cuda.current_stream(dev)
         for _, _, st in lanes.lanes:
             main.wait_stream(st)
         total = used[0]

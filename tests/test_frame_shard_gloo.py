@@ -108,6 +108,11 @@ def _exchange_worker(rank, world, port, P, M, F, V, mode, ret):
         b.accumulate(g, radii)
     if mode == "sparse":
         ret[f"wire{rank}"] = b.sparse_all_reduce()
+    elif mode.startswith("capped"):
+        ret[f"status{rank}"] = b.sparse_all_reduce_capped(int(mode[6:])).clone()
+        assert float(b.flat_ext[P].abs().max()) == 0.0  # the spare row stays zero
+    elif mode == "rs_ag":
+        b.reduce_scatter_all_gather(rank, world)
     elif mode == "reduce_scatter":
         r0, r1 = b.reduce_scatter(rank, world)
         ret[f"rows{rank}"] = (r0, r1, b.flat[r0:r1].clone())
@@ -184,3 +189,31 @@ def test_eight_ranks_ragged_rows_all_three_exchanges():
     assert covered == list(range(P))
     assert GradientBucket.owned_rows(P, world - 1, world)[1] - GradientBucket.owned_rows(P, world - 1, world)[0] < \
         GradientBucket.owned_rows(P, 0, world)[1]  # the ragged tail
+
+
+def test_capped_sparse_exchange_is_sync_free_and_equals_dense():
+    """The capacity-bound form bench.py's weak-scaling mode uses (no host synchronisation: fixed-size packed buffer, unused
+    slots point at the spare zero row): same result as the dense all-reduce bit for bit while the union fits; with too small
+    a capacity the overflow flag is raised on every rank and exactly the first `capacity` rows of the union were exchanged."""
+    dense = _run_exchange("all_reduce")
+    n_union = int((dense["flat"] != 0).any(1).sum())
+    for cap in (n_union, n_union + 37, 301):
+        r = _run_exchange(f"capped{cap}")
+        assert torch.equal(r["flat"], dense["flat"]) and torch.equal(r["densify"], dense["densify"])
+        assert torch.equal(r["max_radii"], dense["max_radii"])
+        assert r["status0"].tolist() == [n_union, 0] == r["status1"].tolist()
+    small = n_union // 2
+    r = _run_exchange(f"capped{small}")
+    assert r["status0"].tolist() == [n_union, 1] == r["status1"].tolist()
+    rows = torch.nonzero((dense["flat"] != 0).any(1)).reshape(-1)
+    assert torch.equal(r["flat"][rows[:small]], dense["flat"][rows[:small]])        # exchanged
+    assert not torch.equal(r["flat"][rows[small:]], dense["flat"][rows[small:]])    # left with rank 0's partial sums
+
+
+def test_two_phase_all_reduce_equals_all_reduce():
+    dense, two = _run_exchange("all_reduce"), _run_exchange("rs_ag")
+    assert torch.equal(two["flat"], dense["flat"]) and torch.equal(two["densify"], dense["densify"])
+    assert torch.equal(two["max_radii"], dense["max_radii"])
+    eight = _run_exchange("rs_ag", P=301, V=12, world=8)
+    ref = _run_exchange("all_reduce", P=301, V=12, world=8)
+    torch.testing.assert_close(eight["flat"], ref["flat"], rtol=1e-5, atol=1e-5)

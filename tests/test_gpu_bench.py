@@ -102,3 +102,46 @@ def test_mapping_iteration_mode_two_ranks_over_gloo():
         d = _last_json(p.stdout)
         assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["views_per_step"] == 5 and d["value"] > 0
         assert d["config"]["views_of_rank0"] == 3 and d["config"]["exchange"] == exchange
+
+
+def test_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (the flag used to be
+    ignored and the line said n_gpus 1).  Over RCCL that needs two GPUs — on a smaller node it must FAIL, loudly, not
+    report one GPU; OLSR_BENCH_BACKEND=gloo is the functional fallback in which the ranks share the device."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OLSR_BENCH_BACKEND")}
+    args = [sys.executable, "bench.py", "--gpus", "2", "--config", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run(args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    if torch.cuda.device_count() >= 2:
+        assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+        d = _last_json(p.stdout)
+        assert d["n_gpus"] == 2 and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 2
+    else:
+        assert p.returncode != 0 and "needs 2 GPUs" in p.stderr and "{" not in p.stdout
+    for exchange in ("sparse", "all_reduce", "reduce_scatter"):
+        p = subprocess.run(args + ["--exchange", exchange], cwd=ROOT, env=dict(env, OLSR_BENCH_BACKEND="gloo"),
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (exchange, p.stdout[-1500:], p.stderr[-1500:])
+        d = _last_json(p.stdout)
+        c = d["config"]
+        assert d["n_gpus"] == 2 and c["views_per_step"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+        assert c["backend"] == "gloo" and c["rccl_ranks"] == 0 and c["exchange"] == exchange
+        assert c["exchange_bytes_per_step"] > 0 and c["exchange_detail"]["rows_nonzero_per_view_max_over_ranks"] > 0
+        if exchange == "sparse":
+            det = c["exchange_detail"]
+            assert not det["overflow"] and 0 < det["rows_in_union_last_step"] <= det["packed_capacity_rows"]
+            sparse_bytes = c["exchange_bytes_per_step"]
+        else:
+            assert c["exchange_bytes_per_step"] == c["exchange_detail"]["bucket_bytes"]
+    assert sparse_bytes < c["exchange_detail"]["bucket_bytes"]
+
+
+def test_self_launched_single_rank_matches_the_plain_line():
+    """--self-launch: the same command under torch.distributed.run with one rank (what the driver's N = 1 SCALE leg looks
+    like): same workload, same keys, n_gpus 1, no exchange."""
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--self-launch", "--config", "1", "--steps", "6", "--warmup",
+                        "2", "--no-cpu-baseline", "--no-extra-legs"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    d = _last_json(p.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["exchange"] is None and d["config"]["rccl_ranks"] == 0 and d["config"]["backend"] is None

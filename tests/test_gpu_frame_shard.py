@@ -184,3 +184,61 @@ def test_eight_ranks_three_steps_every_exchange(hip):
     for k in res["all_reduce:params0"]:
         for m in ("sparse", "reduce_scatter"):
             torch.testing.assert_close(res[f"{m}:params0"][k], res["all_reduce:params0"][k], rtol=2e-4, atol=2e-5)
+
+
+# ---- RCCL itself: every collective of the exchanges in a group of ONE rank over the "nccl" backend --------------------
+def _rccl_worker(rank, world, port, ret):
+    """A one-GPU box cannot run two RCCL ranks (one device per rank), but it can run ONE: the collectives are identities
+    there, and issuing them proves that every call the exchanges make — dtypes (fp32 SUM, int32 MAX, uint8 MAX), the
+    reduce_scatter_tensor / all_gather_into_tensor shapes incl. the ragged tail, the async handles — is accepted and
+    executed by RCCL on this stack, on the caller's stream, with the result left where the exchange promises it."""
+    from online_lang_splatting_amd.frame_shard import FrameShardedStep, FusedAdam, GradientBucket, GradLayout, RasterWorkspace
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    GradientBucket.exchange_single_rank = True
+    try:
+        sc, g, cams, cot = _inputs(dev, P8, V)   # P8 = 6001: also odd, so every padded path runs
+        M = sc.shs.shape[1]
+        ws = RasterWorkspace(P8, W, H, F, M, 400000, dev)
+        out = {}
+        for exchange in ("all_reduce", "sparse", "reduce_scatter"):
+            st = FrameShardedStep(ws, 0, 1, exchange=exchange)
+            params = {k: v.clone() for k, v in g.items() if k != "bg"}
+            adam = FusedAdam(P8, GradLayout(M, F), dev)
+            bucket = st.run(dict(bg=g["bg"], **params), cams, lambda v, o: cot[v], sh_degree=sc.sh_degree)
+            st.optimizer_step(adam, params, LRS)
+            torch.cuda.synchronize()
+            out[exchange] = (bucket.flat.cpu().clone(), {k: v.cpu() for k, v in params.items()})
+        # the bucket-level forms bench.py's weak-scaling mode uses
+        b = st.bucket
+        before = b.flat.clone()
+        for w_ in b.all_reduce(async_op=True):
+            w_.wait()
+        status = b.sparse_all_reduce_capped(4096).cpu()
+        b.reduce_scatter_all_gather(0, 1)
+        torch.cuda.synchronize()
+        ret["weak_forms_identity"] = bool(torch.equal(b.flat, before))
+        ret["capped_status"] = status.tolist()
+        ret["nonzero_rows"] = int((before != 0).any(1).sum())
+        ret["backend"] = dist.get_backend()
+        ret["same_bucket"] = all(torch.equal(out[m][0], out["all_reduce"][0]) for m in out)
+        ret["same_params"] = all(torch.equal(out[m][1][k], out["all_reduce"][1][k]) for m in out for k in out[m][1])
+        ret["moved"] = not torch.equal(out["all_reduce"][1]["means3D"], g["means3D"].cpu())
+    finally:
+        GradientBucket.exchange_single_rank = False
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_every_exchange_collective_runs_on_rccl_single_rank(hip):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    r = dict(ret)
+    assert r["backend"] == "nccl"
+    assert r["same_bucket"] and r["same_params"] and r["moved"] and r["weak_forms_identity"]
+    assert r["capped_status"] == [r["nonzero_rows"], int(r["nonzero_rows"] > 4096)] and r["nonzero_rows"] > 0
