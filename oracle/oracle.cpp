@@ -1168,6 +1168,17 @@ int64_t oracle_get_field(void* h, const char* name, void* dst) {
 
 float oracle_expf_probe(float x) { return oracle_expf(x); }
 
+// computeCov3D's backward (CR/backward.cu:350-413) on its own, for the gradient goldens generated from the reference's
+// build_covariance_from_scaling_rotation (tests/golden/make_golden_gradients.py): the same function preprocess_backward calls.
+int oracle_cov3d_backward(int32_t P, const float* scales, float scale_modifier, const float* rotations,
+                          const float* dL_dcov3D, float* dL_dscales, float* dL_drotations) {
+  if (P < 0 || !scales || !rotations || !dL_dcov3D || !dL_dscales || !dL_drotations) return OLSR_ERR_ARG;
+  for (int idx = 0; idx < P; ++idx)
+    computeCov3D_backward(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D,
+                          dL_dscales, dL_drotations);
+  return OLSR_OK;
+}
+
 // OpenMP team size of the following calls (bench.py's cpu_baseline: all host cores, and one thread)
 // record, per sorted list position, the 256-bit mask of tile thread ranks that blended it (sensitivity studies)
 void oracle_set_record(int on) { g_record_contrib = on != 0; }

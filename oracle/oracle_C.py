@@ -329,3 +329,15 @@ def distCUDA2(points):
 
 def expf(x):
     return lib().oracle_expf_probe(float(x))
+
+
+def cov3d_backward(scales, scale_modifier, rotations, dL_dcov3D):
+    """computeCov3D backward alone (CR/backward.cu:350-413): (dL_dscales [P,3], dL_drotations [P,4])."""
+    sc, ro, dc = (t.contiguous().float() for t in (scales, rotations, dL_dcov3D))
+    P = sc.shape[0]
+    ds, dr = torch.zeros(P, 3), torch.zeros(P, 4)
+    L = lib()
+    L.oracle_cov3d_backward.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(L.oracle_cov3d_backward(P, sc.data_ptr(), float(scale_modifier), ro.data_ptr(), dc.data_ptr(), ds.data_ptr(),
+                                   dr.data_ptr()), "cov3d_backward")
+    return ds, dr

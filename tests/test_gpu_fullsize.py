@@ -23,8 +23,10 @@ from test_gpu_parity import _check
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the worst single element, in the relative units of parity_common.elementwise_report (1e-4 == within tolerance)
-WORST_BOUND = 2e-2
+# the worst single element, in the relative units of parity_common.elementwise_report (1e-4 == within tolerance):
+# end to end (tensors behind the per-Gaussian chain; measured worst 4.7e-3, config 5 view 2) and — through _check's
+# composite_worst_bound = 2e-4 — at composite level (measured worst 8.1e-5)
+WORST_BOUND = 1e-2
 
 
 def _dump(tag, log):
@@ -73,4 +75,51 @@ def test_config3_exact_backward_against_the_oracle(hip, oracle):
     _check(hip, oracle, make_config_scene(3), seed=13, mode=_abi.BWD_EXACT, elementwise=True,
            worst_bound=WORST_BOUND, log=log)
     _dump("config3_exact", log)
+    torch.cuda.empty_cache()
+
+
+def test_config3_against_the_contract_everywhere_model_of_the_reference(hip, oracle):
+    """Both models of what nvcc makes of the reference are on record every round.  The parity
+    oracle contracts the value accumulation only (fma(f alpha, T, C)) and keeps every decision expression un-contracted; nvcc's
+    default --fmad=true would contract the decision expressions as well.  `liboracle_contract.so` is the same restatement
+    built with -ffp-contract=fast: a proxy for that compiler.  The product cannot be bit-identical to both; against this model
+    it must still meet the north-star tolerance — every image and every composite-level gradient per element (a handful of
+    blend decisions flip: 12 of 54.9 M between the two oracles, profiles/r2_cuda_sensitivity.json), the tensors behind the
+    per-Gaussian chain at >= 99.99 % — and the figures are written to gpurun_out/parity_fullsize.json next to the default
+    model's."""
+    from parity_common import assert_elementwise, elementwise_report, run_backend
+    from test_gpu_parity import COMPOSITE_GRADS, DEV
+    sc = make_config_scene(3)
+    log = []
+    oracle.use_variant("contract_fast")
+    try:
+        assert oracle.lib().oracle_variant().decode() != "default"
+        fo, go = run_backend(oracle, sc, None, 3, 15, _abi.BWD_REFERENCE)
+        fg, gg = run_backend(hip, sc, torch.device(DEV), 3, 15, _abi.BWD_REFERENCE, binning=_abi.BINNING_ELLIPSE)
+        torch.cuda.synchronize()
+        n_rad = int((fg["radii"].cpu() != fo["radii"]).sum())
+        log.append(dict(name="contract:radii_different", n=n_rad))
+        assert n_rad <= 2, n_rad
+        for k in ("color", "language", "depth", "opacity"):
+            got = fg[k].cpu().reshape(fo[k].shape)
+            r = elementwise_report(got, fo[k])
+            r.update(name=f"contract:{k}", elements_not_bit_identical=int((got != fo[k]).sum()))
+            log.append(r)
+            print(r)
+            # a flipped blend decision sits at the alpha floor: it moves a pixel's channel by at most ~(1/255) |feature| T —
+            # isolated elements far outside the relative band but small in absolute terms
+            assert r["frac_within"] >= 0.9999 and r["worst_abs"] <= 1.5 / 255.0 * max(1.0, r["max_ref"]), r
+        for k in go:
+            if go[k].numel():
+                r = elementwise_report(gg[k], go[k])
+                r.update(name=f"contract:{k}")
+                log.append(r)
+                print(r)
+                assert r["frac_within"] >= 0.9999, r
+                assert r["worst_abs"] <= 2e-2 * r["max_ref"], r   # (flips are bounded perturbations, not blow-ups)
+        oracle.release(fo["geom"])
+    finally:
+        oracle.use_variant("default")
+    assert oracle.lib().oracle_variant().decode() == "default"
+    _dump("config3_contract_everywhere_oracle", log)
     torch.cuda.empty_cache()

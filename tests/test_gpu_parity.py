@@ -46,7 +46,7 @@ COMPOSITE_KEYS = COMPOSITE_GRADS
 
 
 def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise=False, worst_bound=1e-2, log=None,
-           chain=True, chain_worst_bound=1e-3, chain_min_fraction=ELEM_MIN_FRACTION, **kw):
+           chain=True, chain_worst_bound=1e-3, chain_min_fraction=ELEM_MIN_FRACTION, composite_worst_bound=2e-4, **kw):
     """Oracle vs the HIP library in both binning modes.
     RECT: images, counters AND the instance lists equal the reference's bit for bit.
     ELLIPSE (the product's default): identical images / radii / n_touched / final_T, gradients to RTOL,
@@ -63,6 +63,7 @@ def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise
     tensor within 1e-4 except ONE element — 6.5e-5 in a tensor whose largest is 1.3e-2 — at 8.5e-4; the suite's own
     scenes: one element of 9 308 at 1.5e-4)."""
     fo, go = run_backend(oracle, sc, None, seed, tile, mode, **kw)
+    assert grad_keys is None or all(k in go for k in grad_keys), [k for k in grad_keys if k not in go]
     fr, gr = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, binning=_abi.BINNING_RECT, **kw)
     fg, gg = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, binning=_abi.BINNING_ELLIPSE, **kw)
     torch.cuda.synchronize()
@@ -86,10 +87,17 @@ def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise
         for k in go:
             if go[k].numel() and (grad_keys is None or k in grad_keys):
                 if elementwise:  # the north-star statement itself: per element, outliers bounded
-                    assert_elementwise(g_[k], go[k], f"{name}:{k}", worst_bound, log)
+                    # composite-level tensors (what the composite kernel produces) are held to a tighter worst element
+                    # than the end-to-end ones behind the per-Gaussian chain
+                    assert_elementwise(g_[k], go[k], f"{name}:{k}",
+                                       composite_worst_bound if k in COMPOSITE_GRADS else worst_bound, log)
                 else:
                     r, e = rel_err(g_[k], go[k])
                     assert r <= RTOL, f"{name}: {k}: rel {r:.2e} abs {e:.2e}"
+                    # the max-norm says nothing about small elements: what the composite kernel produces is also held to
+                    # the north-star criterion per ELEMENT on every scene of the suite
+                    if k in COMPOSITE_GRADS:
+                        assert_elementwise(g_[k], go[k], f"{name}:{k}", composite_worst_bound, log)
         if chain and P:
             gc = oracle.backward_chain(max(F, 0), {k: g_[k] for k in ("dL_dmeans2D", "dL_dconic", "dL_dcolors",
                                                                       "dL_ddepths")}, *fo["bwd_args"])
@@ -415,4 +423,4 @@ def test_depth_sort_fourth_pass_for_far_gaussians(hip, oracle, factor):
     assert float(depths.max()) > 13107.0 * 1.5
     # (the gradients of a scene of this size span 1e-12 .. 1e-2 per tensor: the forward, the lists and the composite-level
     #  gradients are what this test is about)
-    _check(hip, oracle, sc, seed=5, grad_keys=("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dlanguage"))
+    _check(hip, oracle, sc, seed=5, grad_keys=COMPOSITE_GRADS)

@@ -8,7 +8,7 @@ import os
 import pytest
 
 from stress_scenes import random_scene
-from test_gpu_parity import _check
+from test_gpu_parity import COMPOSITE_KEYS, _check
 
 pytestmark = pytest.mark.gpu
 N = int(os.environ.get("OLSR_STRESS_SCENES", "6"))
@@ -22,12 +22,15 @@ def test_random_scene_against_the_oracle(hip, oracle, generation, k):
     try:
         _check(hip, oracle, sc, seed=k, tile=tile, mode=mode, **kw)
     except AssertionError as e:
-        if "not bit-identical" in str(e) or "forward" in str(e):
-            raise
-        print("max-norm breach, re-judged per element:", desc, str(e)[:160])
+        head = str(e)[:120]
+        if "not bit-identical" in head or "forward" in head or ":chain:" in head or any(c in head for c in COMPOSITE_KEYS):
+            raise  # the forward, everything the composite kernel produces and the chain on identical inputs are never re-judged
+        print("max-norm breach behind the per-Gaussian chain, re-judged per element:", desc, str(e)[:160])
+        rejudged = "per element"
         try:
             _check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2, **kw)
         except AssertionError as e2:
+            rejudged = "chain on identical inputs"
             # ~2 % of the campaign's scenes (screen-filling splats, random precomputed covariances): a few elements per
             # 10^4 of the gradients behind the inverse of the 2D covariance leave the band — three terms of order 1e8 cancel
             # there, so the chain amplifies the summation-order noise of its INPUTS (the reference's own float atomics
@@ -38,6 +41,8 @@ def test_random_scene_against_the_oracle(hip, oracle, generation, k):
             print("per-element breach in the covariance chain:", desc, str(e2)[:200])
             # ... and the per-Gaussian chain itself once both sides start from the same composite-level gradients (chain=True,
             # the default of _check: the oracle replays the reference's chain on the product's dL_dconic / dL_dmean2D).
-            from test_gpu_parity import COMPOSITE_KEYS
             _check(hip, oracle, sc, seed=k, tile=tile, mode=mode, elementwise=True, worst_bound=2e-2,
                    grad_keys=COMPOSITE_KEYS, chain=True, **kw)
+        # a re-judged scene is reported, not passed silently: it shows as `x` with its reason
+        pytest.xfail(f"{desc}: end-to-end max-norm breach in the covariance chain, accepted by the weaker criterion "
+                     f"'{rejudged}' ({str(e)[:120]})")
