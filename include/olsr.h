@@ -41,6 +41,19 @@ extern "C" {
 #define OLSR_ERR_ALLOC (-3)    /* allocation callback returned NULL */
 #define OLSR_ERR_CAPACITY (-4) /* async mode: instance count exceeded caller capacity */
 
+/* Device-side status words of the sync-free entries (num_rendered_dev[1] of olsr_forward_async, status_dev[1] of
+ * olsr_backward):  0 = fine;  1 = capacity overflow (instances resp. gradient rows; nothing rendered / zero gradients);
+ * 2 = synchronisation error: a block of the frame's radix passes or of the row compaction waited for a predecessor's counts
+ * until its spin bound ran out — the frame's synchronisation words were overwritten from outside mid-frame.  The library
+ * never hangs on that and never writes out of bounds, but the tile lists are garbage: the forward's images must not be used,
+ * the backward writes zero gradients.  The synchronising olsr_backward (scratch_alloc != NULL) returns OLSR_ERR_DEVICE; for
+ * olsr_forward and for an olsr_backward without status_dev (the reference-shaped bindings) the frame's last kernel raises a
+ * flag in mapped host memory and the FIRST olsr_forward / olsr_backward after the GPU got there returns OLSR_ERR_DEVICE
+ * (once), the way an asynchronous HIP error surfaces. */
+#define OLSR_STATUS_OK 0
+#define OLSR_STATUS_OVERFLOW 1
+#define OLSR_STATUS_SYNC_ERROR 2
+
 /* Backward flavour.  REFERENCE reproduces what the shipped CUDA computes with its
  * 15x15 tiles (CR/config.h:17-18): the 225-lane tree reduction of
  * CR/backward.cu:684-702 keeps 128 of 225 pixel ranks, language gradients come from
@@ -154,6 +167,11 @@ size_t olsr_binning_bytes(int64_t num_rendered, int32_t F);
  * binning).  Outputs: out_color[3,H,W], out_language[F,H,W] (ignored when F == 0),
  * out_depth[H,W], out_opacity[H,W], radii[P] (int32), n_touched[P] (int32).
  * *num_rendered receives R, the number of (Gaussian, tile) instances. */
+/* Process-wide state olsr_forward keeps (results never depend on it; tested): per (device, stream, tile count) the previous
+ * frame's heaviest-first tile order (a launch-order hint, a few KB, stream-ordered allocation, at most 64 keys with
+ * least-recently-used eviction, never freed otherwise); a ring of 256 mapped host slots for the gradient-row counts
+ * (olsr_live_rows); two mapped host words per calling thread for the instance count (leaked at thread exit by design: a
+ * thread_local destructor could run after the HIP runtime's teardown). */
 int olsr_forward(const olsr_scene *scene,
                  olsr_alloc_fn geometry_alloc, void *geometry_user,
                  olsr_alloc_fn binning_alloc, void *binning_user,
@@ -164,8 +182,8 @@ int olsr_forward(const olsr_scene *scene,
 
 /* Forward without a host sync: the caller provides all three buffers, the binning
  * buffer sized for `capacity` instances (olsr_binning_bytes(capacity, F)).  R stays on
- * the device; `num_rendered_dev` (device int32[2]) receives {R, overflow_flag}.
- * Nothing is rendered when R > capacity (overflow_flag = 1).  This is the entry the
+ * the device; `num_rendered_dev` (device int32[2]) receives {R, status}: OLSR_STATUS_OK, _OVERFLOW
+ * (nothing is rendered when R > capacity) or _SYNC_ERROR.  This is the entry the
  * benchmark and the frame-sharded trainer use; it has no reference counterpart
  * (SURVEY.md §7 step 8).
  *
@@ -199,7 +217,7 @@ int olsr_forward_async(const olsr_scene *scene,
  *   - scratch_alloc == NULL: `scratch` holds olsr_backward_scratch_bytes(scratch_rows, F) bytes;
  *     no synchronisation.  If L > scratch_rows nothing is written and the overflow is reported
  *     through status_dev.
- * status_dev (device int32[2], may be NULL) receives {L, overflow flag}.
+ * status_dev (device int32[2], may be NULL) receives {L, status}: OLSR_STATUS_OK / _OVERFLOW / _SYNC_ERROR.
  *
  * Cotangents.  dL_dout_color[3,H,W] is required.  dL_dout_language[F,H,W] and dL_dout_depth[H,W] may be NULL: "the loss
  * does not depend on that image" — what autograd hands the reference's backward as None and PyTorch turns into zeros
@@ -356,6 +374,11 @@ int olsr_tracking_loss(const olsr_loss_params *params, const float *image, const
  * and the camera properties the next render reads (utils/camera_utils.py:103-117): world_view_transform = W2C^T,
  * full_proj_transform = world_view_transform @ projection_matrix, camera_center = world_view_transform^-1 [3, :3]
  * — one launch instead of ~40 one-element PyTorch kernels and a host read-back between two dependent renders.
+ * Tolerance: Adam, SE3_exp and the convergence test follow the reference operation for operation; the view matrix is formed
+ * directly as W2C^T, where the reference's Camera goes through getWorld2View2 (gaussian_splatting/utils/graphics_utils.py:
+ * 33-46), which inverts [R|t] twice, and update_pose re-reads R and T from that.  T_w2c and the matrices therefore agree with
+ * the reference to fp32 rounding per iteration (tests/test_gpu_pose.py holds them to 5e-7 x the iteration number), not
+ * bit for bit.
  *   dL_dtau_sum   device float[6] = [rho | theta] as olsr_backward leaves it (rho: gradient of cam_trans_delta,
  *                 theta: of cam_rot_delta), or NULL: no step, only the matrices of the current pose are (re)derived
  *   dL_dexposure  device float[2] from olsr_tracking_loss, or NULL (exposure not optimised)
@@ -406,7 +429,8 @@ int olsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix,
  * f32[P,2], "cov3D" f32[P,6], "conic_opacity" f32[P,4], "rgb" f32[P,3], "clamped"
  * u8[P,3], "tiles_touched" u32[P], "depth_order" u32[P]; binning — "src" u32[R]
  * (sorted position -> emission index), "inst_gid" u32[R] (emission index -> Gaussian id; the
- * reference's point_list is inst_gid[src]), "flags" u8[R], "rowbase" u32[R+1]; image — "final_T" f32[H*W], "n_contrib" u32[H*W], "ranges" u32[tiles,2]. */
+ * reference's point_list is inst_gid[src]), "flags" u8[R], "rowbase" u32[R+1], "row_sync" u32[2] (ticket and done-counter of the
+ * row compaction, zero between kernels); image — "final_T" f32[H*W], "n_contrib" u32[H*W], "ranges" u32[tiles,2]. */
 const void *olsr_geometry_field(const void *geometry_buffer, int32_t P, int32_t F, const char *name);
 const void *olsr_binning_field(const void *binning_buffer, int64_t num_rendered, int32_t F,
                                const char *name);
@@ -431,6 +455,12 @@ void olsr_debug_sort_timing(unsigned long long *device_buffer, int max_blocks, i
  * n keys is launched with (n_is_capacity != 0: n bounds a count only known on the device, see olsr_forward_async), and
  * whether n is sorted by the one-kernel passes at all (return value: 1) or by the multi-kernel fallback (0). */
 int olsr_debug_sort_plan(int64_t n, int n_is_capacity, int32_t *keys_per_thread, int32_t *blocks);
+
+/* Test hook for the synchronisation-error path (OLSR_STATUS_SYNC_ERROR), process-wide.  fault_bits: bit 0 / bit 1 = in every
+ * later forward the block holding ticket 0 of the first depth-sort / tile-sort pass never publishes its digit counts, which is
+ * what its successors see when a status word is lost; spin_limit: polls a look-back makes before it gives up (0 restores the
+ * default, 2^22 — seconds; tests use a few thousand).  A negative argument leaves that knob as it is. */
+void olsr_debug_sync_fault(int fault_bits, int spin_limit);
 
 /* Tuning / test knobs of the radix passes, process-wide.  keys_per_thread in {2, 4, 8, 12, 16} pins the instantiation (0:
  * chosen from the input size); resident_blocks > 0 replaces the 256 blocks a round is planned for; legacy != 0 forces the

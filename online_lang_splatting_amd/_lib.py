@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OLSR_LIB") or os.path.join(_HERE, "libolsr.so")
 EXPORTS = (
     "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_backward_scratch_bytes", "olsr_last_forward_token", "olsr_live_rows", "olsr_forward", "olsr_forward_async",
     "olsr_backward", "olsr_accumulate_gradients", "olsr_mapping_loss", "olsr_mapping_loss_scratch_bytes", "olsr_tracking_loss", "olsr_pose_step", "olsr_knn_mean_dist2", "olsr_knn_scratch_bytes", "olsr_adam_step", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
-    "olsr_set_profiling", "olsr_get_stage_times", "olsr_debug_sort_timing", "olsr_debug_sort_plan", "olsr_debug_sort_knobs", "olsr_live_rows_wait", "olsr_backward_rows", "olsr_last_error", "olsr_version",
+    "olsr_set_profiling", "olsr_get_stage_times", "olsr_debug_sort_timing", "olsr_debug_sort_plan", "olsr_debug_sort_knobs", "olsr_debug_sync_fault", "olsr_live_rows_wait", "olsr_backward_rows", "olsr_last_error", "olsr_version",
 )
 
 _lib = None
@@ -81,6 +81,8 @@ def lib():
     L.olsr_debug_sort_plan.restype = C.c_int
     L.olsr_debug_sort_knobs.argtypes = [C.c_int, C.c_int, C.c_int]
     L.olsr_debug_sort_knobs.restype = None
+    L.olsr_debug_sync_fault.argtypes = [C.c_int, C.c_int]
+    L.olsr_debug_sync_fault.restype = None
     L.olsr_last_error.argtypes, L.olsr_last_error.restype = [], C.c_char_p
     L.olsr_version.argtypes, L.olsr_version.restype = [], C.c_char_p
     _lib = L

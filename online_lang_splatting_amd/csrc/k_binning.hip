@@ -328,13 +328,15 @@ __device__ __forceinline__ u32 lb_load(const u32* p) {
 __device__ __forceinline__ void lb_store(u32* p, u32 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ u32 lb_wait(const u32* p) {
+__device__ __forceinline__ u32 lb_wait(const u32* p, int spin_limit, int32_t* sync_error) {
   u32 v = lb_load(p);
   // (bounded: a predecessor publishes within microseconds; a corrupted state buffer must not hang the GPU)
-  for (int spin = 0; !(v & LB_READY) && spin < (1 << 22); ++spin) {
+  for (int spin = 0; !(v & LB_READY) && spin < spin_limit; ++spin) {
     __builtin_amdgcn_s_sleep(1);
     v = lb_load(p);
   }
+  // it never arrived: the prefix is garbage — mark the frame (the backward then writes zero gradients and reports it)
+  if (!(v & LB_READY)) atomicOr(sync_error, 1);
   return v & ~LB_READY;
 }
 // Sum of the totals of blocks [0, b), for ALL threads of block b (which publishes `total` here).  Blocks take their
@@ -343,13 +345,15 @@ __device__ __forceinline__ u32 lb_wait(const u32* p) {
 // of 64-wide windows costs one per window).  Only beyond THREADS predecessors does a block wait for an inclusive
 // prefix (that of the last block of the previous group of THREADS).
 template <int THREADS>
-__device__ __forceinline__ u32 lb_block_exclusive(u32* status, u32 b, u32 total, u32* s_red /* [THREADS / 64 + 1] */) {
+__device__ __forceinline__ u32 lb_block_exclusive(u32* status, u32 b, u32 total, u32* s_red /* [THREADS / 64 + 1] */,
+                                                  int spin_limit, int32_t* sync_error) {
   const u32 tid = threadIdx.x;
   const u32 first = b & ~(u32)(THREADS - 1);
   if (tid == 0) lb_store(&status[2 * b], LB_READY | total);
   u32 v = 0;
-  if (first + tid < b) v = lb_wait(&status[2 * (first + tid)]);
-  if (tid == THREADS - 1 && first > 0) v += lb_wait(&status[2 * (first - 1) + 1]);  // (first + tid >= b for this thread)
+  if (first + tid < b) v = lb_wait(&status[2 * (first + tid)], spin_limit, sync_error);
+  if (tid == THREADS - 1 && first > 0)  // (first + tid >= b for this thread)
+    v += lb_wait(&status[2 * (first - 1) + 1], spin_limit, sync_error);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   if ((tid & 63) == 0) s_red[tid >> 6] = v;
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
   for (int q = (int)(blockIdx.x * EO_T + threadIdx.x); q < bin_sync_quads; q += (int)(gridDim.x * EO_T))
     bin_sync[q] = make_uint4(0u, 0u, 0u, 0u);
   if (counters[2] != 0) return;  // more instances than the caller's capacity: nothing is emitted (uniform)
+  if (counters[8] != 0) return;  // the depth sort lost a predecessor's counts: its order is garbage, index nothing with it
   const u32 b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r0 = (int)(b * EMIT_CHUNK + threadIdx.x * EO_PER);  // this thread's four consecutive depth ranks
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(EB_T) void emit_balanced_kernel(
   __shared__ uint8_t s_owner[EB_ROWCAP];
   __shared__ u32 s_w[EB_T / 64];
   __shared__ u32 s_flag;
-  if (counters[2] != 0) return;
+  if (counters[2] != 0 || counters[8] != 0) return;
   const u32 R = (u32)counters[1];
   const u32 o0 = blockIdx.x * (u32)EB_OUT;
   if (o0 >= R) return;
@@ -750,7 +755,7 @@ static_assert(ROWS_CHUNK == ROWS_THREADS * 16, "one 16-byte load of flags per th
 __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
     const uint8_t* __restrict__ flags, int64_t n_host, const int32_t* __restrict__ n_dev, int shift, u32 mask,
     u32* __restrict__ rowbase, u32* status, u32* sync /* [0] ticket, [1] finished blocks */,
-    long long row_capacity, int32_t* __restrict__ counters, int32_t* __restrict__ status_dev) {
+    long long row_capacity, int32_t* counters, int32_t* __restrict__ status_dev, int spin_limit) {
   __shared__ u32 s_bid;
   __shared__ u32 s_wsum[ROWS_THREADS / 64 + 1];
   __shared__ u32 s_last;
@@ -762,7 +767,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t n = bounded_n(n_host, n_dev);  // flags beyond the instances of this frame are stale
   const int64_t bbase = (int64_t)b * ROWS_CHUNK;
-  if (bbase <= n) {  // (the block that holds index n writes the total; later blocks have nothing to do)
+  // (a ticket beyond the grid: the ticket word was not the zero the emission left — corrupted from outside)
+  if (b >= gridDim.x && threadIdx.x == 0) atomicOr(&counters[8], 1);
+  if (b < gridDim.x && bbase <= n) {  // (the block that holds index n writes the total; later blocks have nothing to do)
     const int64_t base = bbase + (int64_t)threadIdx.x * 16;
     u32 v[16];
     load_popc16(flags, base, n, shift, mask, v);
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
       total += c;
     }
     __syncthreads();
-    const u32 pre = lb_block_exclusive<ROWS_THREADS>(status, b, total, s_wsum);
+    const u32 pre = lb_block_exclusive<ROWS_THREADS>(status, b, total, s_wsum, spin_limit, &counters[8]);
     u32 run = pre + wbase + incl - sum;
     // (static indices only: a dynamically indexed private array would be promoted to 64 KB of LDS)
     u32 L = 0;
@@ -845,7 +852,8 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
   const int nb = (int)((n_host + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK);  // index n itself belongs to a block
   row_compaction_kernel<<<nb, ROWS_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, rowbase,
                                                      row_status, sync,
-                                                     (long long)row_capacity, counters, status_dev);
+                                                     (long long)row_capacity, counters, status_dev,
+                                                     sort_knobs().spin_limit.load(std::memory_order_relaxed));
 }
 
 // ------------------------------------------------------------------------------- ranges
@@ -917,8 +925,15 @@ __device__ __forceinline__ void sum_and_post_live_rows(u32 a, u32 b, u32 nblocks
 
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
                                                          u32* __restrict__ order_copy, int ntiles,
-                                                         u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq) {
+                                                         u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq,
+                                                         const int32_t* __restrict__ counters,
+                                                         int32_t* __restrict__ num_rendered_dev, int32_t* sticky) {
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
+  // the forward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && counters[8] != 0) {
+    if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
+    if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int x = blockIdx.x;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
@@ -966,8 +981,13 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
 __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __restrict__ work, u32* __restrict__ order,
                                                                   u32* __restrict__ order_copy, int ntiles,
                                                                   u32* __restrict__ live_rows, int32_t* mailbox,
-                                                                  int32_t seq) {
+                                                                  int32_t seq, const int32_t* __restrict__ counters,
+                                                                  int32_t* __restrict__ num_rendered_dev, int32_t* sticky) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && counters[8] != 0) {
+    if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
+    if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (i < ntiles) {
     order[i] = (u32)i;
     if (order_copy != nullptr) order_copy[i] = (u32)i;
@@ -977,16 +997,18 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
 }
 
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
-                       uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st) {
+                       uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
+                       int32_t* num_rendered_dev, int32_t* sticky_error, hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
   if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
     tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_work, tile_order, order_copy, ntiles, live_rows,
-                                                                     rows_mailbox, rows_seq);
+                                                                     rows_mailbox, rows_seq, counters, num_rendered_dev,
+                                                                     sticky_error);
     return;
   }
   tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(
-      tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq);
+      tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq, counters, num_rendered_dev, sticky_error);
 }
 
 }  // namespace olsr

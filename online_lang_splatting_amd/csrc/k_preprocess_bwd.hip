@@ -98,7 +98,7 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float*
   const int wave = (int)(blockIdx.x * (RR_THREADS / 64) + (threadIdx.x >> 6));
   const int nwaves = (int)(gridDim.x * (RR_THREADS / 64));
   const int nbig = counters[5], count = nbig + counters[4];  // front list, then the medium list from the back
-  if (wave >= count || counters[7] != 0) return;
+  if (wave >= count || frame_unusable(counters)) return;
   auto item_at = [&](int i) { return big_list[i < nbig ? i : P - 1 - (i - nbig)]; };
   uint4 cur = item_at(wave);
   for (int item = wave; item < count; item += nwaves) {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     const u32 ntiles_g = vis ? tiles_touched[idx] : 0u;  // (a Gaussian listed in no tile has no rows: all zeros)
     if (ntiles_g > OLSR_MID_FOOTPRINT) {
       has_rows = true;  // (not looked up: listed Gaussians are few)
-      if (counters[7] == 0) {  // summed by row_reduce_big_kernel
+      if (!frame_unusable(counters)) {  // summed by row_reduce_big_kernel
         const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
         for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
           if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
         }
       }
-    } else if (ntiles_g > 0 && counters[7] == 0) {
+    } else if (ntiles_g > 0 && !frame_unusable(counters)) {
       // the Gaussian's partial-gradient rows are one dense run (emission order): sum them here, in ascending
       // (tile, wave) order — no intermediate per-Gaussian buffer
       const u32 u0 = inst_start[idx];
@@ -643,8 +643,15 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
 
 // one block: 1024 threads stride over the block partials (six consecutive floats each), fixed-order reduction
 __global__ __launch_bounds__(1024) void tau_final_kernel(const float* __restrict__ partials, int nb,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, const int32_t* __restrict__ counters,
+                                                         int32_t* __restrict__ status_dev, int32_t* sticky) {
   __shared__ float red[16][6];
+  // the backward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
+  if (threadIdx.x == 0 && counters[8] != 0) {
+    if (status_dev != nullptr) status_dev[1] = 2;
+    if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (out == nullptr) return;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int b = threadIdx.x; b < nb; b += 1024) {
     const float2* p = reinterpret_cast<const float2*>(partials + (size_t)b * 6);  // 24-byte records: 8-byte aligned
@@ -685,7 +692,10 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
       o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign,
       s.activations, s.opacities, F_out);
-  if (o.dL_dtau_sum) tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, nb, o.dL_dtau_sum);
+  if (o.dL_dtau_sum)
+    tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, nb, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
+  else if (o.status_dev || o.sticky_error)
+    tau_final_kernel<<<1, 64, 0, st>>>(tau_partials, 0, nullptr, g.counters, o.status_dev, o.sticky_error);
 }
 
 void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,

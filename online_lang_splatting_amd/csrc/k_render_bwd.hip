@@ -123,7 +123,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   const int bx = tile_id % gx, by = tile_id / gx;
   const u32 r0 = ranges[2 * tile_id], r1 = ranges[2 * tile_id + 1];
   if (r1 <= r0) return;
-  if (counters[7] != 0) return;  // row scratch too small (reported to the caller): write nothing
+  if (frame_unusable(counters)) return;  // row scratch too small / synchronisation error (reported to the caller): write nothing
   const size_t HW = (size_t)H * W;
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];

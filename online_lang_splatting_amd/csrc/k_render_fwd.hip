@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
-    u32* __restrict__ tile_work, const u32* __restrict__ order_hint) {
+    u32* __restrict__ tile_work, const u32* __restrict__ order_hint, const int32_t* __restrict__ counters) {
+  // a radix pass of this frame lost a predecessor's counts (olsr_state.h, counters[8]): the lists are garbage and must not be
+  // used as indices — render nothing; the tile-order kernel behind this one reports OLSR_STATUS_SYNC_ERROR
+  if (counters[8] != 0) return;
   constexpr int BS = TILE * TILE;
   constexpr int FR = feat_row(F);
   constexpr int NA = 4 + F;  // r g b depth lang[F]
@@ -383,12 +386,12 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
 template <int TILE, int F>
 static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, hipStream_t st) {
+                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, int32_t* nr_dev, hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
 #define OLSR_FWD_ARGS                                                                                                  \
   im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
-      n_touched, b.flags, im.tile_work, order_inout
+      n_touched, b.flags, im.tile_work, order_inout, g.counters
   if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
     render_fwd_kernel<TILE, F, 1><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
   else if (s.flags & OLSR_FLAG_FWD_ACCUM_WEIGHT)
@@ -397,30 +400,34 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
     render_fwd_kernel<TILE, F, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
 #undef OLSR_FWD_ARGS
   const RowsMailbox& rm = rows_mailbox_of_this_call();
-  launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, st);
+  launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, g.counters, nr_dev,
+                    rm.sticky, st);
 }
 
 template <int TILE>
 static void launch_fwd_f(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, float* oc, float* ol, float* od, float* oo, int32_t* nt,
-                         uint32_t* ord, hipStream_t st) {
+                         uint32_t* ord, int32_t* nr_dev, hipStream_t st) {
   switch (s.F) {
-    case 0: launch_fwd_t<TILE, 0>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
-    case 3: launch_fwd_t<TILE, 3>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
-    case 15: launch_fwd_t<TILE, 15>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
-    case 16: launch_fwd_t<TILE, 16>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
-    case 32: launch_fwd_t<TILE, 32>(s, d, g, b, im, oc, ol, od, oo, nt, ord, st); break;
+    case 0: launch_fwd_t<TILE, 0>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
+    case 3: launch_fwd_t<TILE, 3>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
+    case 15: launch_fwd_t<TILE, 15>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
+    case 16: launch_fwd_t<TILE, 16>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
+    case 32: launch_fwd_t<TILE, 32>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
     default: break;
   }
 }
 
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                            const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                           float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, hipStream_t st) {
+                           float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, int32_t* num_rendered_dev,
+                           hipStream_t st) {
   if (d.tile == 15)
-    launch_fwd_f<15>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout, st);
+    launch_fwd_f<15>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
+                     num_rendered_dev, st);
   else
-    launch_fwd_f<16>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout, st);
+    launch_fwd_f<16>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
+                     num_rendered_dev, st);
 }
 
 }  // namespace olsr

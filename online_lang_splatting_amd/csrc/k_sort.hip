@@ -33,7 +33,7 @@ namespace olsr {
 constexpr u32 FS_READY = 0x80000000u;
 constexpr int FS_T = FUSED_SORT_THREADS;  // 1024
 constexpr int FS_W = FS_T / 64;           // 16 waves
-constexpr int FS_SPIN_LIMIT = 1 << 22;    // ~0.1 s of polling
+// (the look-back's spin bound is SortKnobs::spin_limit, default 1 << 22 polls: seconds; a predecessor publishes within microseconds)
 
 __device__ __forceinline__ int64_t fs_bounded_n(int64_t n_host, const int32_t* n_dev) {
   if (n_dev) {
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
       house.counters[5] = 0;
       house.counters[6] = 0;
       house.counters[7] = 0;
+      house.counters[8] = 0;  // synchronisation error of this frame (olsr_state.h)
       if (house.live_rows) {
         house.live_rows[0] = 0;
         house.live_rows[1] = 0;
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
                                                          u32* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                          int fsf, uint8_t* __restrict__ flags_clear, u32* ranges,
                                                          const u32* __restrict__ inst_count, u32* emit_totals,
-                                                         unsigned long long* timing) {
+                                                         unsigned long long* timing, int32_t* sync_error, int spin_limit,
+                                                         int fault) {
   constexpr u32 NB = 1u << DB;
   constexpr u32 DMASK = NB - 1u;
   constexpr int CHUNK = FS_T * KPT;
@@ -269,6 +271,15 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   }
   const int64_t n = fs_bounded_n(n_host, n_dev);
   const int64_t bbase = (int64_t)b * CHUNK;
+  // The frame is already broken (an earlier kernel of it lost a predecessor's counts): keys and values may be garbage — the
+  // last tile pass would index the tile ranges with them — so do nothing.  Uniform for an error raised by an earlier kernel;
+  // an error raised inside THIS pass is seen by late blocks only, whose successors then give up in turn (the frame is lost
+  // either way, and this pass's own stores are clamped).
+  if (__hip_atomic_load(sync_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  if (b >= gridDim.x) {  // a ticket beyond the grid: the ticket word was not the zero the frame's head left (corrupted)
+    if (tid == 0) atomicOr(sync_error, 1);
+    return;
+  }
   if (bbase >= n) return;  // (an empty block has only empty successors: nobody waits for it)
   const int64_t wbase = bbase + (int64_t)w * (64 * KPT);
 
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   const u32 start = fs_block_excl_scan(d < NB ? tot : 0u, s_w);
   // publish this block's row: NB / 8 granules of eight 16-bit counts, write-through (sc1)
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)(gridDim.x * NB * 2u), 0x00020000);
-  if (tid < C) {
+  if (tid < C && !(fault != 0 && b == 0)) {  // (fault: test hook — this block's counts never arrive)
     const u32x4 g4 = *reinterpret_cast<const u32x4*>(pub + 8 * tid);
     __builtin_amdgcn_raw_buffer_store_b128(g4, rsrc, (int)((b * NB + 8u * (u32)tid) * 2u), 0, /*sc1*/ 16);
   }
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   {
     const int gc = tid % C, rsub = tid / C;
     u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    bool gave_up = false;
     for (u32 bp0 = 0; bp0 < b; bp0 += RPB * U) {
       u32x4 v[U];
 #pragma unroll
@@ -367,10 +379,11 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
       for (int u = 0; u < U; ++u) {
         const u32 row = bp0 + (u32)rsub + (u32)u * RPB;
         // (bounded: a predecessor publishes within microseconds; a corrupted state buffer must not hang the GPU)
-        for (int spin = 0; !fs_granule_ready(v[u]) && spin < FS_SPIN_LIMIT; ++spin) {
+        for (int spin = 0; !fs_granule_ready(v[u]) && spin < spin_limit; ++spin) {
           __builtin_amdgcn_s_sleep(4);
           v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((row * NB + 8u * (u32)gc) * 2u), 0, 16);
         }
+        gave_up |= !fs_granule_ready(v[u]);
         acc[0] += v[u].x & 0x7FFFu;
         acc[1] += (v[u].x >> 16) & 0x7FFFu;
         acc[2] += v[u].y & 0x7FFFu;
@@ -381,6 +394,9 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
         acc[7] += (v[u].w >> 16) & 0x7FFFu;
       }
     }
+    // A predecessor that never published: the counts below are garbage.  Nothing is written out of bounds (the stores are
+    // clamped), and the frame is marked: the forward reports it, the backward writes zero gradients.
+    if (gave_up) atomicOr(sync_error, 1);
     // lanes of a wave that own the same granule column differ in the lane bits >= log2(C): fold them, then the lanes
     // < C hold the wave's partial sums of their eight digits (cnt is dead after the ranking: reused as [16][NB])
 #pragma unroll
@@ -479,6 +495,8 @@ struct PassArgs {
   const u32* inst_count;
   u32* emit_totals;
   int nblk;
+  int32_t* sync_error;
+  int fault;
 };
 
 template <int DB, int KPT>
@@ -504,7 +522,8 @@ static void launch_pass_t(const PassArgs& a, hipStream_t st) {
     timing = g_timing.buf + (size_t)(g_timing.launch++) * g_timing.max_blocks * 8;
   sort_pass_kernel<DB, KPT><<<a.nblk, FS_T, smem, st>>>(a.kin, a.vin, a.n_host, a.n_dev, a.shift, a.ghist, a.status,
                                                         a.ticket, a.kout, a.vout, a.fsf, a.flags, a.ranges,
-                                                        a.inst_count, a.emit_totals, timing);
+                                                        a.inst_count, a.emit_totals, timing, a.sync_error,
+                                                        sort_knobs().spin_limit.load(std::memory_order_relaxed), a.fault);
 }
 
 template <int DB>
@@ -562,7 +581,7 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
 // zeroed and hist filled by launch_sort_hist.  Returns 0 if the result ends in (key_a, val_a), 1 if in (key_b, val_b).
 int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host, const int32_t* n_dev, int bits,
                       bool vals_in_identity, const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
-                      const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st) {
+                      const uint32_t* inst_count, uint32_t* emit_totals, int32_t* sync_error, int fault, hipStream_t st) {
   if (n_host <= 0) return 0;
   int passes;
   const int db = fused_sort_digit_bits(bits, &passes);
@@ -575,7 +594,7 @@ int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host
     if (p == passes - 1) fsf |= FSF_NO_KEYS | (ranges ? FSF_RANGES : 0) | (emit_totals ? FSF_EMIT_TOTALS : 0);
     PassArgs a{kin, vin, n_host, n_dev, db * p, hist + 256 * p,
                reinterpret_cast<u16*>(status) + (size_t)p * plan.nblk * NB, tickets + p, kout, vout, fsf, flags_clear,
-               ranges, inst_count, emit_totals, plan.nblk};
+               ranges, inst_count, emit_totals, plan.nblk, sync_error, p == 0 ? fault : 0};
     switch (db) {
       case 4: launch_pass_k<4>(plan.kpt, a, st); break;
       case 5: launch_pass_k<5>(plan.kpt, a, st); break;

@@ -172,6 +172,21 @@ RowsRing g_rows;
 thread_local int32_t g_last_token = 0;  // token of the last olsr_forward of this thread (0: none)
 thread_local RowsMailbox g_rows_call;
 
+// A synchronisation error (olsr_state.h, counters[8]) is detected on the device after the call that caused it has returned.
+// The sync-free entries report it through their status words; for the reference-shaped, synchronising API the last kernel of
+// a forward / backward also raises a flag in mapped host memory, and the FIRST library call after the GPU got there fails
+// with OLSR_ERR_DEVICE — the way an asynchronous HIP error surfaces.  Returns true (and clears the flag) if one is pending.
+bool take_sticky_sync_error() {
+  int32_t* ring = g_rows.p.load(std::memory_order_acquire);
+  if (!ring) return false;
+  return __atomic_exchange_n(&ring[4 * ROWS_RING], 0, __ATOMIC_ACQ_REL) != 0;
+}
+int32_t* sticky_sync_error_dev() { return g_rows.p.load(std::memory_order_acquire) ? g_rows.dp + 4 * ROWS_RING : nullptr; }
+const char* const STICKY_MSG =
+    "device-side synchronisation error in an earlier frame of this process: a look-back of its radix sort / row compaction "
+    "never received a predecessor's counts (state buffer corrupted mid-frame?); that frame's images are invalid and its "
+    "gradients are zeros";
+
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
                  int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st) {
@@ -187,7 +202,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   if (s.P > 0 && (!radii || !n_touched)) return fail(OLSR_ERR_ARG, "radii and n_touched must not be NULL");
 
   if (s.P <= 0) {  // nothing below runs: leave a consistent empty state behind
-    HIP_TRY(hipMemsetAsync(g.counters, 0, sizeof(int32_t) * 8, st));
+    HIP_TRY(hipMemsetAsync(g.counters, 0, sizeof(int32_t) * 16, st));
     HIP_TRY(hipMemsetAsync(im.ranges, 0, sizeof(uint32_t) * 2 * (size_t)d.ntiles, st));
     HIP_TRY(hipMemsetAsync(im.live_rows, 0, sizeof(uint32_t) * 4, st));
   }
@@ -220,7 +235,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     if (!legacy && fused_sort_applicable(s.P, 32)) {
       // (values = Gaussian indices: the first pass takes them from the position, preprocess writes no index array)
       launch_sort_fused(sb, sort_plan(s.P), s.P, nullptr, 32, true, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
-                        g.tiles_touched, g.emit_status, st);
+                        g.tiles_touched, g.emit_status, &g.counters[8],
+                        sort_knobs().fault.load(std::memory_order_relaxed) & 1, st);
     } else {
       launch_radix_sort(sb, s.P, nullptr, 32, true, st);
       launch_emit_totals(g.depth_order, s.P, g.tiles_touched, g.emit_status, st);
@@ -284,7 +300,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
         launch_sort_hist(b.key_a, n_host, n_dev, tbits, b.tile_hist, nullptr, st);
         // the first pass also clears the liveness flags, the last one derives the tile ranges
         launch_sort_fused(sb, tile_plan, n_host, n_dev, tbits, true, b.tile_hist, b.tile_status, b.tickets, b.flags, im.ranges,
-                          nullptr, nullptr, st);
+                          nullptr, nullptr, &g.counters[8], sort_knobs().fault.load(std::memory_order_relaxed) & 2, st);
       } else {
         const int where = launch_radix_sort(sb, n_host, n_dev, tbits, true, st);
         launch_tile_ranges(where ? b.key_b : b.key_a, n_host, n_dev, im.ranges, b.flags, st);
@@ -298,9 +314,10 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       std::lock_guard<std::mutex> lk(g_rows.init);
       if (!g_rows.p.load(std::memory_order_relaxed)) {
         int32_t* hp = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&hp, ROWS_RING * 4 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        // (+ 4 words behind the ring: [0] = the sticky synchronisation-error flag, see take_sticky_sync_error)
+        HIP_TRY(hipHostMalloc((void**)&hp, (ROWS_RING * 4 + 4) * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipHostGetDevicePointer((void**)&g_rows.dp, hp, 0));
-        std::memset(hp, 0, ROWS_RING * 4 * sizeof(int32_t));
+        std::memset(hp, 0, (ROWS_RING * 4 + 4) * sizeof(int32_t));
         g_rows.p.store(hp, std::memory_order_release);
       }
     }
@@ -312,9 +329,10 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     g_last_token = tok;
     g_rows_call.dev = g_rows.dp + 4 * (tok % ROWS_RING);
     g_rows_call.seq = tok;
+    g_rows_call.sticky = g_rows.dp + 4 * ROWS_RING;
   }
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
-                        st);
+                        num_rendered_dev, st);
   g_rows_call = RowsMailbox{};
   STAGE("render_forward");
 
@@ -330,7 +348,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
 // heavy tiles are started first (tile_order_inout of olsr_forward_async).  The library therefore keeps, per (device,
 // stream, tile count), the order measured on the previous frame issued on that stream.  Forwards on one stream execute in
 // order, so the array is a complete permutation whenever a kernel reads it; no result depends on its content (a hint from
-// another view of another scene is merely a worse guess).  A few KB each, at most 64 of them, never freed.
+// another view of another scene is merely a worse guess).  A few KB each, at most 64 of them (least recently used evicted),
+// allocated stream-ordered; the survivors live until the process ends.
 __global__ void iota_kernel(uint32_t* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint32_t)i;
@@ -350,16 +369,33 @@ uint32_t* order_hint_of(int ntiles, hipStream_t st) {
   int dev = 0;
   if (ntiles <= 0 || hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lk(g_order_hints.m);
-  for (const auto& e : g_order_hints.v)
-    if (e.dev == dev && e.st == st && e.ntiles == ntiles) return e.buf;
-  if (g_order_hints.v.size() >= 64) return nullptr;  // (unusual: run without a hint rather than grow)
+  auto& v = g_order_hints.v;
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].dev == dev && v[i].st == st && v[i].ntiles == ntiles) {
+      const OrderHints::Entry e = v[i];  // most recently used last (LRU order)
+      v.erase(v.begin() + (long)i);
+      v.push_back(e);
+      return e.buf;
+    }
+  if (v.size() >= 64) {
+    // a caller that keeps creating streams / resolutions: drop the least recently used hint.  Its stream may still have a
+    // forward in flight that writes it, so this is a plain (device-synchronising) hipFree — rare by construction, and the
+    // only synchronisation this path ever causes (the allocation below used to synchronise, and after 64
+    // keys the hint was silently dropped for good)
+    (void)hipFree(v.front().buf);
+    v.erase(v.begin());
+  }
   uint32_t* buf = nullptr;
-  if (hipMalloc((void**)&buf, sizeof(uint32_t) * (size_t)ntiles) != hipSuccess) {
+  // stream-ordered allocation: no device synchronisation on the hot olsr_forward path the first time a key is seen
+  if (hipMallocAsync((void**)&buf, sizeof(uint32_t) * (size_t)ntiles, st) != hipSuccess) {
     (void)hipGetLastError();
-    return nullptr;
+    if (hipMalloc((void**)&buf, sizeof(uint32_t) * (size_t)ntiles) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
   }
   iota_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(buf, ntiles);
-  g_order_hints.v.push_back({dev, st, ntiles, buf});
+  v.push_back({dev, st, ntiles, buf});
   return buf;
 }
 
@@ -467,6 +503,7 @@ int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* ge
   if (!geom) return fail(OLSR_ERR_ALLOC, "geometry allocation callback returned NULL");
   void* img = image_alloc(image_user, olsr_image_bytes(scene->width, scene->height, scene->tile));
   if (!img) return fail(OLSR_ERR_ALLOC, "image allocation callback returned NULL");
+  if (take_sticky_sync_error()) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
   BinningProvider bp;
   bp.fn = binning_alloc;
   bp.user = binning_user;
@@ -505,6 +542,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   hipStream_t st = (hipStream_t)hip_stream;
   if (s.bwd_mode != OLSR_BWD_REFERENCE && s.bwd_mode != OLSR_BWD_EXACT)
     return fail(OLSR_ERR_ARG, "bwd_mode must be OLSR_BWD_REFERENCE or OLSR_BWD_EXACT");
+  if (take_sticky_sync_error()) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
   mark("begin", st);
   if (s.P == 0) {
     if (dL_dtau_sum) HIP_TRY(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), st));
@@ -542,9 +580,13 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
                         scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, status_dev, st);
   STAGE("row_compaction");
   if (scratch_alloc) {
-    int32_t L = 0;
-    HIP_TRY(hipMemcpyAsync(&L, &g.counters[6], sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t c3[3] = {0, 0, 0};  // {live rows, row / instance overflow, synchronisation error}
+    HIP_TRY(hipMemcpyAsync(c3, &g.counters[6], 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (c3[2] != 0)  // (nothing of this frame's lists can be trusted; no gradient has been written)
+      return fail(OLSR_ERR_DEVICE, "device-side synchronisation error: a look-back of this frame's radix sort / row "
+                                   "compaction never received a predecessor's counts (state buffer corrupted mid-frame?)");
+    const int32_t L = c3[0];
     scratch_rows = L;
     scratch = scratch_alloc(scratch_user, olsr_backward_scratch_bytes(L, s.F));
     if (!scratch) return fail(OLSR_ERR_ALLOC, "backward scratch allocation callback returned NULL");
@@ -564,6 +606,10 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
     o.bucket_max_radii = bucket->max_radii;
     o.bucket_assign = bucket->assign;
   }
+  o.status_dev = status_dev;
+  // (a caller that passes status_dev reads the report there; one that does not — the reference-shaped bindings — gets it
+  //  from the library's next call)
+  o.sticky_error = status_dev ? nullptr : sticky_sync_error_dev();
   launch_preprocess_backward(s, F_rows, d, g, b, rows, radii, o, g.tau_partials, st);
   STAGE("preprocess_backward");
   (void)gb;
@@ -711,6 +757,7 @@ const void* olsr_binning_field(const void* binning_buffer, int64_t num_rendered,
   if (!std::strcmp(name, "inst_gid")) return b.inst_gid;
   if (!std::strcmp(name, "flags")) return b.flags;
   if (!std::strcmp(name, "rowbase")) return b.rowbase;
+  if (!std::strcmp(name, "row_sync")) return b.tickets + 8;  // {ticket, finished blocks} of the row compaction
   if (!std::strcmp(name, "key_a")) return b.key_a;
   if (!std::strcmp(name, "key_b")) return b.key_b;
   if (!std::strcmp(name, "src")) return b.src;
@@ -753,6 +800,11 @@ int olsr_get_stage_times(const char** names, float* ms, int max) {
 
 void olsr_debug_sort_timing(unsigned long long* device_buffer, int max_blocks, int max_launches) {
   debug_set_sort_timing(device_buffer, max_blocks, max_launches);
+}
+
+void olsr_debug_sync_fault(int fault_bits, int spin_limit) {
+  if (fault_bits >= 0) sort_knobs().fault = fault_bits & 3;
+  if (spin_limit >= 0) sort_knobs().spin_limit = spin_limit > 0 ? spin_limit : (1 << 22);
 }
 
 void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy) {

@@ -12,6 +12,11 @@
 
 namespace olsr {
 
+// The backward must not trust this frame's lists / rows: the row scratch was too small or the forward overflowed its instance
+// capacity (counters[7]), or a look-back ran into its spin bound (counters[8], olsr_state.h) — every gradient is then zero.
+__device__ __forceinline__ bool frame_unusable(const int32_t* counters) { return (counters[7] | counters[8]) != 0; }
+
+
 typedef unsigned int u32;
 typedef unsigned long long u64;
 

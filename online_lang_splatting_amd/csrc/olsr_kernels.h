@@ -51,10 +51,12 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
 // tile_work[0], sum of tile_work[1], rows_seq, 0} (the drop-in path sizes its backward scratch from them without a
 // synchronisation); live_rows: ImageState::live_rows, zero on entry, the staging of those sums
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
-                       uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, hipStream_t st);
+                       uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
+                       int32_t* num_rendered_dev, int32_t* sticky_error, hipStream_t st);
 struct RowsMailbox {  // set by olsr_forward for the duration of one call (thread-local in olsr_api.hip)
   int32_t* dev = nullptr;
   int32_t seq = 0;
+  int32_t* sticky = nullptr;  // device view of the process-wide "a frame had a synchronisation error" host word (may be null)
 };
 RowsMailbox& rows_mailbox_of_this_call();
 // ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)
@@ -87,7 +89,7 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
 // instance count (inst_count[v]) to emit_totals[final position / EMIT_CHUNK] (zeroed beforehand).
 int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host, const int32_t* n_dev, int bits,
                       bool vals_in_identity, const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
-                      const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
+                      const uint32_t* inst_count, uint32_t* emit_totals, int32_t* sync_error, int fault, hipStream_t st);
 void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_launches);
 // the same totals for a depth order produced by the multi-kernel passes
 void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
@@ -95,7 +97,8 @@ void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count
 // k_render_fwd.hip
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                            const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                           float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, hipStream_t st);
+                           float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, int32_t* num_rendered_dev,
+                           hipStream_t st);
 
 // k_render_bwd.hip
 // (two translation units, one per backward mode, so they compile in parallel)
@@ -116,6 +119,8 @@ struct GradOut {
   float* bucket_densify = nullptr;
   int32_t* bucket_max_radii = nullptr;
   int bucket_assign = 0;
+  int32_t* status_dev = nullptr;  // olsr_backward's {L, overflow}: the last kernel raises [1] to 2 on a synchronisation error
+  int32_t* sticky_error = nullptr;  // ... and sets this mapped host word (RowsMailbox::sticky), if there is one
 };
 // F_rows: language channels of `rows` (see above); with F_rows == 0 < s.F the language gradients are written as zeros
 void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,

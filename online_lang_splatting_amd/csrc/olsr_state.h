@@ -46,6 +46,10 @@ constexpr int FUSED_SORT_MAX_BLOCKS = 4096;  // beyond: the multi-kernel passes 
 //  inputs; no getenv on a call path)
 struct SortKnobs {
   std::atomic<int> kpt{0}, resident{0}, legacy{0};
+  // test hooks (olsr_debug_sync_fault): fault bit 0 / 1 = the block holding ticket 0 of the first depth / tile pass never
+  // publishes its digit counts (what a status word corrupted mid-frame looks like to its successors); spin_limit = polls a
+  // look-back makes before it gives up and raises the frame's synchronisation error
+  std::atomic<int> fault{0}, spin_limit{1 << 22};
 };
 SortKnobs& sort_knobs();  // olsr_api.hip
 inline int sort_plan_resident_blocks() {
@@ -127,10 +131,14 @@ struct GeometryState {
   uint32_t* inst_start;   // [P] Gaussian id -> emission index of its first instance
   uint32_t* radix_table;  // [256 * sort_blocks(P)]
   uint32_t* scan_partials;  // [scan_blocks(max(P, table))]
-  int32_t* counters;      // [8]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag,
+  int32_t* counters;      // [16]: 0 = R (total instances), 1 = R_eff (0 on overflow), 2 = overflow flag,
                           //      3 = instances of the reference's rect binning (== R unless OLSR_BINNING_ELLIPSE),
                           //      4 = #large-footprint Gaussians (backward), 5 = same for the emission (forward),
-                          //      6 = live rows L, 7 = row-capacity overflow
+                          //      6 = live rows L, 7 = row-capacity overflow,
+                          //      8 = synchronisation error: a look-back of a radix pass or of the row compaction ran into its
+                          //          spin bound (a status word corrupted mid-frame).  Reset by the frame's first kernel; the
+                          //          forward reports it as num_rendered_dev[1] = 2, the backward writes zero gradients and
+                          //          reports status_dev[1] = 2 / OLSR_ERR_DEVICE (include/olsr.h).  [9..15] reserved
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
   uint4* big_list;        // [P] work lists {id, first instance, #instances} built by the emission: large footprints from
@@ -164,7 +172,7 @@ struct GeometryState {
     const size_t table = 256 * (size_t)sort_blocks((long long)P);
     g.radix_table = c.take<uint32_t>(table);
     g.scan_partials = c.take<uint32_t>((size_t)scan_blocks((long long)(table > P ? table : P)) + 1);
-    g.counters = c.take<int32_t>(8);
+    g.counters = c.take<int32_t>(16);
     g.tau_partials = c.take<float>(6 * ((P + 127) / 128) + 6);
     g.gacc = c.take<float>(P * (size_t)grad_row_floats);
     g.big_list = c.take<uint4>(P);

@@ -311,6 +311,13 @@ class FusedAdam:
                                    C.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)))
 
 
+def _raise_on_sync_error(status, where):
+    if status >= 2:
+        raise RuntimeError(f"olsr {where}: device-side synchronisation error (OLSR_STATUS_SYNC_ERROR): a look-back of the "
+                           "frame's radix sort / row compaction never received a predecessor's counts; the frame's "
+                           "synchronisation words were overwritten mid-frame.  Images of that frame are invalid, gradients zero")
+
+
 class RasterWorkspace:
     """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
 
@@ -419,13 +426,16 @@ class RasterWorkspace:
         return g
 
     def backward_status(self):
-        """(live rows L, overflow) of the last backward — synchronises; call outside timed regions."""
+        """(live rows L, overflow) of the last backward — synchronises; call outside timed regions.  Raises on a device-side
+        synchronisation error (OLSR_STATUS_SYNC_ERROR, include/olsr.h): the gradients of that backward are zeros."""
         st = self.bwd_status.cpu()
+        _raise_on_sync_error(int(st[1]), "backward")
         return int(st[0]), bool(st[1])
 
     def rendered(self):
-        """(R, overflow) — synchronises; call outside timed regions."""
+        """(R, overflow) — synchronises; call outside timed regions.  Raises on a device-side synchronisation error."""
         r = self.num_rendered.cpu()
+        _raise_on_sync_error(int(r[1]), "forward")
         return int(r[0]), bool(r[1])
 
 
@@ -568,6 +578,7 @@ class FrameShardedStep:
         if multi:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
         ovf, need_R, need_L = (int(x) for x in flags.cpu())  # the step's one host synchronisation
+        _raise_on_sync_error(ovf, "frame-sharded step (some rank)")
         if ovf:
             ws = self.ws
             raise OverflowError(f"a view overflowed the workspace on some rank: it needs capacity >= {need_R} instances "

@@ -8,7 +8,7 @@ import torch
 
 from online_lang_splatting_amd import _abi
 from online_lang_splatting_amd.scene import make_config_scene, make_scene
-from parity_common import rel_err, run_backend
+from parity_common import fwd_args, rel_err, run_backend
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -810,3 +810,95 @@ def _bwd_args(sc, fwd, dev, seed):
     dc, dl, dd = (t.to(dev) for t in sc.cotangents(seed))
     return [a[0], a[1], fwd["radii"], a[2], a[3], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], dc, dl, dd,
             a[16], a[17], a[18], fwd["geom"], fwd["R"], fwd["binning"], fwd["img"], False]
+
+
+# ---- synchronisation errors are reported, never silent -----------------------------------------
+def _sync_error_workspace(dev, P=20000, W=320, H=240, F=15):
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    from online_lang_splatting_amd.scene import make_scene
+    sc = make_scene(P, W, H, F, seed=123)
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    cam = sc.camera
+    c = dict(viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+             projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+             tanfovy=cam.tanfovy)
+    ws = RasterWorkspace(P, W, H, F, sc.shs.shape[1], 600000, dev)
+    ws.set_scene(sh_degree=sc.sh_degree, **c, **g)
+    cot = [t.to(dev) for t in sc.cotangents(1)]
+    return sc, ws, cot
+
+
+def test_corrupted_row_compaction_ticket_is_reported_and_gradients_are_zero(hip):
+    """Between a forward and its backward the test overwrites the row compaction's ticket word in the binning buffer: the
+    blocks then hold tickets whose predecessors do not exist, their look-back runs into its spin bound.  The library must not
+    hang, must not return gradients computed from garbage row offsets, and must say so: status_dev[1] ==
+    OLSR_STATUS_SYNC_ERROR on the sync-free path (zero gradients), OLSR_ERR_DEVICE from the synchronising olsr_backward."""
+    from online_lang_splatting_amd._lib import lib
+    dev = torch.device(DEV)
+    sc, ws, cot = _sync_error_workspace(dev)
+    L = lib()
+    L.olsr_debug_sync_fault(-1, 2000)   # give up after 2000 polls instead of 2^22 (keeps the test short)
+    try:
+        ws.forward()
+        good = {k: v.clone() for k, v in ws.backward(*cot).items()}
+        assert ws.backward_status()[0] > 0 and float(good["dL_dmeans3D"].abs().max()) > 0
+        ws.forward()
+        sync = hip.state_field("binning", ws.binning, "row_sync", R=ws.capacity, F=sc.F, dtype=torch.int32, count=2)
+        sync[0] = 3   # tickets now start at 3: blocks 0..2 never publish
+        g = ws.backward(*cot)
+        torch.cuda.synchronize()
+        assert int(ws.bwd_status.cpu()[1]) == 2
+        with pytest.raises(RuntimeError, match="synchronisation error"):
+            ws.backward_status()
+        for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dlanguage", "dL_dmeans2D"):
+            assert float(g[k].abs().max()) == 0.0, k
+        # the next frame on the same workspace is healthy again (the forward re-zeroes its synchronisation words)
+        ws.forward()
+        again = ws.backward(*cot)
+        assert ws.backward_status()[1] is False
+        for k in good:
+            assert torch.equal(again[k], good[k]), k
+    finally:
+        L.olsr_debug_sync_fault(0, 0)
+
+
+@pytest.mark.parametrize("which,bit", [("depth sort", 1), ("tile sort", 2)])
+def test_lost_digit_counts_in_a_radix_pass_are_reported(hip, which, bit):
+    """Fault injection (olsr_debug_sync_fault): the block holding ticket 0 of the first depth / tile pass never publishes its
+    digit counts — what its successors see when a status word is lost mid-frame.  The forward reports
+    OLSR_STATUS_SYNC_ERROR in num_rendered_dev[1], the backward zero gradients and the same status; through the reference's
+    API the gradients are zeros and the library's next call raises (an error detected on the device surfaces asynchronously)."""
+    from online_lang_splatting_amd._lib import lib
+    dev = torch.device(DEV)
+    # (more than one block per pass: 20 000 keys would fit one block of the depth sort)
+    sc, ws, cot = _sync_error_workspace(dev, P=60000)
+    L = lib()
+    L.olsr_debug_sort_knobs(2, -1, -1)   # 2 keys per thread: 2048 keys per block, so every pass has several blocks
+    L.olsr_debug_sync_fault(bit, 2000)
+    try:
+        ws.forward()
+        torch.cuda.synchronize()
+        assert int(ws.num_rendered.cpu()[1]) == 2, which
+        with pytest.raises(RuntimeError, match="synchronisation error"):
+            ws.rendered()
+        g = ws.backward(*cot)
+        torch.cuda.synchronize()
+        assert int(ws.bwd_status.cpu()[1]) == 2 and float(g["dL_dmeans3D"].abs().max()) == 0.0
+        # the drop-in API: forward (synchronising) + backward -> RuntimeError carrying the library's message
+        a = fwd_args(sc, dev)
+        r = hip.rasterize_language_gaussians(*a)
+        b = [a[0], a[1], r[3], a[2], a[3], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], cot[0], cot[1], cot[2],
+             a[16], a[17], a[18], r[4], r[0], r[5], r[6], False]
+        g2 = hip.rasterize_language_gaussians_backward(*b)   # (may be issued before the GPU has reached the error)
+        torch.cuda.synchronize()
+        assert float(g2[4].abs().max()) == 0.0                 # dL_dmeans3D: zeros, not garbage
+        # ... and the first library call after the GPU got there fails, the way an asynchronous HIP error surfaces
+        with pytest.raises(RuntimeError, match="synchronisation error"):
+            hip.rasterize_language_gaussians(*a)
+    finally:
+        L.olsr_debug_sync_fault(0, 0)
+        L.olsr_debug_sort_knobs(0, -1, -1)
+    ws.forward()
+    ws.backward(*cot)
+    assert ws.rendered()[1] is False and ws.backward_status()[1] is False
