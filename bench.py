@@ -397,10 +397,23 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
         torch.cuda.synchronize(dev)
         trk["rgb_rasterizer_render"] = round(1e3 * (time.perf_counter() - t0) / tracking_iters, 4)
         del ws_rgb
+    # ... and the two-kernel formulation of round 3 (olsr_forward_async + olsr_tracking_loss) instead of the loss in the
+    # composite's epilogue, for comparison
+    pose.reset(T0)
+    loop = TrackingLoop(ws, g_dev, sc.sh_degree, pose, gt_image, gt_depth, language_cotangent="null", fused_loss=False)
+    for _ in range(5):
+        loop.iteration()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(tracking_iters):
+        loop.iteration()
+    torch.cuda.synchronize(dev)
+    trk["no_language_cotangent_two_kernel_loss"] = round(1e3 * (time.perf_counter() - t0) / tracking_iters, 4)
     out["tracking_iteration_ms"] = trk["no_language_cotangent"]
     out["tracking"] = {"ms_per_iteration": trk, "iterations": tracking_iters,
-                       "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) + "
-                               "olsr_tracking_loss + pose-only olsr_backward + olsr_pose_step; dependent iterations",
+                       "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) with the "
+                               "tracking loss in the composite's epilogue (olsr_forward_async_loss) + pose-only olsr_backward + "
+                               "olsr_pose_step; dependent iterations",
                        "library_stage_ms": stage, "library_ms": round(sum(stage.values()), 4),
                        "pose_error_start": round(float((T0 - T_gt).abs().max()), 6),
                        "pose_error_after": round(float((pose.T_w2c - T_gt).abs().max()), 6)}
@@ -415,37 +428,69 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
                  tanfovy=c.tanfovy) for c in cams]
     lanes = FrameLanes(4, P, W, H, F, M, int(1.5 * R0) + (1 << 16), dev)
     lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
-    step = MappingStep(lanes, params, g_dev["bg"], sc.sh_degree, camd, None, lrs, exposure=torch.zeros(2, device=dev))
     gen = torch.Generator().manual_seed(0)
     targets = []
     ws0 = lanes.lanes[0][0]
+    step = MappingStep(lanes, params, g_dev["bg"], sc.sh_degree, camd, None, lrs, exposure=torch.zeros(2, device=dev))
     for c in camd:  # targets: renders of the scene itself, perturbed so that every loss term has a gradient
         o = step.render(ws0, c)
         targets.append((torch.clamp(o["color"] + 0.05 * torch.randn(3, H, W, generator=gen).to(dev), 0, 1).contiguous(),
                         (o["depth"][0] * (1 + 0.02 * torch.randn(H, W, generator=gen).to(dev))).contiguous(),
                         None if F == 0 else torch.nn.functional.normalize(torch.randn(F, 192, 192, generator=gen), dim=0).to(dev)))
-    step.targets = targets
-    step.iteration()
-    first_loss = float(step.last_loss[0])
-    step.iteration()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(mapping_iters):
-        step.iteration()
-    issue = time.perf_counter() - t0  # host time to enqueue the iterations (the GPU is still working)
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    ovf = any(ws_.rendered()[1] or ws_.backward_status()[1] for ws_, _, _ in lanes.lanes)
-    out["mapping_iteration_ms"] = round(1e3 * el / mapping_iters, 3)
+    del step
+    start = {k: (None if v is None else v.clone()) for k, v in params.items()}
+
+    def mapping_leg(fused):
+        """mapping_iters timed iterations from the same start parameters (four views in flight), then one PROFILED iteration
+        whose HIP events give the breakdown: library stages per view (events on the lanes' streams), the stand-alone loss kernel
+        (two-kernel formulation only), the sum of the lane buckets and the Adam step."""
+        for k, v in params.items():
+            if v is not None:
+                v.copy_(start[k])
+        st = MappingStep(lanes, params, g_dev["bg"], sc.sh_degree, camd, targets, lrs, exposure=torch.zeros(2, device=dev),
+                         fused_loss=fused)
+        st.iteration()
+        first = float(st.last_loss[0])
+        st.iteration()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(mapping_iters):
+            st.iteration()
+        issue = time.perf_counter() - t0  # host time to enqueue the iterations (the GPU is still working)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        last = float(st.last_loss[0])
+        ovf = any(ws_.rendered()[1] or ws_.backward_status()[1] for ws_, _, _ in lanes.lanes)
+        _lib.set_profiling(True)
+        st.profile = True
+        st.iteration()
+        per = {}
+        for name, ms in list(_lib.stage_times()) + list(st.stage_ms):
+            per.setdefault(name, []).append(ms)
+        _lib.set_profiling(False)
+        st.profile = False
+        per_view = {k: round(sum(v) / views, 4) for k, v in per.items() if k not in ("lane_sum", "adam")}
+        return {"ms_per_iteration": round(1e3 * el / mapping_iters, 3), "views_per_s": round(views * mapping_iters / el, 1),
+                "host_enqueue_ms_per_iteration": round(1e3 * issue / mapping_iters, 3),
+                "loss_last_view_first_iteration": round(first, 6), "loss_last_view_final_iteration": round(last, 6),
+                "capacity_overflow": bool(ovf),
+                "profiled_iteration": {"stage_ms_per_view": per_view,
+                                       "stage_ms_per_view_sum": round(sum(per_view.values()), 4),
+                                       "lane_sum_ms": round(sum(per.get("lane_sum", [0.0])), 4),
+                                       "adam_ms": round(sum(per.get("adam", [0.0])), 4),
+                                       "note": "events between the stages (~6 us each) on four lane streams: an interval also "
+                                               "holds the time a kernel queues behind other lanes' kernels"}}
+
+    fused_leg = mapping_leg(True)
+    two_leg = mapping_leg(False)
+    out["mapping_iteration_ms"] = fused_leg["ms_per_iteration"]
     out["mapping"] = {"views": views, "views_in_flight": len(lanes), "iterations": mapping_iters,
-                      "views_per_s": round(views * mapping_iters / el, 1),
-                      "host_enqueue_ms_per_iteration": round(1e3 * issue / mapping_iters, 3),
-                      "what": f"{views} arc views x (render from raw parameters + olsr_mapping_loss incl. the 192x192 language "
-                              "target + backward into the gradient bucket) + fused Adam step",
-                      "loss_last_view_first_iteration": round(first_loss, 6),
-                      "loss_last_view_final_iteration": round(float(step.last_loss[0]), 6),
-                      "capacity_overflow": bool(ovf)}
-    del step, lanes
+                      "what": f"{views} arc views x (render from raw parameters with the mapping loss incl. the 192x192 "
+                              "language target in the composite's epilogue + backward into the gradient bucket) + sum of the "
+                              "lane buckets + fused Adam step",
+                      **fused_leg,
+                      "two_kernel_loss": dict(what="olsr_forward_async + olsr_mapping_loss instead (round 3)", **two_leg)}
+    del lanes
     # the tracking iteration once more, recorded into a HIP graph and replayed (one launch from the host per iteration; the
     # Adam step number lives on the device).  Last on purpose: the capture's extra streams share the hardware queues with
     # the lanes' streams, and the mapping leg above ran 12 % slower when this leg preceded it

@@ -349,6 +349,47 @@ int olsr_mapping_loss(const olsr_loss_params *params, const float *image, const 
                       float *dL_dimage, float *dL_ddepth, float *dL_dlanguage,
                       float *loss, float *dL_dexposure, void *scratch, void *hip_stream);
 
+/* ---- the loss in the forward composite's epilogue ------------------------------------------
+ * olsr_forward_async with olsr_mapping_loss / olsr_tracking_loss evaluated where the composite kernel still holds every
+ * pixel's colour, depth, language features and transmittance in registers (the equivalent of CR/forward.cu:490-512): the
+ * kernel writes the cotangents olsr_backward consumes (dL_dimage, dL_ddepth, dL_dlanguage) next to — or, with skip_images,
+ * instead of — the images, and one partial sum per tile that a one-block kernel turns into loss[4] / dL_dexposure[2].
+ * The rendered images make NO round trip: the separate loss kernel re-reads 4 (4 + F) bytes per pixel and writes as many.
+ * Same arithmetic per pixel as the two stand-alone entries (shared source, csrc/olsr_loss_device.h): the cotangents are
+ * bit-identical to theirs, the loss differs in the summation order only (per-tile instead of per-256-pixel partials).
+ *   params        width / height must equal the scene's; params.F: language channels of the loss term — the scene's F, or 0
+ *                 for "no language term" (then dL_dlanguage is not written: hand olsr_backward a NULL language cotangent)
+ *   tracking      0: the mapping loss;  != 0: the tracking loss (opacity-weighted, grad_mask; params.F is ignored)
+ *   skip_images   != 0: out_color / out_language / out_depth / out_opacity are not written and may be NULL
+ *   gt_language   [F, lang_height, lang_width] or NULL (no language term)
+ *   scratch       olsr_fused_loss_scratch_bytes(width, height, tile) bytes
+ * Every normaliser of these losses is the pixel count (means over all elements): nothing has to be precomputed per keyframe.
+ * Supported with the default forward accumulation (not with OLSR_FLAG_FWD_ACCUM_MFMA / _WEIGHT). */
+typedef struct olsr_loss_fusion {
+  olsr_loss_params params;
+  int32_t tracking;
+  int32_t skip_images;
+  const float *gt_image;    /* [3,H,W] */
+  const float *gt_depth;    /* [H,W] */
+  const float *gt_language; /* [F,lang_height,lang_width] or NULL */
+  const float *exposure;    /* device float[2] or NULL */
+  const float *grad_mask;   /* [H,W] float or NULL (tracking only) */
+  float *dL_dimage;         /* [3,H,W] */
+  float *dL_ddepth;         /* [H,W] */
+  float *dL_dlanguage;      /* [F,H,W]; required when a language term is evaluated */
+  float *loss;              /* device float[4] {total, rgb, depth, language} */
+  float *dL_dexposure;      /* device float[2] or NULL */
+  void *scratch;
+} olsr_loss_fusion;
+size_t olsr_fused_loss_scratch_bytes(int32_t width, int32_t height, int32_t tile);
+int olsr_forward_async_loss(const olsr_scene *scene,
+                            void *geometry_buffer, void *binning_buffer, int64_t capacity,
+                            void *image_buffer,
+                            float *out_color, float *out_language, float *out_depth, float *out_opacity,
+                            int32_t *radii, int32_t *n_touched,
+                            int32_t *num_rendered_dev, uint32_t *tile_order_inout,
+                            const olsr_loss_fusion *loss, void *hip_stream);
+
 /* Tracking loss of one view (front end: the pose is optimised, the Gaussians are fixed) and its image cotangents.
  * Replaces get_loss_tracking / get_loss_tracking_rgb / get_loss_tracking_rgbd (utils/slam_utils.py:92-121):
  *   loss = alpha * mean(opacity * |m * (exp(a) * image + b) - m * gt_image|)

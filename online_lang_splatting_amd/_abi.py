@@ -96,6 +96,14 @@ class OlsrLossParams(C.Structure):
                 ("rgb_boundary_threshold", C.c_float), ("lamda_lang", C.c_float), ("_pad0", C.c_int32)]
 
 
+class OlsrLossFusion(C.Structure):
+    """struct olsr_loss_fusion, include/olsr.h: the loss evaluated in the forward composite's epilogue."""
+
+    _fields_ = [("params", OlsrLossParams), ("tracking", C.c_int32), ("skip_images", C.c_int32), ("gt_image", _fp),
+                ("gt_depth", _fp), ("gt_language", _fp), ("exposure", _fp), ("grad_mask", _fp), ("dL_dimage", _fp),
+                ("dL_ddepth", _fp), ("dL_dlanguage", _fp), ("loss", _fp), ("dL_dexposure", _fp), ("scratch", _fp)]
+
+
 def _ptr(t):
     """data_ptr of a tensor, or None for an absent (None / empty) one — the reference maps
     empty tensors to nullptr the same way (contiguous().data<float>() of a 0-element tensor,

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("OLSR_LIB") or os.path.join(_HERE, "libolsr.so")
 
 # every symbol include/olsr.h declares
 EXPORTS = (
-    "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_backward_scratch_bytes", "olsr_last_forward_token", "olsr_live_rows", "olsr_forward", "olsr_forward_async",
+    "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_backward_scratch_bytes", "olsr_last_forward_token", "olsr_live_rows", "olsr_forward", "olsr_forward_async", "olsr_forward_async_loss", "olsr_fused_loss_scratch_bytes",
     "olsr_backward", "olsr_accumulate_gradients", "olsr_mapping_loss", "olsr_mapping_loss_scratch_bytes", "olsr_tracking_loss", "olsr_pose_step", "olsr_knn_mean_dist2", "olsr_knn_scratch_bytes", "olsr_adam_step", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
     "olsr_set_profiling", "olsr_get_stage_times", "olsr_debug_sort_timing", "olsr_debug_sort_plan", "olsr_debug_sort_knobs", "olsr_debug_sync_fault", "olsr_live_rows_wait", "olsr_backward_rows", "olsr_last_error", "olsr_version",
 )
@@ -49,6 +49,10 @@ def lib():
     L.olsr_forward.restype = C.c_int
     L.olsr_forward_async.argtypes = [scene_p, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.olsr_forward_async.restype = C.c_int
+    L.olsr_forward_async_loss.argtypes = [scene_p, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                          C.POINTER(_abi.OlsrLossFusion), vp]
+    L.olsr_forward_async_loss.restype = C.c_int
+    L.olsr_fused_loss_scratch_bytes.argtypes, L.olsr_fused_loss_scratch_bytes.restype = [i32, i32, i32], sz
     L.olsr_backward_scratch_bytes.argtypes, L.olsr_backward_scratch_bytes.restype = [i64, i32], sz
     L.olsr_last_forward_token.argtypes, L.olsr_last_forward_token.restype = [], i32
     L.olsr_live_rows.argtypes, L.olsr_live_rows.restype = [i32, i32], i64

@@ -25,7 +25,8 @@ UNITS = [
     ("k_preprocess.hip", "k_preprocess.o", []),
     ("k_binning.hip", "k_binning.o", []),
     ("k_sort.hip", "k_sort.o", []),
-    ("k_render_fwd.hip", "k_render_fwd.o", []),
+    ("k_render_fwd.hip", "k_render_fwd.o", ["-DOLSR_FWD_TU_LOSS=0"]),
+    ("k_render_fwd.hip", "k_render_fwd_loss.o", ["-DOLSR_FWD_TU_LOSS=1"]),
     ("k_render_bwd.hip", "k_render_bwd_ref.o", ["-DOLSR_BWD_TU_MODE=0"]),
     ("k_render_bwd.hip", "k_render_bwd_exact.o", ["-DOLSR_BWD_TU_MODE=1"]),
     ("k_preprocess_bwd.hip", "k_preprocess_bwd.o", []),
@@ -35,7 +36,7 @@ UNITS = [
     ("k_adam.hip", "k_adam.o", []),
     ("k_pose.hip", "k_pose.o", []),
 ]
-HEADERS = ["olsr_device.h", "olsr_state.h", "olsr_kernels.h", os.path.join("..", "..", "include", "olsr.h")]
+HEADERS = ["olsr_device.h", "olsr_state.h", "olsr_kernels.h", "olsr_loss_device.h", os.path.join("..", "..", "include", "olsr.h")]
 
 
 def hipcc():

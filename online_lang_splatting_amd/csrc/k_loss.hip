@@ -10,25 +10,11 @@
 // adds the partials in double.
 #include "olsr_device.h"
 #include "olsr_kernels.h"
+#include "olsr_loss_device.h"
 
 namespace olsr {
 
 constexpr int LOSS_THREADS = 256;
-constexpr int LOSS_SUMS = 5;  // |rgb|, |depth|, |language|, dL/da, dL/db (unweighted sums)
-
-__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
-
-// upsample_bilinear2d, align_corners=False (ATen UpSample.h: area_pixel_compute_source_index):
-// src = scale * (dst + 0.5) - 0.5, clamped at 0; i1 = i0 + (i0 < in - 1)
-__device__ __forceinline__ void bilinear_index(int dst, float scale, int in_size, int& i0, int& i1, float& l0,
-                                               float& l1) {
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  src = (src < 0.f) ? 0.f : src;
-  i0 = min((int)src, in_size - 1);
-  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
-  l1 = src - (float)i0;
-  l0 = 1.f - l1;
-}
 
 // VEC consecutive pixels of one row per thread (VEC = 4 when W % 4 == 0: 16-byte loads and stores on
 // every plane; VEC = 1 otherwise).
@@ -96,15 +82,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
       const PixVec<VEC> x = load_px<VEC>(image + c * HW, p);
       PixVec<VEC> d;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const float ab = use_exposure ? ea * x.v[i] + eb : x.v[i];
-        const float v = ab * m.v[i] - gt[c].v[i] * m.v[i];
-        s[0] += TRACK ? op.v[i] * fabsf(v) : fabsf(v);  // l1 = opacity * |.|, :103
-        const float dab = TRACK ? op.v[i] * (sgn(v) * m.v[i]) : sgn(v) * m.v[i];  // d loss term / d(image_ab)
-        d.v[i] = wrgb * dab * ea;
-        s[3] += dab * (ea * x.v[i]);        // d(image_ab)/da = e^a image
-        s[4] += dab;
-      }
+      for (int i = 0; i < VEC; ++i)
+        d.v[i] = loss_rgb_term<TRACK>(x.v[i], gt[c].v[i], m.v[i], op.v[i], use_exposure, ea, eb, wrgb, s);
       store_px<VEC>(d_image + c * HW, p, d);
     }
     // ---- depth: |m_d * depth - m_d * gt_depth|, :144,147
@@ -113,13 +92,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
       PixVec<VEC> d;
       const float wd = (1.f - alpha) / (float)HW;
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float md = (gd.v[i] > 0.01f) ? 1.f : 0.f;
-        if constexpr (TRACK) md *= (op.v[i] > 0.95f) ? 1.f : 0.f;  // depth_pixel_mask * opacity_mask, :113-117
-        const float v = x.v[i] * md - gd.v[i] * md;
-        s[1] += fabsf(v);
-        d.v[i] = wd * sgn(v) * md;
-      }
+      for (int i = 0; i < VEC; ++i) d.v[i] = loss_depth_term<TRACK>(x.v[i], gd.v[i], op.v[i], wd, s);
       store_px<VEC>(d_depth, p, d);
     }
     // ---- language: |language - bilinear(gt_language)|, utils/slam_backend.py:579-590
@@ -140,12 +113,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
           const PixVec<VEC> l = load_px<VEC>(lang + c * HW, p);
           PixVec<VEC> d;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) {
-            const float t = ly0 * (lx0[i] * g0[x0[i]] + lx1[i] * g0[x1[i]]) + ly1 * (lx0[i] * g1[x0[i]] + lx1[i] * g1[x1[i]]);
-            const float v = l.v[i] - t;
-            s[2] += fabsf(v);
-            d.v[i] = wl * sgn(v);
-          }
+          for (int i = 0; i < VEC; ++i)
+            d.v[i] = loss_lang_term(l.v[i], g0, g1, x0[i], x1[i], lx0[i], lx1[i], ly0, ly1, wl, s);
           store_px<VEC>(d_lang + c * HW, p, d);
         }
       } else {
@@ -209,6 +178,15 @@ __global__ __launch_bounds__(256) void mapping_loss_final_kernel(const float* __
       d_exposure[1] = (float)((double)alpha * t[4] / (3.0 * HW));
     }
   }
+}
+
+// the per-tile partials of the forward composite's fused epilogue -> loss[4], dL_dexposure[2] (same final reduction)
+void launch_loss_final(const float* partials, int nb, const olsr_loss_params& p, bool tracking, bool has_lang,
+                       bool use_exposure, float* loss, float* dL_dexposure, hipStream_t st) {
+  mapping_loss_final_kernel<<<1, 256, 0, st>>>(partials, nb, p.width, p.height, tracking ? 0 : p.F,
+                                               (!tracking && has_lang) ? 1 : 0, p.alpha, p.lamda_lang, loss,
+                                               use_exposure ? dL_dexposure : nullptr);
+  if (!use_exposure && dL_dexposure) (void)hipMemsetAsync(dL_dexposure, 0, 2 * sizeof(float), st);
 }
 
 int loss_blocks(int W, int H) { return (int)(((size_t)W * H + LOSS_THREADS - 1) / LOSS_THREADS); }

@@ -29,6 +29,7 @@
 // images are bit-identical to the CPU oracle.
 #include "olsr_device.h"
 #include "olsr_kernels.h"
+#include "olsr_loss_device.h"
 
 namespace olsr {
 
@@ -56,7 +57,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ACC: 0 = the reference's rounding fma(f alpha, T, C) on the vector ALU (bit-identical to the oracle, default);
 //      1 = matrix cores (OLSR_FLAG_FWD_ACCUM_MFMA); 2 = w = alpha T once per pixel, then ONE fma(w, f, C) per channel on
 //      the vector ALU (OLSR_FLAG_FWD_ACCUM_WEIGHT: half the lane operations of the accumulation, the MFMA variant's rounding)
-template <int TILE, int F, int ACC>
+// LOSS: 0 = images only; 1 / 2 = the mapping / tracking loss evaluated in the epilogue (olsr_forward_async_loss): the pixel's
+//      colour, depth, language features and transmittance are still in registers, so the cotangents the backward consumes and
+//      the tile's partial loss sums are produced here instead of by a kernel that re-reads the images (csrc/olsr_loss_device.h).
+template <int TILE, int F, int ACC, int LOSS>
 __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FWD_ACC2_WAVES : 7)) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
@@ -64,7 +68,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     const float* __restrict__ bg, float* __restrict__ final_T, u32* __restrict__ n_contrib,
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
-    u32* __restrict__ tile_work, const u32* __restrict__ order_hint, const int32_t* __restrict__ counters) {
+    u32* __restrict__ tile_work, const u32* __restrict__ order_hint, const int32_t* __restrict__ counters,
+    const FusedLossArgs fl) {
   // a radix pass of this frame lost a predecessor's counts (olsr_state.h, counters[8]): the lists are garbage and must not be
   // used as indices — render nothing; the tile-order kernel behind this one reports OLSR_STATUS_SYNC_ERROR
   if (counters[8] != 0) return;
@@ -367,11 +372,13 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
       acc[2 * k + 1] = acc2[k].y;
     }
   }
+  const size_t HW = (size_t)H * W;
+  const u32 p = (u32)W * (u32)py + (u32)px;
   if (inside) {
-    const size_t HW = (size_t)H * W;
-    const u32 p = (u32)W * (u32)py + (u32)px;
     final_T[p] = T;
     n_contrib[p] = last_contributor;
+  }
+  if (inside && (LOSS == 0 || fl.write_images)) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) out_color[ch * HW + p] = acc[ch] + T * bg[ch];
     out_depth[p] = acc[3];
@@ -381,58 +388,220 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
       for (int ch = 0; ch < F; ++ch) out_lang[ch * HW + p] = acc[4 + ch];
     }
   }
+  if constexpr (LOSS != 0) {
+    // ---- the loss of this pixel and its cotangents, from the values the stores above hold (same expressions, same bits) ----
+    constexpr bool TRACK = (LOSS == 2);
+    float sums[LOSS_SUMS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (inside) {
+      const float ea = fl.use_exposure ? expf(fl.exposure[0]) : 1.f;
+      const float eb = fl.use_exposure ? fl.exposure[1] : 0.f;
+      const float g0 = fl.gt_image[p], g1 = fl.gt_image[HW + p], g2 = fl.gt_image[2 * HW + p];
+      float m = ((g0 + g1) + g2 > fl.thr) ? 1.f : 0.f;
+      float op = 1.f;
+      if constexpr (TRACK) {
+        op = 1 - T;
+        if (fl.grad_mask != nullptr) m *= fl.grad_mask[p];
+      }
+      const float wrgb = fl.alpha / (3.0f * (float)HW);
+      fl.d_image[p] = loss_rgb_term<TRACK>(acc[0] + T * bg[0], g0, m, op, fl.use_exposure, ea, eb, wrgb, sums);
+      fl.d_image[HW + p] = loss_rgb_term<TRACK>(acc[1] + T * bg[1], g1, m, op, fl.use_exposure, ea, eb, wrgb, sums);
+      fl.d_image[2 * HW + p] = loss_rgb_term<TRACK>(acc[2] + T * bg[2], g2, m, op, fl.use_exposure, ea, eb, wrgb, sums);
+      fl.d_depth[p] = loss_depth_term<TRACK>(acc[3], fl.gt_depth[p], op, (1.f - fl.alpha) / (float)HW, sums);
+    }
+    if constexpr (F > 0 && !TRACK) {
+      if (fl.gt_lang != nullptr) {  // (uniform)
+        // The language target is small (192 x 192 in the reference) and bilinearly enlarged: the pixels of this tile read a
+        // window of a few texels per channel.  The workgroup stages that window in LDS once (the idle feature rows) instead of
+        // every pixel gathering its 4 F corner values from global memory (60 scattered loads per pixel at F = 15 — the
+        // epilogue's cost, measured at 36 us per view with four views in flight); targets whose window does not fit (a target
+        // LARGER than the image) take the global path.  Same arithmetic, same bits, either way.
+        const float sx = (float)fl.lw / (float)W, sy = (float)fl.lh / (float)H;
+        int wx0, wx1, wy0, wy1, t_;
+        float tf0, tf1;
+        bilinear_index(bx * TILE, sx, fl.lw, wx0, t_, tf0, tf1);
+        bilinear_index(min(bx * TILE + TILE - 1, W - 1), sx, fl.lw, t_, wx1, tf0, tf1);
+        bilinear_index(by * TILE, sy, fl.lh, wy0, t_, tf0, tf1);
+        bilinear_index(min(by * TILE + TILE - 1, H - 1), sy, fl.lh, t_, wy1, tf0, tf1);
+        const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1, wn = ww * wh;
+        const bool staged = wn * F <= B * FR;
+        const size_t plane = (size_t)fl.lh * fl.lw;
+        float* s_win = s_feat;  // (idle: the last batch ended with a barrier, and tile_work's barrier is behind us)
+        if (staged) {
+          for (int i = tid; i < wn * F; i += 256) {
+            const int ch = i / wn, rem = i - ch * wn, yy = rem / ww, xx = rem - yy * ww;
+            s_win[i] = fl.gt_lang[ch * plane + (size_t)(wy0 + yy) * fl.lw + (wx0 + xx)];
+          }
+          __syncthreads();
+        }
+        if (inside) {
+          int x0, x1, y0, y1;
+          float lx0, lx1, ly0, ly1;
+          bilinear_index(px, sx, fl.lw, x0, x1, lx0, lx1);
+          bilinear_index(py, sy, fl.lh, y0, y1, ly0, ly1);
+          const float wl = fl.lamda / ((float)F * (float)HW);
+          if (staged) {
+            const float* r0w = s_win + (y0 - wy0) * ww - wx0;
+            const float* r1w = s_win + (y1 - wy0) * ww - wx0;
+#pragma unroll
+            for (int ch = 0; ch < F; ++ch)
+              fl.d_lang[ch * HW + p] =
+                  loss_lang_term(acc[4 + ch], r0w + ch * wn, r1w + ch * wn, x0, x1, lx0, lx1, ly0, ly1, wl, sums);
+          } else {
+#pragma unroll
+            for (int ch = 0; ch < F; ++ch) {
+              const float* r0p = fl.gt_lang + ch * plane + (size_t)y0 * fl.lw;
+              const float* r1p = fl.gt_lang + ch * plane + (size_t)y1 * fl.lw;
+              fl.d_lang[ch * HW + p] = loss_lang_term(acc[4 + ch], r0p, r1p, x0, x1, lx0, lx1, ly0, ly1, wl, sums);
+            }
+          }
+        }
+      }
+    }
+    // the tile's partial sums, in a fixed order: wave trees, then the four waves in rank order
+    float* s_loss = s_feat;  // (the feature rows are idle: the last batch ended with a barrier)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LOSS_SUMS; ++k) {
+      float v = sums[k];
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm);
+      if ((tid & 63) == 0) s_loss[w * LOSS_SUMS + k] = v;
+    }
+    __syncthreads();
+    if (tid < LOSS_SUMS)
+      fl.partials[(size_t)tile_id * LOSS_SUMS + tid] =
+          ((s_loss[tid] + s_loss[LOSS_SUMS + tid]) + s_loss[2 * LOSS_SUMS + tid]) + s_loss[3 * LOSS_SUMS + tid];
+  }
 }
 
-template <int TILE, int F>
-static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                         const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, int32_t* nr_dev, hipStream_t st) {
-  const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
+#ifndef OLSR_FWD_TU_LOSS
+#error "compile with -DOLSR_FWD_TU_LOSS=0 (images only) or 1 (the instantiations with the fused loss epilogue)"
+#endif
+
 #define OLSR_FWD_ARGS                                                                                                  \
   im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
       n_touched, b.flags, im.tile_work, order_inout, g.counters
+
+#if OLSR_FWD_TU_LOSS == 0
+template <int TILE, int F>
+static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                         const ImageState& im, float* out_color, float* out_language, float* out_depth,
+                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, hipStream_t st) {
+  const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
+  const FusedLossArgs none{};
   if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
-    render_fwd_kernel<TILE, F, 1><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
+    render_fwd_kernel<TILE, F, 1, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
   else if (s.flags & OLSR_FLAG_FWD_ACCUM_WEIGHT)
-    render_fwd_kernel<TILE, F, 2><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
+    render_fwd_kernel<TILE, F, 2, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
   else
-    render_fwd_kernel<TILE, F, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS);
-#undef OLSR_FWD_ARGS
-  const RowsMailbox& rm = rows_mailbox_of_this_call();
-  launch_tile_order(im.tile_work, im.tile_order, order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, g.counters, nr_dev,
-                    rm.sticky, st);
+    render_fwd_kernel<TILE, F, 0, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
 }
+#else
+template <int TILE, int F>
+static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                         const ImageState& im, float* out_color, float* out_language, float* out_depth,
+                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, const olsr_loss_fusion& lf,
+                         hipStream_t st) {
+  const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
+  const bool lang_term = !lf.tracking && lf.params.F > 0 && lf.gt_language != nullptr;
+  FusedLossArgs fl{};
+  fl.gt_image = lf.gt_image;
+  fl.gt_depth = lf.gt_depth;
+  fl.gt_lang = lang_term ? lf.gt_language : nullptr;
+  fl.exposure = lf.exposure;
+  fl.grad_mask = lf.grad_mask;
+  fl.d_image = lf.dL_dimage;
+  fl.d_depth = lf.dL_ddepth;
+  fl.d_lang = lf.dL_dlanguage;
+  fl.partials = reinterpret_cast<float*>(lf.scratch);
+  fl.lw = lf.params.lang_width;
+  fl.lh = lf.params.lang_height;
+  fl.use_exposure = (lf.exposure != nullptr && !lf.params.initialization) ? 1 : 0;
+  fl.write_images = lf.skip_images ? 0 : 1;
+  fl.alpha = lf.params.alpha;
+  fl.thr = lf.params.rgb_boundary_threshold;
+  fl.lamda = lf.params.lamda_lang;
+  if (lf.tracking)
+    render_fwd_kernel<TILE, F, 0, 2><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
+  else
+    render_fwd_kernel<TILE, F, 0, 1><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
+  olsr_loss_params p = lf.params;
+  p.F = s.F;  // (the language term is normalised by the channels it sums over)
+  launch_loss_final(fl.partials, d.ntiles, p, lf.tracking != 0, lang_term, fl.use_exposure != 0, lf.loss, lf.dL_dexposure, st);
+}
+#endif
+#undef OLSR_FWD_ARGS
+
+#if OLSR_FWD_TU_LOSS == 0
+#define OLSR_FWD_EXTRA
+#define OLSR_FWD_EXTRA_DECL
+#define OLSR_FWD_NAME launch_render_forward_images
+#else
+#define OLSR_FWD_EXTRA , lf
+#define OLSR_FWD_EXTRA_DECL , const olsr_loss_fusion& lf
+#define OLSR_FWD_NAME launch_render_forward_loss
+#endif
 
 template <int TILE>
 static void launch_fwd_f(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, float* oc, float* ol, float* od, float* oo, int32_t* nt,
-                         uint32_t* ord, int32_t* nr_dev, hipStream_t st) {
-  switch (s.F) {
-    case 0: launch_fwd_t<TILE, 0>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
-    case 3: launch_fwd_t<TILE, 3>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
-    case 15: launch_fwd_t<TILE, 15>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
-    case 16: launch_fwd_t<TILE, 16>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
-    case 32: launch_fwd_t<TILE, 32>(s, d, g, b, im, oc, ol, od, oo, nt, ord, nr_dev, st); break;
+                         uint32_t* ord OLSR_FWD_EXTRA_DECL, hipStream_t st) {
+  int F = s.F;
+#if OLSR_FWD_TU_LOSS == 1
+  // The tracking loss reads colour, depth and opacity only (utils/slam_utils.py:92-121).  When the images are not written
+  // either, nothing consumes the language accumulation: the RGB instantiation composites the same colour / depth / T with the
+  // same decisions (n_contrib, flags, n_touched are bit-identical) on the language scene's state — 19 instead of 34
+  // accumulated lane-values per blend.
+  if (lf.tracking && lf.skip_images) F = 0;
+#endif
+  switch (F) {
+    case 0: launch_fwd_t<TILE, 0>(s, d, g, b, im, oc, ol, od, oo, nt, ord OLSR_FWD_EXTRA, st); break;
+    case 3: launch_fwd_t<TILE, 3>(s, d, g, b, im, oc, ol, od, oo, nt, ord OLSR_FWD_EXTRA, st); break;
+    case 15: launch_fwd_t<TILE, 15>(s, d, g, b, im, oc, ol, od, oo, nt, ord OLSR_FWD_EXTRA, st); break;
+    case 16: launch_fwd_t<TILE, 16>(s, d, g, b, im, oc, ol, od, oo, nt, ord OLSR_FWD_EXTRA, st); break;
+    case 32: launch_fwd_t<TILE, 32>(s, d, g, b, im, oc, ol, od, oo, nt, ord OLSR_FWD_EXTRA, st); break;
     default: break;
   }
 }
 
+// (two translation units so that they compile in parallel: the images-only instantiations, and those with the loss epilogue)
+void OLSR_FWD_NAME(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                   const ImageState& im, float* out_color, float* out_language, float* out_depth, float* out_opacity,
+                   int32_t* n_touched, uint32_t* tile_order_inout OLSR_FWD_EXTRA_DECL, hipStream_t st) {
+  if (d.tile == 15)
+    launch_fwd_f<15>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout
+                     OLSR_FWD_EXTRA, st);
+  else
+    launch_fwd_f<16>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout
+                     OLSR_FWD_EXTRA, st);
+}
+
+#if OLSR_FWD_TU_LOSS == 0
+void launch_render_forward_loss(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                                const ImageState& im, float* out_color, float* out_language, float* out_depth,
+                                float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout,
+                                const olsr_loss_fusion& lf, hipStream_t st);
+
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                            const ImageState& im, float* out_color, float* out_language, float* out_depth,
                            float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, int32_t* num_rendered_dev,
-                           hipStream_t st) {
-  if (d.tile == 15)
-    launch_fwd_f<15>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
-                     num_rendered_dev, st);
+                           const olsr_loss_fusion* loss, hipStream_t st) {
+  if (loss != nullptr)
+    launch_render_forward_loss(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
+                               *loss, st);
   else
-    launch_fwd_f<16>(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
-                     num_rendered_dev, st);
+    launch_render_forward_images(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched,
+                                 tile_order_inout, st);
+  const RowsMailbox& rm = rows_mailbox_of_this_call();
+  launch_tile_order(im.tile_work, im.tile_order, tile_order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, g.counters,
+                    num_rendered_dev, rm.sticky, st);
 }
+#endif
 
 }  // namespace olsr
 
-#ifdef OLSR_FWD_STATS
+#if defined(OLSR_FWD_STATS) && OLSR_FWD_TU_LOSS == 0
 extern "C" void olsr_debug_fwd_stats(unsigned long long* out8, int reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(olsr::g_fwd_stats), 8 * sizeof(unsigned long long));

@@ -189,7 +189,8 @@ const char* const STICKY_MSG =
 
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
-                 int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st) {
+                 int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st,
+                 const olsr_loss_fusion* loss = nullptr) {
   const FrameDims d = frame_dims(s);
   const size_t N = (size_t)d.W * d.H;
   size_t gb, ib, bb;
@@ -197,7 +198,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   const ImageState im = ImageState::carve(img_buf, N, (size_t)d.ntiles, ib);
   mark("begin", st);
 
-  if (!out_color || !out_depth || !out_opacity || (s.F > 0 && !out_language))
+  if (!(loss && loss->skip_images) && (!out_color || !out_depth || !out_opacity || (s.F > 0 && !out_language)))
     return fail(OLSR_ERR_ARG, "output image pointers must not be NULL");
   if (s.P > 0 && (!radii || !n_touched)) return fail(OLSR_ERR_ARG, "radii and n_touched must not be NULL");
 
@@ -332,7 +333,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     g_rows_call.sticky = g_rows.dp + 4 * ROWS_RING;
   }
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
-                        num_rendered_dev, st);
+                        num_rendered_dev, (s.P > 0) ? loss : nullptr, st);
   g_rows_call = RowsMailbox{};
   STAGE("render_forward");
 
@@ -527,6 +528,44 @@ int olsr_forward_async(const olsr_scene* scene, void* geometry_buffer, void* bin
   bp.capacity = capacity;
   return forward_impl(*scene, geometry_buffer, image_buffer, bp, out_color, out_language, out_depth, out_opacity,
                       radii, n_touched, nullptr, num_rendered_dev, tile_order_inout, (hipStream_t)hip_stream);
+}
+
+size_t olsr_fused_loss_scratch_bytes(int32_t width, int32_t height, int32_t tile) {
+  if (width <= 0 || height <= 0 || (tile != 15 && tile != 16)) return 0;
+  const size_t tiles = (size_t)((width + tile - 1) / tile) * (size_t)((height + tile - 1) / tile);
+  return align_up(tiles * 5 * sizeof(float)) + ALIGN;
+}
+
+int olsr_forward_async_loss(const olsr_scene* scene, void* geometry_buffer, void* binning_buffer, int64_t capacity,
+                            void* image_buffer, float* out_color, float* out_language, float* out_depth,
+                            float* out_opacity, int32_t* radii, int32_t* n_touched, int32_t* num_rendered_dev,
+                            uint32_t* tile_order_inout, const olsr_loss_fusion* loss, void* hip_stream) {
+  if (!loss)
+    return olsr_forward_async(scene, geometry_buffer, binning_buffer, capacity, image_buffer, out_color, out_language,
+                              out_depth, out_opacity, radii, n_touched, num_rendered_dev, tile_order_inout, hip_stream);
+  int rc = check_scene(scene, false);
+  if (rc != OLSR_OK) return rc;
+  if (!geometry_buffer || !binning_buffer || !image_buffer || capacity < 0)
+    return fail(OLSR_ERR_ARG, "state buffers and a non-negative capacity are required");
+  const olsr_loss_params& lp = loss->params;
+  if (lp.width != scene->width || lp.height != scene->height)
+    return fail(OLSR_ERR_ARG, "fused loss: params.width / height must equal the scene's");
+  if (scene->flags & (OLSR_FLAG_FWD_ACCUM_MFMA | OLSR_FLAG_FWD_ACCUM_WEIGHT))
+    return fail(OLSR_ERR_ARG, "fused loss: only with the default forward accumulation");
+  if (!loss->gt_image || !loss->gt_depth || !loss->dL_dimage || !loss->dL_ddepth || !loss->loss || !loss->scratch)
+    return fail(OLSR_ERR_ARG, "fused loss: gt_image, gt_depth, dL_dimage, dL_ddepth, loss and scratch are required");
+  const bool lang_term = !loss->tracking && lp.F > 0 && loss->gt_language != nullptr;
+  if (lang_term && (lp.F != scene->F || !loss->dL_dlanguage || lp.lang_width <= 0 || lp.lang_height <= 0))
+    return fail(OLSR_ERR_ARG, "fused loss: a language term needs params.F == scene F, dL_dlanguage and the target's size");
+  if (scene->P <= 0)  // nothing is rendered (the images are the background): the stand-alone kernels define this case
+    return fail(OLSR_ERR_ARG, "fused loss: P must be > 0 (use olsr_mapping_loss / olsr_tracking_loss on an empty render)");
+  olsr_loss_fusion lf = *loss;
+  lf.scratch = (void*)(((uintptr_t)loss->scratch + ALIGN - 1) / ALIGN * ALIGN);
+  BinningProvider bp;
+  bp.fixed = binning_buffer;
+  bp.capacity = capacity;
+  return forward_impl(*scene, geometry_buffer, image_buffer, bp, out_color, out_language, out_depth, out_opacity, radii,
+                      n_touched, nullptr, num_rendered_dev, tile_order_inout, (hipStream_t)hip_stream, &lf);
 }
 
 int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_buffer, int32_t num_rendered,

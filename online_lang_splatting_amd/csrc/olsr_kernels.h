@@ -95,10 +95,11 @@ void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_laun
 void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
 
 // k_render_fwd.hip
+// loss (may be null): evaluate the mapping / tracking loss in the composite's epilogue (olsr_forward_async_loss)
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                            const ImageState& im, float* out_color, float* out_language, float* out_depth,
                            float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, int32_t* num_rendered_dev,
-                           hipStream_t st);
+                           const olsr_loss_fusion* loss, hipStream_t st);
 
 // k_render_bwd.hip
 // (two translation units, one per backward mode, so they compile in parallel)
@@ -149,6 +150,8 @@ void launch_knn(int P, const float* points, float* mean_dist2, void* scratch, hi
 
 // k_loss.hip
 int loss_blocks(int W, int H);
+void launch_loss_final(const float* partials, int nb, const olsr_loss_params& p, bool tracking, bool has_lang,
+                       bool use_exposure, float* loss, float* dL_dexposure, hipStream_t st);
 void launch_mapping_loss(const olsr_loss_params& p, const float* image, const float* depth, const float* language,
                          const float* gt_image, const float* gt_depth, const float* gt_language, const float* exposure,
                          const float* opacity, const float* grad_mask, bool tracking, float* dL_dimage,

@@ -396,6 +396,55 @@ class RasterWorkspace:
             self.tile_order.data_ptr(), self._stream()))
         return o
 
+    def forward_loss(self, gt_image, gt_depth, gt_language=None, exposure=None, grad_mask=None, *, tracking=False,
+                     alpha=0.95, rgb_boundary_threshold=0.01, lamda_lang=1.0, initialization=False, skip_images=True):
+        """The forward with the mapping (tracking=False) or tracking loss evaluated in the composite kernel's epilogue
+        (olsr_forward_async_loss): no separate loss kernel, the rendered images make no round trip.  Targets as
+        losses.mapping_loss / losses.tracking_loss take them, already float32 and contiguous on the workspace's device.
+        skip_images: the images are not written at all (self.out keeps whatever it held).
+        Returns dict(loss[4], dL_dimage, dL_ddepth, dL_dlanguage or None, dL_dexposure[2]) — workspace-owned buffers that
+        the next call overwrites; hand the three cotangents to backward()."""
+        f32 = dict(dtype=torch.float32, device=self.device)
+        if getattr(self, "_fl", None) is None:
+            L = lib()
+            self._fl = dict(loss=torch.empty(4, **f32), dL_dimage=torch.empty(3, self.H, self.W, **f32),
+                            dL_ddepth=torch.empty(1, self.H, self.W, **f32), dL_dexposure=torch.empty(2, **f32),
+                            dL_dlanguage=torch.empty(self.F, self.H, self.W, **f32) if self.F > 0 else None,
+                            scratch=torch.empty(L.olsr_fused_loss_scratch_bytes(self.W, self.H, self.tile),
+                                                dtype=torch.uint8, device=self.device))
+        fl = self._fl
+        lang = (not tracking) and self.F > 0 and gt_language is not None
+        for name, t in (("gt_image", gt_image), ("gt_depth", gt_depth), ("gt_language", gt_language if lang else None),
+                        ("exposure", exposure), ("grad_mask", grad_mask)):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()
+                                  or t.device != self.device):
+                raise RuntimeError(f"forward_loss: {name} must be a contiguous float32 tensor on {self.device}")
+        if tuple(gt_image.shape) != (3, self.H, self.W) or gt_depth.numel() != self.H * self.W:
+            raise RuntimeError("forward_loss: gt_image must be [3,H,W] and gt_depth [H,W] of the workspace's size")
+        if grad_mask is not None and grad_mask.numel() != self.H * self.W:
+            raise RuntimeError("forward_loss: grad_mask must be [H,W]")
+        if lang and (gt_language.dim() != 3 or gt_language.shape[0] != self.F):
+            raise RuntimeError("forward_loss: gt_language must be [F,h,w]")
+        p = _abi.OlsrLossParams(width=self.W, height=self.H, F=self.F if lang else 0,
+                                lang_width=gt_language.shape[2] if lang else 0,
+                                lang_height=gt_language.shape[1] if lang else 0, initialization=int(bool(initialization)),
+                                alpha=float(alpha), rgb_boundary_threshold=float(rgb_boundary_threshold),
+                                lamda_lang=float(lamda_lang))
+        ptr = lambda t: t.data_ptr() if t is not None and t.numel() > 0 else None  # noqa: E731
+        lf = _abi.OlsrLossFusion(params=p, tracking=int(bool(tracking)), skip_images=int(bool(skip_images)),
+                                 gt_image=ptr(gt_image), gt_depth=ptr(gt_depth), gt_language=ptr(gt_language) if lang else None,
+                                 exposure=ptr(exposure), grad_mask=ptr(grad_mask), dL_dimage=ptr(fl["dL_dimage"]),
+                                 dL_ddepth=ptr(fl["dL_ddepth"]), dL_dlanguage=ptr(fl["dL_dlanguage"]) if lang else None,
+                                 loss=ptr(fl["loss"]), dL_dexposure=ptr(fl["dL_dexposure"]), scratch=ptr(fl["scratch"]))
+        o = self.out
+        check(lib().olsr_forward_async_loss(
+            C.byref(self._scene), self.geom.data_ptr(), self.binning.data_ptr(), self.capacity, self.img.data_ptr(),
+            o["color"].data_ptr(), o["language"].data_ptr() if self.F > 0 else None, o["depth"].data_ptr(),
+            o["opacity"].data_ptr(), o["radii"].data_ptr(), o["n_touched"].data_ptr(), self.num_rendered.data_ptr(),
+            self.tile_order.data_ptr(), C.byref(lf), self._stream()))
+        return dict(loss=fl["loss"], dL_dimage=fl["dL_dimage"], dL_ddepth=fl["dL_ddepth"],
+                    dL_dlanguage=fl["dL_dlanguage"] if lang else None, dL_dexposure=fl["dL_dexposure"])
+
     def backward(self, dL_dcolor, dL_dlanguage, dL_ddepth, bucket=None, first=False, bucket_only=False,
                  pose_only=False):
         """Backward of the last forward.  With `bucket` (a GradientBucket) the per-Gaussian backward kernel also
@@ -502,6 +551,10 @@ class FrameShardedStep:
         self.owned = GradientBucket.owned_rows(ws.P, rank, world)
         self.wire = None  # dict from the sparse exchange
         # per lane: max over its views {R, live rows} and the overflow flag (stay on the device, on the lane's stream)
+        # launch-order hints of the forward composite, one per VIEW index (created on first use): consecutive steps of a
+        # mapping call render the same window of keyframes, and a view's own previous order is worth 25-35 % of its forward
+        # composite against the order of whatever the lane rendered last (slam_iterations.MappingStep)
+        self.view_hints: Dict[int, torch.Tensor] = {}
         self._need = [torch.zeros(2, dtype=torch.int32, device=ws.device) for _ in self.lanes]
         self._ovf = [torch.zeros(1, dtype=torch.int32, device=ws.device) for _ in self.lanes]
 
@@ -534,7 +587,10 @@ class FrameShardedStep:
             if first:
                 used.append(i)
             cam = cameras[v]
+            if v not in self.view_hints:
+                self.view_hints[v] = torch.arange(ws.tile_order.numel(), dtype=torch.int32, device=ws.device)
             with torch.cuda.stream(st):
+                ws.tile_order = self.view_hints[v]
                 ws.set_scene(sh_degree=sh_degree, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
                              projmatrix_raw=cam["projmatrix_raw"], campos=cam["campos"], tanfovx=cam["tanfovx"],
                              tanfovy=cam["tanfovy"], **gaussians)

@@ -88,12 +88,22 @@ class TrackingLoop:
 
     def __init__(self, workspace: RasterWorkspace, gaussians: Dict[str, torch.Tensor], sh_degree: int, pose: PoseState,
                  gt_image: torch.Tensor, gt_depth: torch.Tensor, grad_mask: Optional[torch.Tensor] = None,
-                 alpha=0.95, rgb_boundary_threshold=0.01, language_cotangent: str = "null"):
+                 alpha=0.95, rgb_boundary_threshold=0.01, language_cotangent: str = "null", fused_loss: bool = True):
         """language_cotangent: "null" — olsr_backward gets no language cotangent (what the tracking loss means; the RGB
         instantiation of the composite backward runs); "zeros" — a zero-filled [F,H,W] cotangent through the language
         backward (what autograd materialises for the reference, kept for comparison)."""
         assert language_cotangent in ("null", "zeros")
         self.ws, self.g, self.sh_degree, self.pose = workspace, gaussians, sh_degree, pose
+        # fused_loss (default): the tracking loss is evaluated in the forward composite's epilogue (olsr_forward_async_loss):
+        # no loss kernel, no image round trip, the images themselves are not written.  False: olsr_forward_async +
+        # olsr_tracking_loss, the two-kernel path (same cotangents bit for bit; tests/test_gpu_loss.py).
+        self.fused = bool(fused_loss)
+        f32 = dict(device=workspace.device, dtype=torch.float32)
+        gt_image, gt_depth = gt_image.detach().to(**f32).contiguous(), gt_depth.detach().to(**f32).contiguous()
+        if gt_depth.dim() == 3:
+            gt_depth = gt_depth.reshape(gt_depth.shape[-2], gt_depth.shape[-1])
+        if grad_mask is not None:
+            grad_mask = grad_mask.detach().to(**f32).reshape(gt_depth.shape).contiguous()
         self.gt_image, self.gt_depth, self.grad_mask = gt_image, gt_depth, grad_mask
         self.alpha, self.thr = alpha, rgb_boundary_threshold
         dev = workspace.device
@@ -122,9 +132,14 @@ class TrackingLoop:
     def iteration(self, read_convergence=False) -> bool:
         ws = self.ws
         ws.set_scene(sh_degree=self.sh_degree, **self.pose.camera(), **self.g)
-        out = ws.forward()
-        lo = losses.tracking_loss(out["color"], out["depth"], out["opacity"], self.gt_image, self.gt_depth,
-                                  self.grad_mask, self.pose.exposure, alpha=self.alpha, rgb_boundary_threshold=self.thr)
+        if self.fused:
+            lo = ws.forward_loss(self.gt_image, self.gt_depth, None, self.pose.exposure, self.grad_mask, tracking=True,
+                                 alpha=self.alpha, rgb_boundary_threshold=self.thr, skip_images=True)
+        else:
+            out = ws.forward()
+            lo = losses.tracking_loss(out["color"], out["depth"], out["opacity"], self.gt_image, self.gt_depth,
+                                      self.grad_mask, self.pose.exposure, alpha=self.alpha,
+                                      rgb_boundary_threshold=self.thr)
         self.loss = lo["loss"]
         g = ws.backward(lo["dL_dimage"], self.zero_lang, lo["dL_ddepth"], pose_only=True)
         self.pose.step(g["dL_dtau_sum"], lo["dL_dexposure"])
@@ -139,12 +154,42 @@ class MappingStep:
 
     def __init__(self, lanes: FrameLanes, params: Dict[str, torch.Tensor], bg: torch.Tensor, sh_degree: int,
                  cameras: Sequence[Dict], targets: Sequence, lrs: Dict[str, float], exposure=None,
-                 activations=_abi.ACT_ALL):
+                 activations=_abi.ACT_ALL, fused_loss: bool = True):
+        """targets[v] = (gt_image [3,H,W], gt_depth [H,W], gt_language [F,h,w] or None); fused_loss (default): the mapping
+        loss is evaluated in the forward composite's epilogue (olsr_forward_async_loss) instead of by olsr_mapping_loss."""
         self.lanes, self.params, self.bg, self.sh_degree = lanes, params, bg, sh_degree
-        self.cameras, self.targets, self.lrs, self.exposure, self.act = cameras, targets, lrs, exposure, activations
+        self.cameras, self.lrs, self.exposure, self.act = cameras, lrs, exposure, activations
+        self.fused = bool(fused_loss)
+        self.targets = targets
         ws0 = lanes.lanes[0][0]
         self.adam = FusedAdam(ws0.P, GradLayout(ws0.M, ws0.F), ws0.device)
         self.last_loss = None
+        # profile = True: iteration() brackets its caller-side steps (the stand-alone loss kernel, the sum of the lane
+        # buckets, the Adam step) with HIP events and leaves (name, ms) pairs in self.stage_ms — for bench.py's breakdown;
+        # an event is a barrier packet on its stream, so timed runs keep it off
+        self.profile = False
+        self.stage_ms = []
+        # Launch-order hint of the forward composite, one PER VIEW: a mapping call iterates over the same window of keyframes
+        # (utils/slam_backend.py:510-670), so view v's heaviest-first tile order of the previous iteration is the right hint
+        # for it — the lane's own previous frame was another view, and a stale order costs the forward composite 25-35 %
+        # (measured, scripts/probe/arc_views.py: 0.17 -> 0.23 ms at config 3; the order cannot be predicted from the list
+        # lengths, which correlate with the measured work at -0.4 .. 0.8).
+        self.view_hints = [ws0.tile_order.clone() for _ in cameras]
+
+    @property
+    def targets(self):
+        return self._targets
+
+    @targets.setter
+    def targets(self, targets):
+        """Targets are converted ONCE to contiguous float32 on the device (the reference keeps gt_lang_feat on the CPU and
+        moves it every iteration, utils/slam_backend.py:576)."""
+        if targets is None:
+            self._targets = None
+            return
+        dev = self.lanes.device
+        cv = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        self._targets = [(cv(a), cv(b.reshape(b.shape[-2], b.shape[-1])), cv(c)) for a, b, c in targets]
 
     def render(self, ws, cam):
         ws.set_scene(bg=self.bg, sh_degree=self.sh_degree, activations=self.act, **cam, **self.params)
@@ -155,6 +200,13 @@ class MappingStep:
         dev = lanes.device
         used = []
         main = torch.cuda.current_stream(dev)
+        marks = []
+
+        def mark(name, stream):
+            if self.profile:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(stream)
+                marks.append((name, ev))
         for _, _, st in lanes.lanes:  # the parameters (and, the first time, the targets) were written on the caller's stream
             if st != main:
                 st.wait_stream(main)
@@ -164,20 +216,43 @@ class MappingStep:
             if first:
                 used.append(bucket)
             with torch.cuda.stream(stream):
-                out = self.render(ws, cam)
-                lo = losses.mapping_loss(out["color"], out["depth"], out["language"] if ws.F > 0 else None,
-                                         *self.targets[v], self.exposure)
-                ws.backward(lo["dL_dimage"], lo["dL_dlanguage"] if ws.F > 0 else None, lo["dL_ddepth"], bucket=bucket,
-                            first=first, bucket_only=True)
+                ws.tile_order = self.view_hints[v]   # in: this view's order of the last iteration; out: this iteration's
+                if self.fused:
+                    ws.set_scene(bg=self.bg, sh_degree=self.sh_degree, activations=self.act, **cam, **self.params)
+                    lo = ws.forward_loss(*self.targets[v], self.exposure, skip_images=True)
+                else:
+                    out = self.render(ws, cam)
+                    mark("loss:begin", stream)
+                    lo = losses.mapping_loss(out["color"], out["depth"], out["language"] if ws.F > 0 else None,
+                                             *self.targets[v], self.exposure)
+                    mark("loss:end", stream)
+                    if ws.F > 0 and self.targets[v][2] is None:
+                        lo["dL_dlanguage"] = None
+                ws.backward(lo["dL_dimage"], lo["dL_dlanguage"], lo["dL_ddepth"], bucket=bucket, first=first,
+                            bucket_only=True)
                 self.last_loss = lo["loss"]
         for _, _, st in lanes.lanes:
             main.wait_stream(st)
         total = used[0]
+        mark("lane_sum:begin", main)
         for b in used[1:]:
             total.sum_storage.add_(b.sum_storage)
             torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
+        mark("lane_sum:end", main)
         total.all_reduce()
+        mark("adam:begin", main)
         self.adam.step(total, self.params, self.lrs)
+        mark("adam:end", main)
         for _, _, st in lanes.lanes:
             st.wait_stream(main)
+        if self.profile:
+            torch.cuda.synchronize(dev)
+            self.stage_ms = []
+            open_ = {}
+            for name, ev in marks:
+                stage, edge = name.split(":")
+                if edge == "begin":
+                    open_[stage] = ev
+                else:
+                    self.stage_ms.append((stage, open_.pop(stage).elapsed_time(ev)))
         return total

@@ -60,11 +60,17 @@ def test_config3_line_carries_the_config4_substitute():
     trk = c4["tracking"]["ms_per_iteration"]
     assert set(trk) == {"no_language_cotangent", "no_language_cotangent_with_convergence_readback",
                         "zero_language_cotangent", "zero_language_cotangent_with_convergence_readback",
-                        "rgb_rasterizer_render", "no_language_cotangent_hip_graph_replay"}
+                        "rgb_rasterizer_render", "no_language_cotangent_hip_graph_replay",
+                        "no_language_cotangent_two_kernel_loss"}
     assert trk["no_language_cotangent_hip_graph_replay"] < 1.15 * trk["no_language_cotangent"]
     assert c4["tracking"]["pose_error_after"] < c4["tracking"]["pose_error_start"]  # it moved towards the target pose
     assert not c4["mapping"]["capacity_overflow"] and c4["mapping"]["views"] == 12
     assert c4["mapping"]["loss_last_view_final_iteration"] < c4["mapping"]["loss_last_view_first_iteration"]
+    two = c4["mapping"]["two_kernel_loss"]   # the round-3 formulation beside the fused one: same losses, its own breakdown
+    assert abs(two["loss_last_view_final_iteration"] - c4["mapping"]["loss_last_view_final_iteration"]) < 1e-5
+    prof, prof2 = c4["mapping"]["profiled_iteration"], two["profiled_iteration"]
+    assert prof["adam_ms"] > 0 and prof["lane_sum_ms"] > 0 and "loss" not in prof["stage_ms_per_view"]
+    assert prof2["stage_ms_per_view"]["loss"] > 0 and prof["stage_ms_per_view"]["render_backward"] > 0
     assert set(d["bracket"]) == {"exact_mode", "tile16", "rect_binning", "fwd_accum_weight"}
     assert d["bracket"]["fwd_accum_weight"]["forward_accumulation"] == "weight"
     valu = d["roofline"].get("valu")

@@ -212,3 +212,100 @@ def test_mapping_iterations_reduce_the_loss(hip):
         hist.append(total)
     assert all(torch.isfinite(t).all() for t in params.values())
     assert hist[-1] < 0.6 * hist[0], (hist[0], hist[-1])
+
+
+# ---- the loss in the forward composite's epilogue (olsr_forward_async_loss) ---------------------------------------------
+def _fused_case(F, W, H, tile, seed, bg=None, lang_hw=(37, 53)):
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    from online_lang_splatting_amd.scene import make_scene
+    dev = torch.device(DEV)
+    sc = make_scene(5000, W, H, F, seed=seed, bg=bg)
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=None if F == 0 else sc.language.to(dev))
+    cam = sc.camera
+    c = dict(viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+             projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+             tanfovy=cam.tanfovy)
+    ws = RasterWorkspace(sc.P, W, H, F, sc.shs.shape[1], 400000, dev, tile=tile)
+    ws.set_scene(sh_degree=sc.sh_degree, **c, **g)
+    gen = torch.Generator().manual_seed(seed + 1)
+    gt_image = torch.rand(3, H, W, generator=gen)
+    gt_image[:, : H // 3] *= 0.001                       # below the rgb boundary threshold
+    gt_depth = torch.rand(H, W, generator=gen) * 5
+    gt_depth[:, : W // 4] = 0.0                          # invalid depth
+    gt_lang = torch.nn.functional.normalize(torch.randn(max(F, 1), lang_hw[0], lang_hw[1], generator=gen), dim=0)[:F] if F else None
+    grad_mask = (torch.rand(H, W, generator=gen) > 0.3).float()
+    exposure = torch.tensor([0.11, -0.03])
+    mv = lambda t: None if t is None else t.to(dev).contiguous()
+    return ws, mv(gt_image), mv(gt_depth), mv(gt_lang), mv(grad_mask), mv(exposure)
+
+
+@pytest.mark.parametrize("F,W,H,tile,lang_hw", [(15, 200, 150, 15, (37, 53)), (0, 157, 101, 15, (37, 53)),
+                                                (32, 128, 96, 16, (37, 53)), (3, 64, 64, 15, (200, 300)),
+                                                (16, 171, 93, 16, (93, 171)), (15, 1200, 680, 15, (192, 192))])
+@pytest.mark.parametrize("use_exposure", [True, False])
+def test_fused_mapping_loss_equals_the_two_kernel_path(hip, F, W, H, tile, lang_hw, use_exposure):
+    """olsr_forward_async_loss against olsr_forward_async + olsr_mapping_loss on the same render: the cotangents are
+    bit-identical (same per-pixel source, csrc/olsr_loss_device.h), the loss and the exposure gradient agree to the
+    summation order (per-tile instead of per-256-pixel partials), the state the backward reads is the same, and so the
+    gradients are bit-identical.  The stand-alone kernel is what the reference-generated goldens pin."""
+    from online_lang_splatting_amd import losses
+    # (the language target's window of a tile is staged in LDS when it fits — a small target enlarged, the reference's 192 x 192
+    #  at 1200 x 680, an identity-size one — and gathered from global memory when it does not: a 200 x 300 target for 64 x 64)
+    ws, gt_image, gt_depth, gt_lang, _, exposure = _fused_case(F, W, H, tile, seed=300 + F, bg=torch.tensor([0.2, 0.1, 0.3]),
+                                                               lang_hw=lang_hw)
+    ex = exposure if use_exposure else None
+    out = ws.forward()
+    two = losses.mapping_loss(out["color"], out["depth"], out["language"] if F else None, gt_image, gt_depth, gt_lang, ex)
+    g2 = {k: v.clone() for k, v in ws.backward(two["dL_dimage"], two["dL_dlanguage"] if F else None, two["dL_ddepth"]).items()}
+    images = {k: out[k].clone() for k in ("color", "depth", "opacity", "language")}
+    for skip in (False, True):
+        for k in images:
+            ws.out[k].fill_(-7.0)
+        fu = ws.forward_loss(gt_image, gt_depth, gt_lang, ex, skip_images=skip)
+        torch.cuda.synchronize()
+        for k in images:  # written exactly as by the plain forward, or not at all
+            assert torch.equal(ws.out[k], images[k] if not skip else torch.full_like(images[k], -7.0)), (k, skip)
+        assert torch.equal(fu["dL_dimage"], two["dL_dimage"]) and torch.equal(fu["dL_ddepth"], two["dL_ddepth"])
+        if F:
+            assert torch.equal(fu["dL_dlanguage"], two["dL_dlanguage"])
+        else:
+            assert fu["dL_dlanguage"] is None
+        _close(fu["loss"], two["loss"], "loss")
+        assert float(two["loss"][0]) > 0 and (F == 0 or float(two["loss"][3]) > 0)
+        assert float((fu["dL_dexposure"] - two["dL_dexposure"]).abs().max()) <= 1e-6
+        gf = ws.backward(fu["dL_dimage"], fu["dL_dlanguage"], fu["dL_ddepth"])
+        for k in g2:
+            assert torch.equal(gf[k], g2[k]), k
+
+
+@pytest.mark.parametrize("F,W,H,tile", [(15, 200, 150, 15), (0, 157, 101, 16)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_fused_tracking_loss_equals_the_two_kernel_path(hip, F, W, H, tile, masked):
+    from online_lang_splatting_amd import losses
+    ws, gt_image, gt_depth, _, grad_mask, exposure = _fused_case(F, W, H, tile, seed=400 + F)
+    gm = grad_mask if masked else None
+    out = ws.forward()
+    two = losses.tracking_loss(out["color"], out["depth"], out["opacity"], gt_image, gt_depth, gm, exposure)
+    g2 = ws.backward(two["dL_dimage"], None, two["dL_ddepth"], pose_only=True)["dL_dtau_sum"].clone()
+    fu = ws.forward_loss(gt_image, gt_depth, None, exposure, gm, tracking=True)
+    assert fu["dL_dlanguage"] is None
+    assert torch.equal(fu["dL_dimage"], two["dL_dimage"]) and torch.equal(fu["dL_ddepth"], two["dL_ddepth"])
+    _close(fu["loss"], two["loss"], "loss")
+    assert float((fu["dL_dexposure"] - two["dL_dexposure"]).abs().max()) <= 1e-6
+    gf = ws.backward(fu["dL_dimage"], None, fu["dL_ddepth"], pose_only=True)["dL_dtau_sum"]
+    assert torch.equal(gf, g2) and float(g2.abs().max()) > 0
+
+
+def test_fused_loss_argument_checks(hip):
+    from online_lang_splatting_amd import _abi
+    from online_lang_splatting_amd._lib import OlsrError
+    ws, gt_image, gt_depth, gt_lang, _, _ = _fused_case(15, 64, 48, 15, seed=9)
+    with pytest.raises(RuntimeError):
+        ws.forward_loss(gt_image.cpu(), gt_depth)
+    with pytest.raises(RuntimeError):
+        ws.forward_loss(gt_image[:, :10].contiguous(), gt_depth)
+    ws.flags = _abi.FLAG_FWD_ACCUM_WEIGHT
+    ws._scene.flags = _abi.FLAG_FWD_ACCUM_WEIGHT
+    with pytest.raises(OlsrError, match="default forward accumulation"):
+        ws.forward_loss(gt_image, gt_depth, gt_lang)
