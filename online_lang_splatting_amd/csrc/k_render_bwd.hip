@@ -65,12 +65,19 @@ constexpr int BWD_BATCH = 128;
 #ifndef OLSR_BWD_LDS_REDUCE
 #define OLSR_BWD_LDS_REDUCE 1  // fold the lanes of the per-splat sums through LDS (olsr_device.h) instead of permlane swaps
 #endif
+#ifndef OLSR_BWD_MFMA_REDUCE
+#define OLSR_BWD_MFMA_REDUCE 0  // 1: sum the ten per-splat values over the wave with MFMAs (round-4 experiment, slower: see the kernel)
+#endif
+typedef float bwd_f32x4 __attribute__((ext_vector_type(4)));
 
 // PACKED (reference mode, 15x15 tiles): the workgroup is the 128 survivors of the reference's reduction
 // tree in two full waves (ref15_rank_of_packed); the 97 other pixels of the tile are not evaluated at all —
 // nothing they compute reaches an output of the reference's backward.
+#ifndef OLSR_BWD_MIN_WAVES
+#define OLSR_BWD_MIN_WAVES 5  // waves per SIMD the packed reference-mode instantiations with F <= 16 are compiled for
+#endif
 template <int TILE, int F, int MODE, bool PACKED>
-__global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
+__global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_MIN_WAVES : 1) void render_bwd_kernel(
     const u32* __restrict__ ranges, const u32* __restrict__ inst_gid, const u32* __restrict__ src,
     const uint8_t* __restrict__ flags, const u32* __restrict__ rowbase, const int32_t* __restrict__ counters,
     const u32* __restrict__ tile_order, int W, int H, int gx, int ntiles, const float* __restrict__ bg,
@@ -114,7 +121,20 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   constexpr int NTRI = MERGED ? 0 : NG4 / 3;
   static_assert(NTRI <= 4 && NG4 + 1 <= 16 && own_lanes_clear(3 * NTRI, NG4 + (REM ? 1 : 0), NTRI),
                 "the lanes of the groups reduced on their own must stay clear of the triples' lanes");
-  __shared__ __attribute__((aligned(16))) float s_red[LDSR ? NWV * 256 : 4];  // 1 KB per wave: the exchange
+  // The ten-value sums (NV == 10) on the MATRIX pipe (round 4): the cross-lane sum of a value is a
+  // product with a constant matrix, and v_mfma_f32_16x16x4_f32 is exact fp32.  Value m goes in as the A operand (lane l holds
+  // A[i = l % 16][k = l / 16]) against the selector B_m[k][j] = (j == m): D[i][m] += sum_k v_m[16 k + i], so ten chained MFMAs
+  // leave, in the lanes of column m, the sixteen partial sums of value m (four registers x four rows of lanes).  Three adds
+  // fold the registers — for all ten values at once, every column holds another value — and an eleventh MFMA against a ones
+  // operand folds the four rows: every lane of column m then holds total m, and lanes 0..9 store row elements 0..9 as ONE
+  // contiguous 40-byte store.  VALU work of the reduction: 3 adds, against 9 adds + 7 DPP + 2 selects + 8 LDS instructions
+  // of the LDS fold.  MEASURED (config 3, profiles/r4_experiments.json): 0.188 -> 0.262 ms, the tracking iteration's F = 0
+  // backward 0.143 -> 0.249 ms; parity suite green.  The f32-input MFMA runs at the f32 VECTOR rate (64 FLOP / clk / SIMD,
+  // MI355X_MICROARCH.md) — 11 x 32 cycles per visit that behave like VALU time, not like time on an idle pipe, plus a chain
+  // of ten dependent accumulations (40 cycles each) that an in-order wave sits out.  Kept behind the macro, off.
+  // (A non-finite value would poison all ten sums of its visit (0 x inf), not only its own.)
+  constexpr bool MRED = (OLSR_BWD_MFMA_REDUCE != 0) && MERGED;
+  __shared__ __attribute__((aligned(16))) float s_red[(LDSR && !MRED) ? NWV * 256 : 4];  // 1 KB per wave: the exchange
 
   // workgroup b runs on XCD b % 8 and takes the (b / 8)-th heaviest tile of that XCD's chunk
   const int tile_id = (int)tile_order[xcd_remap((int)blockIdx.x, ntiles)];
@@ -181,7 +201,12 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
   // to the free lanes in ascending order.
   const int lg = lane & 15, lr = lane >> 4;
   int role = -1;
-  if constexpr (MERGED) {
+  float sel[MRED ? 10 : 1];  // MRED: the selectors B_m (1 in the lanes of column m)
+#pragma unroll
+  for (int m = 0; m < (MRED ? 10 : 1); ++m) sel[m] = (lg == m) ? 1.0f : 0.0f;
+  if constexpr (MRED) {
+    role = (lane < NV) ? lane : -1;  // every lane of column m ends with total m; row 0's lanes store
+  } else if constexpr (MERGED) {
     // row_sums3: (lane & 15) == 4 -> group 0, == 12 -> group 1, == 0 -> the pair (rows 1 and 3 store it)
     if (lg == 4) role = (((lr & 1) << 1) | (lr >> 1));
     if (lg == 12) role = 4 + (((lr & 1) << 1) | (lr >> 1));
@@ -404,7 +429,14 @@ __global__ __launch_bounds__(PACKED ? 128 : 256) void render_bwd_kernel(
       // Wave reduction (olsr_device.h): four values per permlane-swap tree, the 1-2 left over in a
       // two-value tree.  Total j ends up in the lanes whose role is j (role_of below); that lane stores it.
       float rowval = 0.f;
-      if constexpr (MERGED && LDSR) {
+      if constexpr (MRED) {
+        bwd_f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 10; ++m) d4 = __builtin_amdgcn_mfma_f32_16x16x4f32(sum[m], sel[m], d4, 0, 0, 0);
+        const float part = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+        const bwd_f32x4 t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, part, bwd_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        rowval = t4[0];
+      } else if constexpr (MERGED && LDSR) {
         float* wl = &s_red[w * 256];
         const float t0 = wave_fold4_lds(sum[0], sum[1], sum[2], sum[3], wl);
         const float t1 = wave_fold4_lds(sum[4], sum[5], sum[6], sum[7], wl);
