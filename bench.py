@@ -17,7 +17,13 @@ frames in flight on S HIP streams with S workspaces (frame k on stream k mod S):
 kernels of one frame overlap the compositing kernels of another, and with N > 1 the all-reduce of
 one frame overlaps the compute of the next.  The timed region still issues exactly K steps.
 
-Rank 0 prints ONE JSON line.  `isolated` repeats the measurement with ONE frame in flight: there the
+`python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run on 127.0.0.1, one per GPU over
+RCCL; fewer GPUs than ranks is an error, OLSR_BENCH_BACKEND=gloo shares devices for functional checks).  `--exchange
+{sparse,all_reduce,reduce_scatter}` picks how the shared-Gaussian gradients travel; sparse (default) exchanges only the rows
+that are non-zero on some rank, capacity-bound and without a host synchronisation.  The contract's K-step region is run
+`--repeats` (5) times back to back: `value` is the median run, `value_runs` lists all of them.
+
+Rank 0 prints ONE JSON line.  `non_coherent`: the camera changes every step.  `isolated` repeats the measurement with ONE frame in flight: there the
 intervals between the library's HIP events (recorded on the launch stream) ARE the kernel durations, whereas
 with S > 1 an interval also contains the time a kernel queues behind other frames' kernels.  `roofline`
 therefore takes the dominant kernel â€” the longest stage of the isolated leg â€” and prices it three ways:
@@ -33,7 +39,8 @@ therefore takes the dominant kernel â€” the longest stage of the isolated leg â€
 `latency_ms` holds median / p10 / p90 of the per-step completion intervals of the timed region and of the
 isolated leg's per-frame GPU time.  `bracket`: one frame in flight under the settings the headline does not use
 (exact backward, 16x16 tiles, the reference's tile lists, the one-fma accumulation).  `config4_substitute`: the
-tracking and the 12-view mapping iteration (BASELINE configs[3] itself is blocked in this image).  `cpu_baseline` is
+tracking and the 12-view mapping iteration with the loss in the forward composite's epilogue, beside the two-kernel
+formulation, with a stage breakdown (BASELINE configs[3] itself is blocked in this image).  `cpu_baseline` is
 the CPU oracle (a port â€” the reference has no CPU path) on whole frames of the same workload with the CPUs the
 container may use and, once, with one thread; the frame it times is checked against the GPU's result of the same
 view.
