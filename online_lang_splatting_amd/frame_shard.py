@@ -224,12 +224,14 @@ class GradientBucket:
 
     def sparse_all_reduce_capped(self, capacity, group=None):
         """The sparse exchange WITHOUT a host synchronisation, for callers that keep several frames in flight
-        (bench.py's weak-scaling mode): the packed buffer has a fixed `capacity` of rows instead of the exact count.
-        Step 1: all-reduce (MAX) of the per-rank byte masks of non-zero rows (P bytes) - afterwards every rank holds the
-        same union; step 2: the union's rows are packed in ascending order into [capacity, width] (unused slots point at
-        the spare zero row P), all-reduced (SUM) and scattered back; step 3: the side buffers, dense.  Everything is
-        enqueued on the current stream.  Returns a device int32[2] {rows in the union, overflow flag}: with more than
-        `capacity` rows in the union only the first `capacity` of them were exchanged - the step's gradients are then
+        (bench.py's weak-scaling mode): the packed buffer has a fixed `capacity` of rows instead of the exact count, and the
+        step is TWO collectives (each costs a launch and a latency on every rank, whatever its size):
+        1. all-reduce (MAX) of one int32 buffer [byte mask of this rank's non-zero gradient rows | max_radii] (8 P bytes) —
+           afterwards every rank holds the same union of rows, and max_radii is done;
+        2. all-reduce (SUM) of one fp32 buffer [the union's rows, packed in ascending order into capacity x width (unused
+           slots point at the spare zero row P) | the two densification statistics], scattered back afterwards.
+        Everything is enqueued on the current stream.  Returns a device int32[2] {rows in the union, overflow flag}: with more
+        than `capacity` rows in the union only the first `capacity` of them were exchanged - the step's gradients are then
         incomplete and the caller must repeat it with a larger capacity (or densely), the same contract as an instance
         overflow of olsr_forward_async.  Same values as all_reduce() otherwise."""
         import torch.distributed as dist
@@ -239,25 +241,30 @@ class GradientBucket:
         st = getattr(self, "_capped", None)
         if st is None or st["cap"] != cap:
             st = dict(cap=cap, idx=torch.empty(cap + 1, dtype=torch.int64, device=dev),
-                      packed=torch.empty(cap, width, dtype=torch.float32, device=dev),
+                      fsum=torch.empty(cap * width + 2 * P, dtype=torch.float32, device=dev),
+                      imax=torch.empty(2 * P, dtype=torch.int32, device=dev),
                       arange=torch.arange(P, dtype=torch.int64, device=dev),
                       status=torch.zeros(2, dtype=torch.int32, device=dev))
             self._capped = st
         multi = self._multi(group)
-        mask = (self.flat != 0).any(dim=1).to(torch.uint8)
+        imax, fsum = st["imax"], st["fsum"]
+        mask, packed, tail = imax[:P], fsum[: cap * width].view(cap, width), fsum[cap * width:]
+        mask.copy_((self.flat != 0).any(dim=1))
         if multi:
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)       # the union, identical on every rank
+            imax[P:].copy_(self.max_radii)
+            dist.all_reduce(imax, op=dist.ReduceOp.MAX, group=group)       # the union, identical on every rank; the radii
+            self.max_radii.copy_(imax[P:])
         pos = torch.cumsum(mask, 0, dtype=torch.int32)                     # 1-based rank of every row of the union
         slot = torch.where((mask != 0) & (pos <= cap), pos - 1, cap).to(torch.int64)
         st["idx"].fill_(P)
         st["idx"].scatter_(0, slot, st["arange"])                          # (slot `cap` collects the rows left out)
         idx = st["idx"][:cap]
-        torch.index_select(self.flat_ext, 0, idx, out=st["packed"])
+        torch.index_select(self.flat_ext, 0, idx, out=packed)
         if multi:
-            dist.all_reduce(st["packed"], op=dist.ReduceOp.SUM, group=group)
-            self.flat_ext.index_copy_(0, idx, st["packed"])                # (fill slots write zeros to the spare row)
-            dist.all_reduce(self.densify, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
+            tail.copy_(self.densify.reshape(-1))
+            dist.all_reduce(fsum, op=dist.ReduceOp.SUM, group=group)
+            self.flat_ext.index_copy_(0, idx, packed)                      # (fill slots write zeros to the spare row)
+            self.densify.copy_(tail.view(P, 2))
         st["status"][0:1] = pos[-1:]
         st["status"][1:2] = (pos[-1:] > cap).to(torch.int32)
         return st["status"]
@@ -267,8 +274,8 @@ class GradientBucket:
         this times the algorithm's factor, e.g. 2 (G-1)/G for a ring all-reduce)."""
         P, width = self.flat.shape
         side = P * 8 + P * 4
-        if exchange == "sparse":
-            return P + int(capacity) * width * 4 + side
+        if exchange == "sparse":  # (capacity-bound form: [mask | radii] as int32, then [packed rows | statistics] as fp32)
+            return 8 * P + (int(capacity) * width + 2 * P) * 4
         return self.sum_storage.numel() * 4 + P * 4
 
 
