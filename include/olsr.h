@@ -167,9 +167,11 @@ size_t olsr_binning_bytes(int64_t num_rendered, int32_t F);
  * binning).  Outputs: out_color[3,H,W], out_language[F,H,W] (ignored when F == 0),
  * out_depth[H,W], out_opacity[H,W], radii[P] (int32), n_touched[P] (int32).
  * *num_rendered receives R, the number of (Gaussian, tile) instances. */
-/* Process-wide state olsr_forward keeps (results never depend on it; tested): per (device, stream, tile count) the previous
- * frame's heaviest-first tile order (a launch-order hint, a few KB, stream-ordered allocation, at most 64 keys with
- * least-recently-used eviction, never freed otherwise); a ring of 256 mapped host slots for the gradient-row counts
+/* Process-wide state olsr_forward keeps (results never depend on it; tested): per (device, stream, tile count) the
+ * heaviest-first tile orders of up to 16 VIEWS the stream has rendered (launch-order hints: a one-wave kernel in front of the
+ * composite picks the stored view matrix nearest to this frame's, else recycles the least recently used slot — the
+ * reference's mapping loop renders its window of keyframes in turn on one stream; 16 x tiles x 4 bytes, stream-ordered
+ * allocation, at most 64 keys with least-recently-used eviction, never freed otherwise); a ring of 256 mapped host slots for the gradient-row counts
  * (olsr_live_rows); two mapped host words per calling thread for the instance count (leaked at thread exit by design: a
  * thread_local destructor could run after the HIP runtime's teardown). */
 int olsr_forward(const olsr_scene *scene,

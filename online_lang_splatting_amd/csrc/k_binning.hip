@@ -927,8 +927,10 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
                                                          u32* __restrict__ order_copy, int ntiles,
                                                          u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq,
                                                          const int32_t* __restrict__ counters,
-                                                         int32_t* __restrict__ num_rendered_dev, int32_t* sticky) {
+                                                         int32_t* __restrict__ num_rendered_dev, int32_t* sticky,
+                                                         const u32* __restrict__ hint_slot) {
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
+  if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
   // the forward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && counters[8] != 0) {
     if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
@@ -982,8 +984,10 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
                                                                   u32* __restrict__ order_copy, int ntiles,
                                                                   u32* __restrict__ live_rows, int32_t* mailbox,
                                                                   int32_t seq, const int32_t* __restrict__ counters,
-                                                                  int32_t* __restrict__ num_rendered_dev, int32_t* sticky) {
+                                                                  int32_t* __restrict__ num_rendered_dev, int32_t* sticky,
+                                                                  const u32* __restrict__ hint_slot) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
   if (i == 0 && counters[8] != 0) {
     if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
     if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -998,17 +1002,18 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
 
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
-                       int32_t* num_rendered_dev, int32_t* sticky_error, hipStream_t st) {
+                       int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, hipStream_t st) {
   if (ntiles <= 0) return;
   const int len = (ntiles >> 3) + 1;
   if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
     tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_work, tile_order, order_copy, ntiles, live_rows,
                                                                      rows_mailbox, rows_seq, counters, num_rendered_dev,
-                                                                     sticky_error);
+                                                                     sticky_error, hint_slot);
     return;
   }
   tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(
-      tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq, counters, num_rendered_dev, sticky_error);
+      tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq, counters, num_rendered_dev, sticky_error,
+      hint_slot);
 }
 
 }  // namespace olsr

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
     u32* __restrict__ tile_work, const u32* __restrict__ order_hint, const int32_t* __restrict__ counters,
-    const FusedLossArgs fl) {
+    const u32* __restrict__ hint_slot, const FusedLossArgs fl) {
   // a radix pass of this frame lost a predecessor's counts (olsr_state.h, counters[8]): the lists are garbage and must not be
   // used as indices — render nothing; the tile-order kernel behind this one reports OLSR_STATUS_SYNC_ERROR
   if (counters[8] != 0) return;
@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
   // workgroup b runs on XCD b % 8; with a hint it takes the (b / 8)-th heaviest tile of that XCD's chunk as
   // measured on the caller's previous frame, else the (b / 8)-th tile of the chunk
   int tile_id = xcd_remap((int)blockIdx.x, ntiles);
-  if (order_hint != nullptr) tile_id = (int)order_hint[tile_id];
+  // (hint_slot: the synchronising entry keeps several orders per stream, one per view it has seen; word 0 names this frame's)
+  if (order_hint != nullptr)
+    tile_id = (int)order_hint[(hint_slot != nullptr ? (size_t)hint_slot[0] * (size_t)ntiles : (size_t)0) + (size_t)tile_id];
   const int tid = threadIdx.x;
   const int w = tid >> 6;
   const int bx = tile_id % gx, by = tile_id / gx;
@@ -481,13 +483,14 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
 #define OLSR_FWD_ARGS                                                                                                  \
   im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
-      n_touched, b.flags, im.tile_work, order_inout, g.counters
+      n_touched, b.flags, im.tile_work, order_inout, g.counters, hint_slot
 
 #if OLSR_FWD_TU_LOSS == 0
 template <int TILE, int F>
 static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, hipStream_t st) {
+                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, const uint32_t* hint_slot,
+                         hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
   const FusedLossArgs none{};
   if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
@@ -501,8 +504,8 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
 template <int TILE, int F>
 static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                          const ImageState& im, float* out_color, float* out_language, float* out_depth,
-                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, const olsr_loss_fusion& lf,
-                         hipStream_t st) {
+                         float* out_opacity, int32_t* n_touched, uint32_t* order_inout, const uint32_t* hint_slot,
+                         const olsr_loss_fusion& lf, hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
   const bool lang_term = !lf.tracking && lf.params.F > 0 && lf.gt_language != nullptr;
   FusedLossArgs fl{};
@@ -534,12 +537,12 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
 #undef OLSR_FWD_ARGS
 
 #if OLSR_FWD_TU_LOSS == 0
-#define OLSR_FWD_EXTRA
-#define OLSR_FWD_EXTRA_DECL
+#define OLSR_FWD_EXTRA , hint_slot
+#define OLSR_FWD_EXTRA_DECL , const uint32_t* hint_slot
 #define OLSR_FWD_NAME launch_render_forward_images
 #else
-#define OLSR_FWD_EXTRA , lf
-#define OLSR_FWD_EXTRA_DECL , const olsr_loss_fusion& lf
+#define OLSR_FWD_EXTRA , hint_slot, lf
+#define OLSR_FWD_EXTRA_DECL , const uint32_t* hint_slot, const olsr_loss_fusion& lf
 #define OLSR_FWD_NAME launch_render_forward_loss
 #endif
 
@@ -581,21 +584,21 @@ void OLSR_FWD_NAME(const olsr_scene& s, const FrameDims& d, const GeometryState&
 void launch_render_forward_loss(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                                 const ImageState& im, float* out_color, float* out_language, float* out_depth,
                                 float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout,
-                                const olsr_loss_fusion& lf, hipStream_t st);
+                                const uint32_t* hint_slot, const olsr_loss_fusion& lf, hipStream_t st);
 
 void launch_render_forward(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                            const ImageState& im, float* out_color, float* out_language, float* out_depth,
                            float* out_opacity, int32_t* n_touched, uint32_t* tile_order_inout, int32_t* num_rendered_dev,
                            const olsr_loss_fusion* loss, hipStream_t st) {
+  const RowsMailbox& rm = rows_mailbox_of_this_call();
   if (loss != nullptr)
     launch_render_forward_loss(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
-                               *loss, st);
+                               rm.hint_slot, *loss, st);
   else
     launch_render_forward_images(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched,
-                                 tile_order_inout, st);
-  const RowsMailbox& rm = rows_mailbox_of_this_call();
+                                 tile_order_inout, rm.hint_slot, st);
   launch_tile_order(im.tile_work, im.tile_order, tile_order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, g.counters,
-                    num_rendered_dev, rm.sticky, st);
+                    num_rendered_dev, rm.sticky, rm.hint_slot, st);
 }
 #endif
 

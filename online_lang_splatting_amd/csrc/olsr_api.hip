@@ -172,6 +172,54 @@ RowsRing g_rows;
 thread_local int32_t g_last_token = 0;  // token of the last olsr_forward of this thread (0: none)
 thread_local RowsMailbox g_rows_call;
 
+// (per-view tile orders of the synchronising entry: described at order_hint_of below)
+constexpr int HINT_SLOTS = 16;
+constexpr int HINT_HDR = 4 + HINT_SLOTS + 16 * HINT_SLOTS;  // words in front of the orders
+static_assert(HINT_HDR % 4 == 0, "the orders stay 16-byte aligned");
+constexpr float HINT_VIEW_TOL = 0.03f;
+__global__ void hint_init_kernel(uint32_t* base, int ntiles) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)HINT_HDR + (size_t)HINT_SLOTS * (size_t)ntiles;
+  if (i >= total) return;
+  if (i < 4 + HINT_SLOTS) base[i] = 0u;
+  else if (i < HINT_HDR) base[i] = 0x7FC00000u;  // NaN: matches no view
+  else base[i] = (uint32_t)((i - HINT_HDR) % (size_t)ntiles);
+}
+__global__ __launch_bounds__(64) void hint_pick_kernel(uint32_t* base, const float* __restrict__ view) {
+  const int lane = threadIdx.x;
+  float d = __builtin_inff();
+  uint32_t age = 0xFFFFFFFFu;
+  if (lane < HINT_SLOTS) {
+    d = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const float sv = __uint_as_float(base[4 + HINT_SLOTS + 16 * lane + i]);
+      const float e = fabsf(view[i] - sv);
+      d = (e == e && d >= e) ? d : ((e == e) ? e : __builtin_inff());  // max; a NaN (empty slot) matches nothing
+    }
+    age = base[4 + lane];
+  }
+  // nearest slot, else the least recently used one (ties: the lower slot)
+  float dbest = d;
+  int ibest = lane;
+  uint32_t abest = age;
+  int iold = lane;
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float od = __shfl_xor(dbest, m);
+    const int oi = __shfl_xor(ibest, m);
+    if (od < dbest || (od == dbest && oi < ibest)) { dbest = od; ibest = oi; }
+    const uint32_t oa = (uint32_t)__shfl_xor((int)abest, m);
+    const int oo = __shfl_xor(iold, m);
+    if (oa < abest || (oa == abest && oo < iold)) { abest = oa; iold = oo; }
+  }
+  const int pick = (dbest <= HINT_VIEW_TOL) ? ibest : iold;
+  if (lane < 16) base[4 + HINT_SLOTS + 16 * pick + lane] = __float_as_uint(view[lane]);
+  if (lane == 0) {
+    const uint32_t c = base[1] + 1u;
+    base[0] = (uint32_t)pick;
+    base[1] = c;
+    base[4 + pick] = c;
+  }
+}
 // A synchronisation error (olsr_state.h, counters[8]) is detected on the device after the call that caused it has returned.
 // The sync-free entries report it through their status words; for the reference-shaped, synchronising API the last kernel of
 // a forward / backward also raises a flag in mapped host memory, and the FIRST library call after the GPU got there fails
@@ -190,7 +238,7 @@ const char* const STICKY_MSG =
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
                  int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st,
-                 const olsr_loss_fusion* loss = nullptr) {
+                 const olsr_loss_fusion* loss = nullptr, uint32_t* view_hints = nullptr) {
   const FrameDims d = frame_dims(s);
   const size_t N = (size_t)d.W * d.H;
   size_t gb, ib, bb;
@@ -332,6 +380,11 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     g_rows_call.seq = tok;
     g_rows_call.sticky = g_rows.dp + 4 * ROWS_RING;
   }
+  if (view_hints != nullptr && s.P > 0) {  // (the synchronising entry) this frame's slot among the stream's per-view orders
+    hint_pick_kernel<<<1, 64, 0, st>>>(view_hints, s.viewmatrix);
+    g_rows_call.hint_slot = view_hints;
+    tile_order_inout = view_hints + HINT_HDR;
+  }
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
                         num_rendered_dev, (s.P > 0) ? loss : nullptr, st);
   g_rows_call = RowsMailbox{};
@@ -351,10 +404,14 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
 // order, so the array is a complete permutation whenever a kernel reads it; no result depends on its content (a hint from
 // another view of another scene is merely a worse guess).  A few KB each, at most 64 of them (least recently used evicted),
 // allocated stream-ordered; the survivors live until the process ends.
-__global__ void iota_kernel(uint32_t* out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (uint32_t)i;
-}
+// Several orders per (device, stream, tile count), one per VIEW the stream has rendered (round 4): the reference's mapping
+// loop renders its window of keyframes one after the other on one stream (utils/slam_backend.py:510-670), so "the previous
+// frame's order" belongs to another view — and a stale order costs the forward composite 25-35 % with one frame in flight
+// (0.17 -> 0.23 ms at config 3, scripts/probe/arc_views.py).  A one-wave kernel in front of the composite compares the frame's
+// view matrix with the HINT_SLOTS stored ones and names the nearest slot (within HINT_VIEW_TOL per entry), else recycles the
+// least recently used one; the composite reads that slot's order, the tile-order kernel writes this frame's order back into
+// it.  Buffer (32-bit words): [0] chosen slot, [1] use counter, [4, 4 + S) last use of every slot, then S x 16 floats (view
+// matrices, NaN = empty), then S x ntiles orders (each a permutation at all times: iota initially).
 struct OrderHints {
   struct Entry {
     int dev;
@@ -366,6 +423,7 @@ struct OrderHints {
   std::vector<Entry> v;
 } g_order_hints;
 
+// the hint buffer of (current device, st, ntiles): header + HINT_SLOTS orders (layout above); nullptr: run without a hint
 uint32_t* order_hint_of(int ntiles, hipStream_t st) {
   int dev = 0;
   if (ntiles <= 0 || hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -387,15 +445,16 @@ uint32_t* order_hint_of(int ntiles, hipStream_t st) {
     v.erase(v.begin());
   }
   uint32_t* buf = nullptr;
+  const size_t words = (size_t)HINT_HDR + (size_t)HINT_SLOTS * (size_t)ntiles;
   // stream-ordered allocation: no device synchronisation on the hot olsr_forward path the first time a key is seen
-  if (hipMallocAsync((void**)&buf, sizeof(uint32_t) * (size_t)ntiles, st) != hipSuccess) {
+  if (hipMallocAsync((void**)&buf, sizeof(uint32_t) * words, st) != hipSuccess) {
     (void)hipGetLastError();
-    if (hipMalloc((void**)&buf, sizeof(uint32_t) * (size_t)ntiles) != hipSuccess) {
+    if (hipMalloc((void**)&buf, sizeof(uint32_t) * words) != hipSuccess) {
       (void)hipGetLastError();
       return nullptr;
     }
   }
-  iota_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(buf, ntiles);
+  hint_init_kernel<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(buf, ntiles);
   v.push_back({dev, st, ntiles, buf});
   return buf;
 }
@@ -512,7 +571,8 @@ int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* ge
   const int tile = scene->tile > 0 ? scene->tile : 15;
   const int ntiles = ((scene->width + tile - 1) / tile) * ((scene->height + tile - 1) / tile);
   return forward_impl(*scene, geom, img, bp, out_color, out_language, out_depth, out_opacity, radii, n_touched,
-                      num_rendered, nullptr, order_hint_of(ntiles, (hipStream_t)hip_stream), (hipStream_t)hip_stream);
+                      num_rendered, nullptr, nullptr, (hipStream_t)hip_stream, nullptr,
+                      order_hint_of(ntiles, (hipStream_t)hip_stream));
 }
 
 int olsr_forward_async(const olsr_scene* scene, void* geometry_buffer, void* binning_buffer, int64_t capacity,

@@ -52,11 +52,12 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
 // synchronisation); live_rows: ImageState::live_rows, zero on entry, the staging of those sums
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
-                       int32_t* num_rendered_dev, int32_t* sticky_error, hipStream_t st);
+                       int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, hipStream_t st);
 struct RowsMailbox {  // set by olsr_forward for the duration of one call (thread-local in olsr_api.hip)
   int32_t* dev = nullptr;
   int32_t seq = 0;
   int32_t* sticky = nullptr;  // device view of the process-wide "a frame had a synchronisation error" host word (may be null)
+  const uint32_t* hint_slot = nullptr;  // word 0 = which of the stream's per-view tile orders this frame uses (olsr_api.hip)
 };
 RowsMailbox& rows_mailbox_of_this_call();
 // ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)

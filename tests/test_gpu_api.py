@@ -902,3 +902,43 @@ def test_lost_digit_counts_in_a_radix_pass_are_reported(hip, which, bit):
     ws.forward()
     ws.backward(*cot)
     assert ws.rendered()[1] is False and ws.backward_status()[1] is False
+
+
+def test_per_view_tile_orders_of_the_dropin_entry_never_change_a_result(hip):
+    """olsr_forward keeps, per stream, one launch-order hint per VIEW it has seen (16 slots, nearest view matrix, least
+    recently used recycled).  Twenty views in turn — more than there are slots — then the first ones again: every call's
+    images, radii and n_touched equal what a fresh workspace renders for that view without any hint."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    from online_lang_splatting_amd.scene import arc_cameras
+    dev = torch.device(DEV)
+    W, H, F = 200, 150, 15
+    sc = make_scene(8000, W, H, F, seed=77)
+    cams = arc_cameras(W, H, n=20)
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    ws = RasterWorkspace(sc.P, W, H, F, sc.shs.shape[1], 600000, dev)
+    ws.tile_order = None  # (no hint at all on the reference side of the comparison)
+    ref = []
+    for c in cams:
+        cd = dict(viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev),
+                  projmatrix_raw=c.projection_matrix.to(dev), campos=c.camera_center.to(dev), tanfovx=c.tanfovx,
+                  tanfovy=c.tanfovy)
+        ws.set_scene(sh_degree=sc.sh_degree, **cd, **g)
+        check_ = __import__("online_lang_splatting_amd._lib", fromlist=["check"]).check
+        lib_ = __import__("online_lang_splatting_amd._lib", fromlist=["lib"]).lib()
+        import ctypes as C
+        o = ws.out
+        check_(lib_.olsr_forward_async(C.byref(ws._scene), ws.geom.data_ptr(), ws.binning.data_ptr(), ws.capacity,
+                                       ws.img.data_ptr(), o["color"].data_ptr(), o["language"].data_ptr(),
+                                       o["depth"].data_ptr(), o["opacity"].data_ptr(), o["radii"].data_ptr(),
+                                       o["n_touched"].data_ptr(), ws.num_rendered.data_ptr(), None, ws._stream()))
+        ref.append({k: v.clone() for k, v in o.items()})
+    order = list(range(20)) + [0, 1, 2, 19, 0, 10, 0]
+    for v in order:
+        c = cams[v]
+        sc.camera = c
+        a = fwd_args(sc, dev)
+        r = hip.rasterize_language_gaussians(*a)
+        assert torch.equal(r[1], ref[v]["color"]) and torch.equal(r[2], ref[v]["language"]), v
+        assert torch.equal(r[3], ref[v]["radii"]) and torch.equal(r[7].reshape(-1), ref[v]["depth"].reshape(-1)), v
+        assert torch.equal(r[9], ref[v]["n_touched"]), v

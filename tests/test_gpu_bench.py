@@ -75,6 +75,7 @@ def test_config3_line_carries_the_config4_substitute():
     runs = d["value_runs"]   # the K-step region repeated; the value is the median run
     assert len(runs["fps"]) == 5 and runs["min"] <= runs["median"] <= runs["max"] and abs(runs["median"] - d["value"]) < 0.01
     assert "untimed set-up frames" in d["config"]["workload"]
+    assert d["dropin"]["alternating_4_views"]["value"] > 0.8 * d["dropin"]["value"]   # per-view orders inside the library
     nc = d["non_coherent"]   # the camera changes every step: no reusable tile-order hint
     assert 0 < nc["value"] and 0 < nc["isolated_value"] and not nc["overflow"]
     valu = d["roofline"].get("valu")
