@@ -27,8 +27,10 @@ UNITS = [
     ("k_sort.hip", "k_sort.o", []),
     ("k_render_fwd.hip", "k_render_fwd.o", ["-DOLSR_FWD_TU_LOSS=0"]),
     ("k_render_fwd.hip", "k_render_fwd_loss.o", ["-DOLSR_FWD_TU_LOSS=1"]),
-    ("k_render_bwd.hip", "k_render_bwd_ref.o", ["-DOLSR_BWD_TU_MODE=0"]),
-    ("k_render_bwd.hip", "k_render_bwd_exact.o", ["-DOLSR_BWD_TU_MODE=1"]),
+    # (-fno-slp-vectorize: the backward's value path is written on scalar fp32 — packed fp32 is half rate on gfx950 and the
+    #  moves that pair its operands up cost 2 % of the kernel — and the compiler must not pack it again)
+    ("k_render_bwd.hip", "k_render_bwd_ref.o", ["-DOLSR_BWD_TU_MODE=0", "-fno-slp-vectorize"]),
+    ("k_render_bwd.hip", "k_render_bwd_exact.o", ["-DOLSR_BWD_TU_MODE=1", "-fno-slp-vectorize"]),
     ("k_preprocess_bwd.hip", "k_preprocess_bwd.o", []),
     ("k_accumulate.hip", "k_accumulate.o", []),
     ("k_loss.hip", "k_loss.o", []),

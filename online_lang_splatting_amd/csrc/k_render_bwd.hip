@@ -33,6 +33,8 @@
 //   - the language recursion (accum_rec_F, last_language_feature) runs for every pixel of the
 //     tile whenever the tile as a whole does not skip the splat.
 // MODE = OLSR_BWD_EXACT sums all pixels and guards the language recursion like colour.
+#include <type_traits>
+
 #include "olsr_device.h"
 #include "olsr_kernels.h"
 
@@ -69,6 +71,29 @@ constexpr int BWD_BATCH = 128;
 #define OLSR_BWD_MFMA_REDUCE 0  // 1: sum the ten per-splat values over the wave with MFMAs (round-4 experiment, slower: see the kernel)
 #endif
 typedef float bwd_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef OLSR_BWD_SCALAR_VALUE
+#define OLSR_BWD_SCALAR_VALUE 1  // the value path on scalar fp32 (build with -fno-slp-vectorize); 0: packed pairs (rounds 1-3)
+#endif
+// packed fp32 is half rate on gfx950: two lanes' work in twice the time, plus the moves that pair the operands up
+struct bv2s {
+  float x, y;
+};
+__device__ __forceinline__ bv2s operator+(bv2s a, bv2s b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ bv2s operator-(bv2s a, bv2s b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ bv2s operator*(bv2s a, bv2s b) { return {a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ bv2s operator*(bv2s a, float b) { return {a.x * b, a.y * b}; }
+__device__ __forceinline__ bv2s operator-(bv2s a) { return {-a.x, -a.y}; }
+__device__ __forceinline__ bv2s& operator+=(bv2s& a, bv2s b) {
+  a.x += b.x;
+  a.y += b.y;
+  return a;
+}
+// F <= 16: scalar (config 3: 0.1907 -> 0.1864 ms, exact mode 1 108 -> 1 123 fps, tracking iteration 0.548 -> 0.538 ms);
+// F = 32 keeps the packed pairs (scalar measured slower there: 0.547 -> 0.563 ms at config 5, three waves per SIMD)
+template <int F>
+struct bwd_pair {
+  typedef typename std::conditional<(OLSR_BWD_SCALAR_VALUE != 0) && (F <= 16), bv2s, v2f>::type type;
+};
 
 // PACKED (reference mode, 15x15 tiles): the workgroup is the 128 survivors of the reference's reduction
 // tree in two full waves (ref15_rank_of_packed); the 97 other pixels of the tile are not evaluated at all —
@@ -85,6 +110,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
     const float* __restrict__ lang, const float* __restrict__ depths, const float* __restrict__ final_Ts,
     const u32* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_lang,
     const float* __restrict__ dL_dpixels_depth, float* __restrict__ rows) {
+  typedef typename bwd_pair<F>::type bv2;
   constexpr int BS = TILE * TILE;
   constexpr int FR = feat_row(F);
   constexpr int ROW = grad_row(F);
@@ -173,7 +199,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
   // (CR/backward.cu:1110-1123).  The same quantity in running form: Z = colour composited from everything behind,
   // used as accum_rec and then advanced, Z <- Z + alpha * (c - Z).  Algebraically identical, 4 state registers
   // instead of 8, one operation less per channel (value path: no decision depends on it).
-  v2f Z01 = {0.f, 0.f}, Z23 = {0.f, 0.f};  // {r, g} and {b, depth} composited from everything behind
+  bv2 Z01 = {0.f, 0.f}, Z23 = {0.f, 0.f};  // {r, g} and {b, depth} composited from everything behind
   float dLc[3];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) dLc[ch] = inside ? dL_dpixels[ch * HW + pix] : 0.f;
@@ -182,12 +208,12 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
   bg_dot += bg1 * dLc[1];
   bg_dot += bg2 * dLc[2];
   const float dLd = (inside && dL_dpixels_depth != nullptr) ? dL_dpixels_depth[pix] : 0.f;  // (NULL: no depth term in the loss)
-  const v2f dL01 = {dLc[0], dLc[1]}, dL23 = {dLc[2], dLd};  // the pixel's cotangents, in the same pairs
+  const bv2 dL01 = {dLc[0], dLc[1]}, dL23 = {dLc[2], dLd};  // the pixel's cotangents, in the same pairs
   float A_f = 0.f, D_last = 0.f, dLf[FX];
   bool seen_mine = false;  // wave-uniform: an entry of this wave's own has been visited
 #pragma unroll
   for (int ch = 0; ch < FX; ++ch) dLf[ch] = (F > 0 && inside) ? dL_dpixels_lang[ch * HW + pix] : 0.f;
-  v2f dLf2[F2X];  // the same cotangents in pairs, for packed fp32 math
+  bv2 dLf2[F2X];  // the same cotangents in pairs, for packed fp32 math
 #pragma unroll
   for (int k2 = 0; k2 < F2X; ++k2) {
     dLf2[k2].x = (2 * k2 < F) ? dLf[(2 * k2 < F) ? 2 * k2 : 0] : 0.f;
@@ -317,8 +343,8 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
       float D_cur = 0.f;
       if constexpr (F > 0) {
 #pragma clang fp contract(fast)
-        const v2f* fr2 = reinterpret_cast<const v2f*>(fr + 4);
-        v2f acc2 = {0.f, 0.f};
+        const bv2* fr2 = reinterpret_cast<const bv2*>(fr + 4);
+        bv2 acc2 = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < F2; ++k) acc2 += fr2[k] * dLf2[k];
         D_cur = acc2.x + acc2.y;
@@ -371,10 +397,10 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
         const float inv_eff = skip ? 1.f : inv;
         T = T * inv_eff;
         const float4 f4 = *reinterpret_cast<const float4*>(fr);  // r g b depth of the splat (wave-uniform LDS read)
-        const v2f d01 = v2f{f4.x, f4.y} - Z01, d23 = v2f{f4.z, f4.w} - Z23;
-        const v2f dd = d01 * dL01 + d23 * dL23;
+        const bv2 d01 = bv2{f4.x, f4.y} - Z01, d23 = bv2{f4.z, f4.w} - Z23;
+        const bv2 dd = d01 * dL01 + d23 * dL23;
         float dL_dalpha = dd.x + dd.y;
-        const v2f a2 = {alpha_eff, alpha_eff};
+        const bv2 a2 = {alpha_eff, alpha_eff};
         Z01 = Z01 + a2 * d01;
         Z23 = Z23 + a2 * d23;
         if constexpr (F > 0) {
@@ -397,13 +423,13 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
         const float s_dLa = surv ? f_dLa : 0.f;
         const float s_dcd = surv ? f_dcd : 0.f;
         const float dL_dG = co.w * s_dLa;
-        const v2f dxy = {dx, dy};
-        const v2f gd = dxy * v2f{Gm, Gm};                                        // {gdx, gdy}
-        const v2f dGd = -(gd * v2f{co.x, co.z}) - v2f{gd.y, gd.x} * v2f{co.y, co.y};  // {dG_ddelx, dG_ddely}
-        const v2f s01 = (dGd * v2f{dL_dG, dL_dG}) * v2f{ddelx_dx, ddely_dy};
+        const bv2 dxy = {dx, dy};
+        const bv2 gd = dxy * bv2{Gm, Gm};                                        // {gdx, gdy}
+        const bv2 dGd = -(gd * bv2{co.x, co.z}) - bv2{gd.y, gd.x} * bv2{co.y, co.y};  // {dG_ddelx, dG_ddely}
+        const bv2 s01 = (dGd * bv2{dL_dG, dL_dG}) * bv2{ddelx_dx, ddely_dy};
         const float h = -0.5f * dL_dG;
-        const v2f s23 = dxy * v2f{gd.x * h, gd.x * h};                           // -0.5 gdx {dx, dy} dL_dG
-        const v2f s67 = dL01 * v2f{s_dcd, s_dcd}, s89 = dL23 * v2f{s_dcd, s_dcd};
+        const bv2 s23 = dxy * bv2{gd.x * h, gd.x * h};                           // -0.5 gdx {dx, dy} dL_dG
+        const bv2 s67 = dL01 * bv2{s_dcd, s_dcd}, s89 = dL23 * bv2{s_dcd, s_dcd};
         sum[0] = s01.x;
         sum[1] = s01.y;
         sum[2] = s23.x;
@@ -417,7 +443,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
         if constexpr (!REF && F > 0) {
 #pragma unroll
           for (int k2 = 0; k2 < F2; ++k2) {
-            const v2f pr = dLf2[k2] * s_dcd;
+            const bv2 pr = dLf2[k2] * s_dcd;
             sum[10 + 2 * k2] = pr.x;
             if (10 + 2 * k2 + 1 < NVP) sum[10 + 2 * k2 + 1] = pr.y;
           }
