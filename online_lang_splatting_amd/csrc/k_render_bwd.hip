@@ -78,6 +78,9 @@ typedef float bwd_f32x4 __attribute__((ext_vector_type(4)));
 struct bv2s {
   float x, y;
 };
+// (value path only: its products and sums may contract to FMAs like the packed form's did — the flag travels with the
+//  operations when they are inlined; the decision path never touches this type)
+#pragma clang fp contract(fast)
 __device__ __forceinline__ bv2s operator+(bv2s a, bv2s b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ bv2s operator-(bv2s a, bv2s b) { return {a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ bv2s operator*(bv2s a, bv2s b) { return {a.x * b.x, a.y * b.y}; }
@@ -88,6 +91,7 @@ __device__ __forceinline__ bv2s& operator+=(bv2s& a, bv2s b) {
   a.y += b.y;
   return a;
 }
+#pragma clang fp contract(off)
 // F <= 16: scalar (config 3: 0.1907 -> 0.1864 ms, exact mode 1 108 -> 1 123 fps, tracking iteration 0.548 -> 0.538 ms);
 // F = 32 keeps the packed pairs (scalar measured slower there: 0.547 -> 0.563 ms at config 5, three waves per SIMD)
 template <int F>

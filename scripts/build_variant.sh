@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; src=$2; objdir=$3; shift 3
 C=online_lang_splatting_amd/csrc
 mkdir -p /tmp/olsr_variant_$name
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function "$@" -c $C/$src -o /tmp/olsr_variant_$name/v.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function "$@" -c $C/$src -o /tmp/olsr_variant_$name/v.o
 objs=""
 for d in $C/_obj/*/; do
   b=$(basename $d)
