@@ -71,6 +71,9 @@ constexpr int BWD_BATCH = 128;
 #define OLSR_BWD_MFMA_REDUCE 0  // 1: sum the ten per-splat values over the wave with MFMAs (round-4 experiment, slower: see the kernel)
 #endif
 typedef float bwd_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef OLSR_BWD_SCALAR_MAX_F
+#define OLSR_BWD_SCALAR_MAX_F 32
+#endif
 #ifndef OLSR_BWD_SCALAR_VALUE
 #define OLSR_BWD_SCALAR_VALUE 1  // the value path on scalar fp32 (build with -fno-slp-vectorize); 0: packed pairs (rounds 1-3)
 #endif
@@ -92,11 +95,11 @@ __device__ __forceinline__ bv2s& operator+=(bv2s& a, bv2s b) {
   return a;
 }
 #pragma clang fp contract(off)
-// F <= 16: scalar (config 3: 0.1907 -> 0.1864 ms, exact mode 1 108 -> 1 123 fps, tracking iteration 0.548 -> 0.538 ms);
-// F = 32 keeps the packed pairs (scalar measured slower there: 0.547 -> 0.563 ms at config 5, three waves per SIMD)
+// scalar for every F (config 3: 0.1907 -> 0.1763 ms, exact mode 1 108 -> 1 155 fps, tracking iteration 0.548 -> 0.538 ms;
+// config 5, F = 32: 0.525 -> 0.506 ms).  OLSR_BWD_SCALAR_VALUE=0 / OLSR_BWD_SCALAR_MAX_F restore the packed pairs.
 template <int F>
 struct bwd_pair {
-  typedef typename std::conditional<(OLSR_BWD_SCALAR_VALUE != 0) && (F <= 16), bv2s, v2f>::type type;
+  typedef typename std::conditional<(OLSR_BWD_SCALAR_VALUE != 0) && (F <= OLSR_BWD_SCALAR_MAX_F), bv2s, v2f>::type type;
 };
 
 // PACKED (reference mode, 15x15 tiles): the workgroup is the 128 survivors of the reference's reduction
