@@ -214,6 +214,9 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
   bg_dot += bg0 * dLc[0];
   bg_dot += bg1 * dLc[1];
   bg_dot += bg2 * dLc[2];
+  // the background's share of dL_dalpha, (-T_final / (1 - alpha)) <bg, dL_dpixel> (CR/backward.cu:1119-1125), as ONE fma per visit
+  // against the visit's 1 / (1 - alpha): a per-pixel constant, zero without a background
+  const float bg_term = has_bg ? -T_final * bg_dot : 0.f;
   const float dLd = (inside && dL_dpixels_depth != nullptr) ? dL_dpixels_depth[pix] : 0.f;  // (NULL: no depth term in the loss)
   const bv2 dL01 = {dLc[0], dLc[1]}, dL23 = {dLc[2], dLd};  // the pixel's cotangents, in the same pairs
   float A_f = 0.f, D_last = 0.f, dLf[FX];
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
           }
         }
         dL_dalpha *= T;
-        if (has_bg) dL_dalpha += (-T_final * inv) * bg_dot;
+        dL_dalpha += bg_term * inv;  // (-T_final / (1 - alpha)) <bg, dL_dpixel>, CR/backward.cu:1119-1125; one fma, 0 without a background
         last_alpha = skip ? last_alpha : alpha;
         f_dcd = alpha_eff * T;
         f_dLa = skip ? 0.f : dL_dalpha;
