@@ -305,6 +305,14 @@ int olsr_adam_step(int32_t P, int32_t M, int32_t F, const olsr_adam_params *para
                    float *means3D, float *shs, float *opacities, float *scales, float *rotations,
                    float *language, float *exp_avg, float *exp_avg_sq, void *hip_stream);
 
+/* The same step fed by SEVERAL buckets (1 <= n_flats <= 8, `flats` a host array of device pointers): the gradient of a row
+ * is ((flats[0] + flats[1]) + flats[2]) + ... — exactly what adding the buckets into flats[0] first would leave, without
+ * the read-modify-write passes over P x width floats (a caller that renders a step's views on several HIP streams keeps one
+ * bucket per stream: frame_shard.FrameLanes). */
+int olsr_adam_step_sum(int32_t P, int32_t M, int32_t F, const olsr_adam_params *params, int32_t n_flats,
+                       const float *const *flats, float *means3D, float *shs, float *opacities, float *scales,
+                       float *rotations, float *language, float *exp_avg, float *exp_avg_sq, void *hip_stream);
+
 /* ---- the reference's other native dependency ----------------------------
  * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest neighbours (FLT_MAX counts
  * for a missing neighbour when P < 4).  Replaces simple_knn._C.distCUDA2 -> SimpleKNN::knn

@@ -27,7 +27,15 @@ struct AdamScalars {
       neg_step_language;  // -(lr / bias_correction1)
 };
 
+// up to OLSR_ADAM_MAX_BUCKETS gradient buckets summed on the fly, in order: ((f0 + f1) + f2) + ... — what a sum of the lane
+// buckets (frame_shard.FrameLanes) leaves, bit for bit, without writing it anywhere
+struct AdamBuckets {
+  const float* more[OLSR_ADAM_MAX_BUCKETS - 1];
+  int n_more;
+};
+
 __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int width, const float* __restrict__ flat,
+                                                        AdamBuckets extra,
                                                         float* __restrict__ means3D, float* __restrict__ shs,
                                                         float* __restrict__ opacities, float* __restrict__ scales,
                                                         float* __restrict__ rotations, float* __restrict__ language,
@@ -51,7 +59,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int
     else if (c < 7 + sh_w) { p = scales + 3 * g + (c - 4 - sh_w); neg_step = hp.neg_step_scale; }
     else if (c < 11 + sh_w) { p = rotations + 4 * g + (c - 7 - sh_w); neg_step = hp.neg_step_rotation; }
     else { p = language + g * F + (c - 11 - sh_w); neg_step = hp.neg_step_language; }
-    const float grad = flat[base + e];
+    float grad = flat[base + e];
+    for (int b = 0; b < extra.n_more; ++b) grad += extra.more[b][base + e];
     float m = exp_avg[base + e], v = exp_avg_sq[base + e];
     m = m + (grad - m) * hp.one_minus_beta1;              // exp_avg.lerp_(grad, 1 - beta1)
     v = v * hp.beta2 + hp.one_minus_beta2 * grad * grad;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
@@ -62,10 +71,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int
   }
 }
 
-void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* flat, float* means3D, float* shs,
-                      float* opacities, float* scales, float* rotations, float* language, float* exp_avg,
-                      float* exp_avg_sq, hipStream_t st) {
+void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* const* flats, int n_flats,
+                      float* means3D, float* shs, float* opacities, float* scales, float* rotations, float* language,
+                      float* exp_avg, float* exp_avg_sq, hipStream_t st) {
   if (P <= 0) return;
+  const float* flat = flats[0];
+  AdamBuckets extra{};
+  extra.n_more = n_flats - 1;
+  for (int b = 1; b < n_flats; ++b) extra.more[b - 1] = flats[b];
   const int width = 11 + 3 * M + F;
   // torch/optim/adam.py, _single_tensor_adam: Python-float (double) arithmetic for every scalar
   const double bc1 = 1.0 - pow(hp.beta1, (double)hp.step);
@@ -83,7 +96,7 @@ void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const flo
   k.neg_step_scale = (float)(-(hp.lr_scale / bc1));
   k.neg_step_rotation = (float)(-(hp.lr_rotation / bc1));
   k.neg_step_language = (float)(-(hp.lr_language / bc1));
-  adam_step_kernel<<<(P + ADAM_G - 1) / ADAM_G, 256, 0, st>>>(P, M, F, width, flat, means3D, shs, opacities, scales,
+  adam_step_kernel<<<(P + ADAM_G - 1) / ADAM_G, 256, 0, st>>>(P, M, F, width, flat, extra, means3D, shs, opacities, scales,
                                                              rotations, language, exp_avg, exp_avg_sq, k);
 }
 

@@ -738,10 +738,31 @@ int olsr_adam_step(int32_t P, int32_t M, int32_t F, const olsr_adam_params* para
   if (!flat || !means3D || !opacities || !scales || !rotations || !exp_avg || !exp_avg_sq || (M > 0 && !shs) ||
       (F > 0 && !language))
     return fail(OLSR_ERR_ARG, "the bucket, every parameter array and both moment buffers are required");
-  launch_adam_step(P, M, F, *params, flat, means3D, shs, opacities, scales, rotations, language, exp_avg, exp_avg_sq,
+  const float* one[1] = {flat};
+  launch_adam_step(P, M, F, *params, one, 1, means3D, shs, opacities, scales, rotations, language, exp_avg, exp_avg_sq,
                    (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("adam_step launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
+int olsr_adam_step_sum(int32_t P, int32_t M, int32_t F, const olsr_adam_params* params, int32_t n_flats,
+                       const float* const* flats, float* means3D, float* shs, float* opacities, float* scales,
+                       float* rotations, float* language, float* exp_avg, float* exp_avg_sq, void* hip_stream) {
+  if (P < 0 || M < 0 || !supported_F(F)) return fail(OLSR_ERR_ARG, "P, M must be >= 0 and F one of 0, 3, 15, 16, 32");
+  if (!params || params->step < 1) return fail(OLSR_ERR_ARG, "adam params are required and step must be >= 1");
+  if (n_flats < 1 || n_flats > OLSR_ADAM_MAX_BUCKETS || !flats)
+    return fail(OLSR_ERR_ARG, "adam_step_sum: between 1 and 8 gradient buckets");
+  for (int b = 0; b < n_flats; ++b)
+    if (!flats[b]) return fail(OLSR_ERR_ARG, "adam_step_sum: a gradient bucket is NULL");
+  if (P == 0) return OLSR_OK;
+  if (!means3D || !opacities || !scales || !rotations || !exp_avg || !exp_avg_sq || (M > 0 && !shs) ||
+      (F > 0 && !language))
+    return fail(OLSR_ERR_ARG, "every parameter array and both moment buffers are required");
+  launch_adam_step(P, M, F, *params, flats, n_flats, means3D, shs, opacities, scales, rotations, language, exp_avg,
+                   exp_avg_sq, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("adam_step_sum launch: ") + hipGetErrorString(e));
   return OLSR_OK;
 }
 

@@ -137,9 +137,10 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
                        hipStream_t st);
 
 // k_adam.hip
-void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* flat, float* means3D, float* shs,
-                      float* opacities, float* scales, float* rotations, float* language, float* exp_avg,
-                      float* exp_avg_sq, hipStream_t st);
+constexpr int OLSR_ADAM_MAX_BUCKETS = 8;
+void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* const* flats, int n_flats,
+                      float* means3D, float* shs, float* opacities, float* scales, float* rotations, float* language,
+                      float* exp_avg, float* exp_avg_sq, hipStream_t st);
 
 // k_pose.hip
 void launch_pose_step(const olsr_pose_params& p, const float* dL_dtau_sum, const float* dL_dexposure, const float* proj,

@@ -290,7 +290,7 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
         self.step_count = 0
 
-    def step(self, bucket: GradientBucket, params: Dict[str, torch.Tensor], lrs: Dict[str, float], rows=None):
+    def step(self, bucket, params: Dict[str, torch.Tensor], lrs: Dict[str, float], rows=None):
         """params: means3D [P,3], shs [P,M,3], opacities [P(,1)], scales [P,3], rotations [P,4], language [P,F]
         (contiguous fp32 on the GPU, updated in place); lrs: xyz, sh_dc, sh_rest, opacity, scale, rotation, language.
         rows = (r0, r1): update only that contiguous range of Gaussians (the rows a rank owns after a
@@ -302,6 +302,10 @@ class FusedAdam:
         for k, t in params.items():
             if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
                 raise RuntimeError(f"FusedAdam: {k} must be a contiguous fp32 tensor on the GPU")
+        # `bucket` may be a LIST of buckets (the lane buckets of a FrameLanes): their rows are summed on the fly, in list
+        # order — the bits a sum into the first one would give, without its passes over the buckets (olsr_adam_step_sum)
+        buckets = list(bucket) if isinstance(bucket, (list, tuple)) else [bucket]
+        bucket = buckets[0]
         P = bucket.flat.shape[0]
         r0, r1 = (0, P) if rows is None else rows
         if r1 <= r0:
@@ -312,10 +316,18 @@ class FusedAdam:
         def p(name):
             t = params.get(name)
             return t.data_ptr() + 4 * r0 * per_row[name] if t is not None and t.numel() > 0 else None
+        stream = C.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)
+        if len(buckets) > 1:
+            flats = (C.c_void_p * len(buckets))(*[b.flat.data_ptr() + 4 * r0 * W for b in buckets])
+            check(lib().olsr_adam_step_sum(r1 - r0, M, F, C.byref(hp), len(buckets), flats, p("means3D"), p("shs"),
+                                           p("opacities"), p("scales"), p("rotations"), p("language"),
+                                           self.exp_avg.data_ptr() + 4 * r0 * W, self.exp_avg_sq.data_ptr() + 4 * r0 * W,
+                                           stream))
+            return
         check(lib().olsr_adam_step(r1 - r0, M, F, C.byref(hp), bucket.flat.data_ptr() + 4 * r0 * W, p("means3D"),
                                    p("shs"), p("opacities"), p("scales"), p("rotations"), p("language"),
                                    self.exp_avg.data_ptr() + 4 * r0 * W, self.exp_avg_sq.data_ptr() + 4 * r0 * W,
-                                   C.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)))
+                                   stream))
 
 
 def _raise_on_sync_error(status, where):

@@ -223,17 +223,24 @@ class MappingStep:
         for _, _, st in lanes.lanes:
             main.wait_stream(st)
         total = used[0]
+        from .frame_shard import GradientBucket
+        multi = GradientBucket._multi()
         mark("lane_sum:begin", main)
         for b in used[1:]:
-            total.sum_storage.add_(b.sum_storage)
+            if multi:   # an exchange follows: it needs the total in one place
+                total.sum_storage.add_(b.sum_storage)
+            else:       # one process: only the small densification statistics are summed, Adam adds the gradient rows itself
+                total.densify.add_(b.densify)
             torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
         mark("lane_sum:end", main)
         total.all_reduce()
         mark("adam:begin", main)
-        self.adam.step(total, self.params, self.lrs)
+        self.adam.step(total if multi else used, self.params, self.lrs)
         mark("adam:end", main)
         for _, _, st in lanes.lanes:
             st.wait_stream(main)
+        # (single process: total.flat holds lane 0's rows only — the sum over the lanes exists inside the Adam kernel;
+        #  total.densify / total.max_radii are the step's totals)
         if self.profile:
             torch.cuda.synchronize(dev)
             self.stage_ms = []

@@ -942,3 +942,38 @@ def test_per_view_tile_orders_of_the_dropin_entry_never_change_a_result(hip):
         assert torch.equal(r[1], ref[v]["color"]) and torch.equal(r[2], ref[v]["language"]), v
         assert torch.equal(r[3], ref[v]["radii"]) and torch.equal(r[7].reshape(-1), ref[v]["depth"].reshape(-1)), v
         assert torch.equal(r[9], ref[v]["n_touched"]), v
+
+
+def test_adam_step_over_several_buckets_equals_the_summed_bucket(hip):
+    """olsr_adam_step_sum: the lane buckets of a step summed inside the Adam kernel, in list order — parameters and moments
+    bit-identical to adding the buckets into the first one and stepping on it (what MappingStep used to do)."""
+    from online_lang_splatting_amd.frame_shard import FusedAdam, GradientBucket, GradLayout
+    dev = torch.device(DEV)
+    P, M, F = 5003, 1, 15
+    lay = GradLayout(M, F)
+    gen = torch.Generator().manual_seed(5)
+    buckets = [GradientBucket(P, lay, dev) for _ in range(4)]
+    for i, b in enumerate(buckets):
+        x = torch.randn(P, lay.width, generator=gen)
+        x[torch.rand(P, generator=gen) < 0.9] = 0.0   # mostly empty rows, as in a real step
+        b.flat.copy_(x.to(dev))
+    lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
+
+    def params():
+        g = torch.Generator().manual_seed(9)
+        return dict(means3D=torch.randn(P, 3, generator=g).to(dev), shs=torch.randn(P, M, 3, generator=g).to(dev),
+                    opacities=torch.randn(P, 1, generator=g).to(dev), scales=torch.randn(P, 3, generator=g).to(dev),
+                    rotations=torch.randn(P, 4, generator=g).to(dev), language=torch.randn(P, F, generator=g).to(dev))
+    pa, pb = params(), params()
+    a, b = FusedAdam(P, lay, dev), FusedAdam(P, lay, dev)
+    total = GradientBucket(P, lay, dev)
+    for step in range(3):
+        total.flat.copy_(buckets[0].flat)
+        for k in buckets[1:]:
+            total.flat.add_(k.flat)
+        a.step(total, pa, lrs)
+        b.step(buckets, pb, lrs)
+    torch.cuda.synchronize()
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
