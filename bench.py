@@ -440,6 +440,43 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
         loop.iteration()
     torch.cuda.synchronize(dev)
     trk["no_language_cotangent_two_kernel_loss"] = round(1e3 * (time.perf_counter() - t0) / tracking_iters, 4)
+    # Per-tile depth cut-offs (include/olsr.h, RasterWorkspace(depth_cut=True)): every iteration bins only what the
+    # previous one needed; an iteration whose cut-offs hid something is a device-side no-op and is counted as lost.
+    # Reported beside the plain loop, never as the headline: same poses (tests/test_gpu_depth_cut.py), shorter lists.
+    ws_cut = RasterWorkspace(P, W, H, F, M, int(1.4 * R0) + (1 << 16), dev, depth_cut=True)
+    pose_c = PoseState(T_gt, proj, cam.tanfovx, cam.tanfovy, device_step_count=True)
+    pose_c.reset(T0)
+    loop = TrackingLoop(ws_cut, g_dev, sc.sh_degree, pose_c, gt_image, gt_depth, language_cotangent="null")
+    for _ in range(5):
+        loop.iteration()
+    torch.cuda.synchronize(dev)
+    steps0 = loop.steps_done()
+    t0 = time.perf_counter()
+    for _ in range(tracking_iters):
+        loop.iteration()
+    torch.cuda.synchronize(dev)
+    el_cut = time.perf_counter() - t0
+    counted = loop.steps_done() - steps0
+    _lib.set_profiling(True)
+    for _ in range(10):
+        loop.iteration()
+    per = {}
+    for name, ms in _lib.stage_times():
+        per.setdefault(name, []).append(ms)
+    _lib.set_profiling(False)
+    stage_cut = {k: round(sum(v) / len(v), 4) for k, v in per.items()}
+    trk["depth_cut_offs"] = round(1e3 * el_cut / tracking_iters, 4)
+    out["tracking_depth_cut"] = {
+        "ms_per_iteration": trk["depth_cut_offs"], "iterations": tracking_iters, "iterations_that_counted": counted,
+        "ms_per_counted_iteration": round(1e3 * el_cut / max(counted, 1), 4),
+        "instances_last_frame": ws_cut.rendered()[0], "instances_without_cut": ws.rendered()[0],
+        "tiles_with_a_cut": int(torch.isfinite(ws_cut.depth_cut).sum()), "tiles": ws_cut.depth_cut.numel(),
+        "library_stage_ms": stage_cut, "library_ms": round(sum(stage_cut.values()), 4),
+        "pose_error_after": round(float((pose_c.T_w2c - T_gt).abs().max()), 6),
+        "what": "the no_language_cotangent loop on a workspace with per-tile depth cut-offs: emission, tile sort and row "
+                "compaction see only the instances in front of the depth at which each tile saturated one iteration earlier "
+                "(x1.1 + 0.01); exact or flagged, a flagged iteration takes no pose step"}
+    del ws_cut
     out["tracking_iteration_ms"] = trk["no_language_cotangent"]
     out["tracking"] = {"ms_per_iteration": trk, "iterations": tracking_iters,
                        "what": "render (language rasterizer, as gaussian_renderer.render does for a language map) with the "

@@ -151,7 +151,27 @@ typedef struct olsr_scene {
   int32_t activations; /* OLSR_ACT_* bit mask: which parameter arrays are RAW (pre-activation); 0 = the
                         * reference's calling convention (already activated) */
   int32_t flags;       /* OLSR_FLAG_* bit mask, 0 = the reference's behaviour */
+  float *tile_depth_cut; /* NULL (the default), or device float[2 x tiles], in/out — see "Per-tile depth cut-offs" below.
+                          * Used by olsr_forward_async / olsr_forward_async_loss only. */
 } olsr_scene;
+
+/* Per-tile depth cut-offs (round 4; an opt-in for SEQUENCES of nearly identical views: the ~100 tracking iterations of a
+ * frame).  The forward composite reads a tile's depth-sorted list only until every pixel of the tile is saturated — at config 3
+ * that is 14 % of the instances; the rest is emitted, tile-sorted and compacted for nothing.  With scene->tile_depth_cut
+ * (device float[2 x tiles]: [0, tiles) the cut-offs in force, in/out — initialise with +infinity = no cut; [tiles, 2 tiles)
+ * library scratch) the forward drops every Gaussian that lies behind the cut-off of EVERY tile its footprint reaches, and
+ * leaves behind, per tile, the cut-off for the NEXT frame: 1.1 x the depth of the entry at which the tile saturated (+ 0.01),
+ * +infinity if it did not saturate, then the largest of the tile's 3 x 3 neighbourhood (a depth edge may move into the tile).
+ * A tile's list is complete up to its cut-off depth, so the result is EXACT — bit-identical images, radii and n_touched,
+ * gradients equal up to the order of their per-Gaussian sums; num_rendered counts the kept instances — whenever every tile
+ * saturated at an entry in front of its cut-off.  If one did not (the view or the scene moved too much) the frame is flagged
+ * OLSR_STATUS_CUT_MISS in num_rendered_dev[1]: its images and gradients may lack contributions in that tile, and the caller
+ * re-renders (the array has been updated: the offending tile and its neighbours carry +infinity again).  Exact tile binning
+ * only (OLSR_BINNING_ELLIPSE); olsr_forward (the synchronising entry) ignores the field.
+ * Without a host read-back: olsr_backward on the state buffers of a CUT_MISS frame writes zero gradients (status_dev[1] = 3),
+ * and olsr_pose_step_gated given that frame's num_rendered_dev takes no step — an iteration whose frame missed is a no-op on
+ * the device, the next one renders the offending tiles uncut, and the sequence of poses is the one without cut-offs. */
+#define OLSR_STATUS_CUT_MISS 3
 
 /* Sizes of the three opaque state buffers (bytes).  Replace
  * CudaRasterizer::required<GeometryState|ImageState|BinningState>, CR/rasterizer_impl.h:84-90. */
@@ -450,6 +470,13 @@ typedef struct olsr_pose_params {
 } olsr_pose_params;
 int olsr_pose_step(const olsr_pose_params *params, const float *dL_dtau_sum, const float *dL_dexposure,
                    const float *projection_matrix, float *state, int32_t *status, void *hip_stream);
+/* olsr_pose_step, skipped on the device when the frame its gradient came from was not usable:
+ *   frame_status  device int32[2], the num_rendered_dev of that frame's olsr_forward_async[_loss] (or NULL: always step).
+ * frame_status[1] != 0 (OLSR_STATUS_OVERFLOW / SYNC_ERROR / CUT_MISS): no optimiser step — state [0,16) and [52,76) and
+ * status[1] keep their values, status[0] = 0 — only the matrices are re-derived, as with dL_dtau_sum == NULL. */
+int olsr_pose_step_gated(const olsr_pose_params *params, const float *dL_dtau_sum, const float *dL_dexposure,
+                         const float *projection_matrix, float *state, int32_t *status, const int32_t *frame_status,
+                         void *hip_stream);
 
 /* Adds one view's per-Gaussian gradients into the flat fp32 buffer
  *   flat[P][3 xyz | 3M sh | 1 opacity | 3 scale | 4 rotation | F language]

@@ -65,6 +65,7 @@ class OlsrScene(C.Structure):
         ("cam_pos", _fp),
         ("activations", C.c_int32),
         ("flags", C.c_int32),
+        ("tile_depth_cut", _fp),
     ]
 
 
@@ -115,7 +116,7 @@ def _ptr(t):
 
 def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode, tan_fovx, tan_fovy,
                scale_modifier, binning=BINNING_RECT, activations=0, flags=0, background, means3D, shs, colors_precomp, language_precomp, opacities,
-               scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos):
+               scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos, tile_depth_cut=None):
     s = OlsrScene()
     s.P, s.D, s.M, s.F = int(P), int(D), int(M), int(F)
     s.width, s.height, s.tile = int(width), int(height), int(tile)
@@ -137,4 +138,5 @@ def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode,
     s.projmatrix = _ptr(projmatrix)
     s.projmatrix_raw = _ptr(projmatrix_raw)
     s.cam_pos = _ptr(cam_pos)
+    s.tile_depth_cut = _ptr(tile_depth_cut)
     return s

@@ -923,18 +923,46 @@ __device__ __forceinline__ void sum_and_post_live_rows(u32 a, u32 b, u32 nblocks
   __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Per-tile depth cut-offs (include/olsr.h): the forward composite left each tile's own cut-off in the second half of the
+// caller's array; the cut-off the NEXT frame applies to a tile is the largest of its 3 x 3 neighbourhood — what a tile needs
+// one frame later is, after a small camera step, what it or a neighbour needed now (a depth edge that moves into the tile).
+struct CutDilate {
+  float* cut;  // [2 * ntiles]: applied (written here) | raw (read here), or null
+  int gx, gy;
+};
+__device__ __forceinline__ void dilate_depth_cuts(const CutDilate& cd, int thread, int nthreads) {
+  if (cd.cut == nullptr) return;
+  const int ntiles = cd.gx * cd.gy;
+  const float* raw = cd.cut + ntiles;
+  for (int t = thread; t < ntiles; t += nthreads) {
+    const int tx = t % cd.gx, ty = t / cd.gx;
+    float m = raw[t];
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int x = tx + dx, y = ty + dy;
+        if (x >= 0 && x < cd.gx && y >= 0 && y < cd.gy) m = fmaxf(m, raw[y * cd.gx + x]);
+      }
+    cd.cut[t] = m;
+  }
+}
+
 __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
                                                          u32* __restrict__ order_copy, int ntiles,
                                                          u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq,
                                                          const int32_t* __restrict__ counters,
                                                          int32_t* __restrict__ num_rendered_dev, int32_t* sticky,
-                                                         const u32* __restrict__ hint_slot) {
+                                                         const u32* __restrict__ hint_slot, const CutDilate cd) {
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
   if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
+  dilate_depth_cuts(cd, (int)((blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x),
+                    (int)(gridDim.x * gridDim.y * blockDim.x));
   // the forward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && counters[8] != 0) {
     if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
     if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && counters[9] != 0) {
+    // a tile's depth cut-off may have hidden contributions (OLSR_STATUS_CUT_MISS); an overflow (1) stays
+    if (num_rendered_dev != nullptr && num_rendered_dev[1] == 0) num_rendered_dev[1] = 3;
   }
   const int x = blockIdx.x;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
@@ -985,12 +1013,15 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
                                                                   u32* __restrict__ live_rows, int32_t* mailbox,
                                                                   int32_t seq, const int32_t* __restrict__ counters,
                                                                   int32_t* __restrict__ num_rendered_dev, int32_t* sticky,
-                                                                  const u32* __restrict__ hint_slot) {
+                                                                  const u32* __restrict__ hint_slot, const CutDilate cd) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
+  dilate_depth_cuts(cd, i, (int)(gridDim.x * 256));
   if (i == 0 && counters[8] != 0) {
     if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
     if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (i == 0 && counters[9] != 0) {
+    if (num_rendered_dev != nullptr && num_rendered_dev[1] == 0) num_rendered_dev[1] = 3;
   }
   if (i < ntiles) {
     order[i] = (u32)i;
@@ -1002,18 +1033,20 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
 
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
-                       int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, hipStream_t st) {
+                       int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, float* depth_cut,
+                       int gx, int gy, hipStream_t st) {
   if (ntiles <= 0) return;
+  const CutDilate cd{depth_cut, gx, gy};
   const int len = (ntiles >> 3) + 1;
   if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
     tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_work, tile_order, order_copy, ntiles, live_rows,
                                                                      rows_mailbox, rows_seq, counters, num_rendered_dev,
-                                                                     sticky_error, hint_slot);
+                                                                     sticky_error, hint_slot, cd);
     return;
   }
   tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(
       tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq, counters, num_rendered_dev, sticky_error,
-      hint_slot);
+      hint_slot, cd);
 }
 
 }  // namespace olsr

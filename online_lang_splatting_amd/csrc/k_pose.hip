@@ -39,8 +39,15 @@ struct PoseScalars {
 __global__ __launch_bounds__(64) void pose_step_kernel(PoseScalars hp, const float* __restrict__ dL_dtau_sum,
                                                        const float* __restrict__ dL_dexposure,
                                                        const float* __restrict__ proj, float* __restrict__ state,
-                                                       int32_t* __restrict__ status) {
+                                                       int32_t* __restrict__ status,
+                                                       const int32_t* __restrict__ frame_status) {
   if (threadIdx.x != 0) return;
+  // olsr_pose_step_gated: the frame the gradient came from was not usable (overflow, synchronisation error, depth cut-off
+  // miss) — no optimiser step, nothing of the state changes, the matrices are re-derived from the pose as it is
+  if (frame_status != nullptr && frame_status[1] != 0) {
+    hp.has_grad = 0;
+    status[0] = 0;
+  }
   float T[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) T[i] = state[i];
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(64) void pose_step_kernel(PoseScalars hp, const flo
 }
 
 void launch_pose_step(const olsr_pose_params& p, const float* dL_dtau_sum, const float* dL_dexposure, const float* proj,
-                      float* state, int32_t* status, hipStream_t st) {
+                      float* state, int32_t* status, const int32_t* frame_status, hipStream_t st) {
   PoseScalars k{};
   const int step = p.step > 0 ? p.step : 1;
   const double bc1 = 1.0 - pow(p.beta1, (double)step);
@@ -195,7 +202,7 @@ void launch_pose_step(const olsr_pose_params& p, const float* dL_dtau_sum, const
   k.lr_rot_d = p.lr_rot;
   k.lr_trans_d = p.lr_trans;
   k.lr_exposure_d = p.lr_exposure;
-  pose_step_kernel<<<1, 64, 0, st>>>(k, dL_dtau_sum, dL_dexposure, proj, state, status);
+  pose_step_kernel<<<1, 64, 0, st>>>(k, dL_dtau_sum, dL_dexposure, proj, state, status, frame_status);
 }
 
 }  // namespace olsr

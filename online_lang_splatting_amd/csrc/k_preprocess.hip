@@ -75,18 +75,24 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float m
 struct PendingRows {
   CullEllipse e;
   int ya, nrows, x0, x1;
+  float depth;  // view-space depth of the Gaussian (per-tile depth cut-offs, include/olsr.h)
 };
 constexpr int PRE_ROWCAP = 512;  // rows per fill of a wave's row -> owner table
 struct PreWaveLds {
   float4 e0[64];  // px py b inv_a
   float4 e1[64];  // A det_lo xstar ystar
   int4 m[64];     // exact, x0 | x1 << 16, first row, first row's index among the wave's rows
+  float dz[64];   // depth (only read with depth cut-offs)
+  u32 keep[64];   // depth cut-offs: some tile of the footprint has a cut-off behind the Gaussian
   u32 cnt[64];
   uint8_t owner[PRE_ROWCAP];
 };
 
+// cut (may be null): per-tile depth cut-offs — a Gaussian that lies behind the cut-off of EVERY tile its footprint reaches
+// counts no tiles at all (the emission then skips it like a culled one); any other keeps its whole footprint
 template <int TILE>
-__device__ __forceinline__ u32 count_pending_rows(const PendingRows& pd, PreWaveLds& L, int W, int H) {
+__device__ __forceinline__ u32 count_pending_rows(const PendingRows& pd, PreWaveLds& L, int W, int H, int gx,
+                                                  const float* __restrict__ cut) {
   const int lane = threadIdx.x & 63;
   const u32 nrows = (u32)pd.nrows;
   u32 incl = nrows;
@@ -99,10 +105,12 @@ __device__ __forceinline__ u32 count_pending_rows(const PendingRows& pd, PreWave
   if (total == 0) return 0;  // (wave-uniform)
   const u32 rowoff = incl - nrows;
   L.cnt[lane] = 0;
+  L.keep[lane] = 0;
   if (nrows) {
     L.e0[lane] = make_float4(pd.e.px, pd.e.py, pd.e.b, pd.e.inv_a);
     L.e1[lane] = make_float4(pd.e.A, pd.e.det_lo, pd.e.xstar, pd.e.ystar);
     L.m[lane] = make_int4(pd.e.exact ? 1 : 0, pd.x0 | (pd.x1 << 16), pd.ya, (int)rowoff);
+    L.dz[lane] = pd.depth;
   }
   for (u32 sbase = 0; sbase < total; sbase += PRE_ROWCAP) {
     const u32 k0 = max(rowoff, sbase), k1 = min(rowoff + nrows, sbase + (u32)PRE_ROWCAP);
@@ -125,13 +133,23 @@ __device__ __forceinline__ u32 count_pending_rows(const PendingRows& pd, PreWave
         const int y = m.z + (int)(idx - (u32)m.w);
         int xa = m.y & 0xFFFF, xb = (int)((u32)m.y >> 16);
         cull_row_span<TILE>(e, xa, xb, y, W, H, xa, xb);
-        if (xb > xa) atomicAdd(&L.cnt[o], (u32)(xb - xa));
+        if (xb > xa) {
+          atomicAdd(&L.cnt[o], (u32)(xb - xa));
+          if (cut != nullptr && L.keep[o] == 0u) {  // (stale reads only repeat the search)
+            const float dzo = L.dz[o];
+            for (int x = xa; x < xb; ++x)
+              if (depth_cut_keeps(dzo, cut[y * gx + x])) {
+                L.keep[o] = 1u;
+                break;
+              }
+          }
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  return L.cnt[lane];
+  return (cut != nullptr && L.keep[lane] == 0u) ? 0u : L.cnt[lane];
 }
 
 template <int TILE>
@@ -242,6 +260,7 @@ __device__ __forceinline__ u32 preprocess_one(
       pend.nrows = yb - ya;
       pend.x0 = rc.x0;
       pend.x1 = rc.x1;
+      pend.depth = p_view.z;
       // the emission re-evaluates the row spans from this record without the radius: a radius beyond cull_setup's
       // range (full spans) is handed on as a threshold beyond its range (full spans as well)
       if (!(irad < (1 << 20))) t2 = 2e6f;
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
     int ellipse, int act, u32* __restrict__ rect_partials, u32* __restrict__ count_partials,
-    uint4* __restrict__ sync_words, int sync_quads) {
+    uint4* __restrict__ sync_words, int sync_quads, const float* __restrict__ depth_cut) {
   __shared__ u32 s_area[4], s_cnt[4];
   __shared__ PreWaveLds s_rows[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                                 tan_fovy, focal_x, focal_y, radii, means2D, depths, cov3Ds, rgb, conic_opacity, gx, gy,
                                 tiles_touched, emit_rec, sort_key, sort_val, n_touched, prefiltered, ellipse, act,
                                 count, pend);
-  if (ellipse) count += count_pending_rows<TILE>(pend, s_rows[threadIdx.x >> 6], W, H);
+  if (ellipse) count += count_pending_rows<TILE>(pend, s_rows[threadIdx.x >> 6], W, H, gx, depth_cut);
   if (idx < P) tiles_touched[idx] = count;
   // instances of the reference's rect binning (its num_rendered) and instances this frame emits: one partial per
   // block each, summed by the next kernel (7.8 k same-address atomics would cost more than the whole kernel)
@@ -312,7 +331,8 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
       s.colors_precomp, s.viewmatrix, s.projmatrix, s.cam_pos, d.W, d.H, s.tan_fovx, s.tan_fovy, d.focal_x,           \
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
       g.emit_rec, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
-      s.activations | (s.flags << 16), g.part_rect, g.part_count, reinterpret_cast<uint4*>(g.sync_words), sync_quads
+      s.activations | (s.flags << 16), g.part_rect, g.part_count, reinterpret_cast<uint4*>(g.sync_words), sync_quads,      \
+      ((s.binning == OLSR_BINNING_ELLIPSE) ? s.tile_depth_cut : nullptr)
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

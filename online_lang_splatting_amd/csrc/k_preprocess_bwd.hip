@@ -650,6 +650,8 @@ __global__ __launch_bounds__(1024) void tau_final_kernel(const float* __restrict
   if (threadIdx.x == 0 && counters[8] != 0) {
     if (status_dev != nullptr) status_dev[1] = 2;
     if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (threadIdx.x == 0 && counters[9] != 0 && status_dev != nullptr) {
+    status_dev[1] = 3;  // the forward reported a depth cut-off miss: every gradient of this call is zero (olsr_device.h)
   }
   if (out == nullptr) return;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

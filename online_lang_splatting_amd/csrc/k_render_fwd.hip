@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     float* __restrict__ out_color, float* __restrict__ out_lang, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
     u32* __restrict__ tile_work, const u32* __restrict__ order_hint, const int32_t* __restrict__ counters,
-    const u32* __restrict__ hint_slot, const FusedLossArgs fl) {
+    const u32* __restrict__ hint_slot, float* __restrict__ depth_cut, int32_t* __restrict__ cut_miss,
+    const FusedLossArgs fl) {
   // a radix pass of this frame lost a predecessor's counts (olsr_state.h, counters[8]): the lists are garbage and must not be
   // used as indices — render nothing; the tile-order kernel behind this one reports OLSR_STATUS_SYNC_ERROR
   if (counters[8] != 0) return;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
   // blending pixel belongs to (15x15 tiles); each wave writes only its own 16 bits
   __shared__ uint2 s_hit[B];
   __shared__ u32 s_work, s_work2;
+  __shared__ int s_stop, s_undone;  // per-tile depth cut-offs: the deepest list position a wave stopped at; waves not saturated
 
   // workgroup b runs on XCD b % 8; with a hint it takes the (b / 8)-th heaviest tile of that XCD's chunk as
   // measured on the caller's previous frame, else the (b / 8)-th tile of the chunk
@@ -128,7 +130,11 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
   if (tid == 0) {
     s_work = 0;
     s_work2 = 0;
+    s_stop = -1;
+    s_undone = 0;
   }
+  int my_stop = -1;   // (wave-uniform) list position of the entry at which this wave's last pixel saturated
+  int last_base = 0;  // (uniform) first list position of the batch staged last
   // (the tile's live-pair counts are summed per flush with wave ballots straight into LDS: a per-thread counter kept across
   //  the loop cost a register the accumulation variants do not have)
 #ifdef OLSR_FWD_STATS
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     // also the barrier that separates the previous batch's flush from this batch's staging
     if (__syncthreads_and(done_m == ~0ull)) break;
     const int cnt = min(B, n - base);
+    last_base = base;
     {
       const int e = tid & (B - 1);
       if (e == cnt && (cnt & 1) && tid < B) {  // odd tail: the partner slot of the last entry can never be reached
@@ -293,7 +300,10 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
             if constexpr (TILE == 15) rec |= ((contrib_m & cls_m0) ? 0x100u : 0u) | ((contrib_m & cls_m1) ? 0x200u : 0u);
             if (lane0) reinterpret_cast<uint16_t*>(s_hit)[4 * jj + w] = (uint16_t)rec;
           }
-          if (done_m == ~0ull) break;
+          if (done_m == ~0ull) {
+            my_stop = base + jj;
+            break;
+          }
         }
         if (done_m == ~0ull) break;
       }
@@ -333,6 +343,31 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     atomicAdd(&g_fwd_stats[5], (unsigned long long)n);
   }
 #endif
+  // Per-tile depth cut-offs (include/olsr.h).  The frame dropped every Gaussian that lies behind the cut-off of each tile
+  // it reaches, so a tile's list is complete up to its cut-off depth and may have holes behind it.  The tile is exact if its
+  // last pixel saturated at an entry not deeper than the cut-off; if it read on into the part with holes, or ran out of list
+  // without saturating although a cut-off was in force, the frame is flagged.  It leaves its own cut-off for the next frame in
+  // the second half of the array — 1.1 x the depth of the entry at which its last pixel saturated (that entry is in the batch
+  // staged last, still in LDS) + 0.01, +infinity if a wave never saturated; the tile-order kernel dilates them (k_binning.hip).
+  if (depth_cut != nullptr) {
+    if (lane0) {
+      if (done_m != ~0ull) atomicAdd(&s_undone, 1);
+      else if (my_stop >= 0) atomicMax(&s_stop, my_stop);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const float old_cut = depth_cut[tile_id];
+      float new_cut = __builtin_inff();
+      bool miss = s_undone != 0 && old_cut < __builtin_inff();
+      if (s_undone == 0 && s_stop >= 0) {
+        const float stop_depth = s_feat[(s_stop - last_base) * FR + 3];
+        new_cut = stop_depth * 1.1f + 0.01f;
+        miss = stop_depth > old_cut;
+      }
+      if (miss) atomicOr(cut_miss, 1);
+      depth_cut[ntiles + tile_id] = new_cut;
+    }
+  }
   // backward work estimate of this tile: the number of (instance, slot) pairs it will visit
   __syncthreads();
   if (tid == 0) {
@@ -483,7 +518,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
 #define OLSR_FWD_ARGS                                                                                                  \
   im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
-      n_touched, b.flags, im.tile_work, order_inout, g.counters, hint_slot
+      n_touched, b.flags, im.tile_work, order_inout, g.counters, hint_slot,                                             \
+      (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), &g.counters[9]
 
 #if OLSR_FWD_TU_LOSS == 0
 template <int TILE, int F>
@@ -598,7 +634,8 @@ void launch_render_forward(const olsr_scene& s, const FrameDims& d, const Geomet
     launch_render_forward_images(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched,
                                  tile_order_inout, rm.hint_slot, st);
   launch_tile_order(im.tile_work, im.tile_order, tile_order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, g.counters,
-                    num_rendered_dev, rm.sticky, rm.hint_slot, st);
+                    num_rendered_dev, rm.sticky, rm.hint_slot,
+                    (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), d.gx, d.gy, st);
 }
 #endif
 

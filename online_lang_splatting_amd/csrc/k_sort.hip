@@ -186,6 +186,7 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
       house.counters[6] = 0;
       house.counters[7] = 0;
       house.counters[8] = 0;  // synchronisation error of this frame (olsr_state.h)
+      house.counters[9] = 0;  // a tile with a depth cut-off did not saturate (include/olsr.h, OLSR_STATUS_CUT_MISS)
       if (house.live_rows) {
         house.live_rows[0] = 0;
         house.live_rows[1] = 0;

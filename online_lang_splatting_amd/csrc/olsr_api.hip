@@ -334,7 +334,11 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     int tpasses = 0;
     const int tdb = fused_sort_digit_bits(tbits, &tpasses);
     const bool fused_tiles = !legacy && fused_sort_applicable(n_host, tbits);
-    const SortPlan tile_plan = sort_plan(n_host, /*n_is_capacity=*/!sync_mode);
+    // (with depth cut-offs a steady-state frame keeps a fraction of the instances its capacity was sized for — config 3: a
+    //  quarter —, and a pass is bound by the latency of its fattest block: plan the chunks for that, the uncut first frame of a
+    //  sequence pays a few rounds more)
+    const bool cut_mode = !sync_mode && s.tile_depth_cut != nullptr && s.binning == OLSR_BINNING_ELLIPSE;
+    const SortPlan tile_plan = sort_plan(n_host, /*n_is_capacity=*/!sync_mode, cut_mode ? 25 : 85);
     // synchronisation words of the binning buffer that this frame uses (zeroed by the emission kernel)
     const int64_t bin_sync_words =
         (b.tile_status - b.sync_words) +
@@ -570,7 +574,9 @@ int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* ge
   if (num_rendered) *num_rendered = 0;
   const int tile = scene->tile > 0 ? scene->tile : 15;
   const int ntiles = ((scene->width + tile - 1) / tile) * ((scene->height + tile - 1) / tile);
-  return forward_impl(*scene, geom, img, bp, out_color, out_language, out_depth, out_opacity, radii, n_touched,
+  olsr_scene sc = *scene;
+  sc.tile_depth_cut = nullptr;  // (per-tile depth cut-offs belong to the sync-free entries: their verdict is a device status word)
+  return forward_impl(sc, geom, img, bp, out_color, out_language, out_depth, out_opacity, radii, n_touched,
                       num_rendered, nullptr, nullptr, (hipStream_t)hip_stream, nullptr,
                       order_hint_of(ntiles, (hipStream_t)hip_stream));
 }
@@ -768,11 +774,18 @@ int olsr_adam_step_sum(int32_t P, int32_t M, int32_t F, const olsr_adam_params* 
 
 int olsr_pose_step(const olsr_pose_params* params, const float* dL_dtau_sum, const float* dL_dexposure,
                    const float* projection_matrix, float* state, int32_t* status, void* hip_stream) {
+  return olsr_pose_step_gated(params, dL_dtau_sum, dL_dexposure, projection_matrix, state, status, nullptr, hip_stream);
+}
+
+int olsr_pose_step_gated(const olsr_pose_params* params, const float* dL_dtau_sum, const float* dL_dexposure,
+                         const float* projection_matrix, float* state, int32_t* status, const int32_t* frame_status,
+                         void* hip_stream) {
   if (!params || !projection_matrix || !state || !status)
     return fail(OLSR_ERR_ARG, "pose params, projection_matrix, state and status are required");
   // (step <= 0 with a gradient: the step count is status[1] + 1, kept on the device — see include/olsr.h)
   if (!dL_dtau_sum && dL_dexposure) return fail(OLSR_ERR_ARG, "an exposure gradient needs a pose gradient (one optimiser step)");
-  launch_pose_step(*params, dL_dtau_sum, dL_dexposure, projection_matrix, state, status, (hipStream_t)hip_stream);
+  launch_pose_step(*params, dL_dtau_sum, dL_dexposure, projection_matrix, state, status, frame_status,
+                   (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("pose_step launch: ") + hipGetErrorString(e));
   return OLSR_OK;

@@ -14,7 +14,10 @@ namespace olsr {
 
 // The backward must not trust this frame's lists / rows: the row scratch was too small or the forward overflowed its instance
 // capacity (counters[7]), or a look-back ran into its spin bound (counters[8], olsr_state.h) — every gradient is then zero.
-__device__ __forceinline__ bool frame_unusable(const int32_t* counters) { return (counters[7] | counters[8]) != 0; }
+// or a tile's depth cut-off hid contributions (counters[9], OLSR_STATUS_CUT_MISS: the forward's images are not the frame's).
+__device__ __forceinline__ bool frame_unusable(const int32_t* counters) {
+  return (counters[7] | counters[8] | counters[9]) != 0;
+}
 
 
 typedef unsigned int u32;
@@ -456,6 +459,10 @@ __device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f
 __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
                                        0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
                                        -0.5900435899266435f};
+
+// Per-tile depth cut-offs (include/olsr.h): the test preprocess applies to a (tile, Gaussian) pair.  NaN cut-offs keep
+// everything.
+__device__ __forceinline__ bool depth_cut_keeps(float depth, float cut) { return !(depth > cut); }
 
 // XCD-aware tile remap: workgroup b is observed to run on XCD b % 8; give each XCD a
 // contiguous run of tiles so neighbouring tiles (which share Gaussians) share an L2.

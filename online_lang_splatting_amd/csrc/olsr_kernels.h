@@ -52,7 +52,8 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
 // synchronisation); live_rows: ImageState::live_rows, zero on entry, the staging of those sums
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
-                       int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, hipStream_t st);
+                       int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, float* depth_cut,
+                       int gx, int gy, hipStream_t st);
 struct RowsMailbox {  // set by olsr_forward for the duration of one call (thread-local in olsr_api.hip)
   int32_t* dev = nullptr;
   int32_t seq = 0;
@@ -144,7 +145,7 @@ void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const flo
 
 // k_pose.hip
 void launch_pose_step(const olsr_pose_params& p, const float* dL_dtau_sum, const float* dL_dexposure, const float* proj,
-                      float* state, int32_t* status, hipStream_t st);
+                      float* state, int32_t* status, const int32_t* frame_status, hipStream_t st);
 
 // k_knn.hip
 size_t knn_scratch_bytes(int P);

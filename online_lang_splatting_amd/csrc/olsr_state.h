@@ -63,10 +63,11 @@ inline int sort_plan_forced_kpt() {
 // n_is_capacity: n bounds a count that is only known on the device (olsr_forward_async); the rounds are then estimated
 // for 85 % of it — callers size a capacity with headroom, blocks past the real count exit at once, and the choice only
 // moves time, never the result.
-inline SortPlan sort_plan(long long n, bool n_is_capacity = false) {
+// fill_pct: the share of a capacity the caller expects to be used (per-tile depth cut-offs leave a fraction of the instances).
+inline SortPlan sort_plan(long long n, bool n_is_capacity = false, int fill_pct = 85) {
   static const int cand[5] = {2, 4, 8, 12, 16};
   const long long res = sort_plan_resident_blocks();
-  const long long n_est = n_is_capacity ? (n * 85 + 99) / 100 : n;
+  const long long n_est = n_is_capacity ? (n * fill_pct + 99) / 100 : n;
   int best = sort_plan_forced_kpt();
   // (a forced kpt whose block count would overrun the status rows reserved for FUSED_SORT_MAX_BLOCKS is ignored)
   if (best != 0 && (n + 1024LL * best - 1) / (1024LL * best) > FUSED_SORT_MAX_BLOCKS) best = 0;
@@ -138,7 +139,8 @@ struct GeometryState {
                           //      8 = synchronisation error: a look-back of a radix pass or of the row compaction ran into its
                           //          spin bound (a status word corrupted mid-frame).  Reset by the frame's first kernel; the
                           //          forward reports it as num_rendered_dev[1] = 2, the backward writes zero gradients and
-                          //          reports status_dev[1] = 2 / OLSR_ERR_DEVICE (include/olsr.h).  [9..15] reserved
+                          //          reports status_dev[1] = 2 / OLSR_ERR_DEVICE (include/olsr.h),
+                          //      9 = a tile with a depth cut-off did not saturate (OLSR_STATUS_CUT_MISS).  [10..15] reserved
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
   uint4* big_list;        // [P] work lists {id, first instance, #instances} built by the emission: large footprints from

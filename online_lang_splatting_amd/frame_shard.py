@@ -331,7 +331,7 @@ class FusedAdam:
 
 
 def _raise_on_sync_error(status, where):
-    if status >= 2:
+    if status == 2:
         raise RuntimeError(f"olsr {where}: device-side synchronisation error (OLSR_STATUS_SYNC_ERROR): a look-back of the "
                            "frame's radix sort / row compaction never received a predecessor's counts; the frame's "
                            "synchronisation words were overwritten mid-frame.  Images of that frame are invalid, gradients zero")
@@ -341,7 +341,7 @@ class RasterWorkspace:
     """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
 
     def __init__(self, P, W, H, F, M, capacity, device, tile=15, bwd_mode=_abi.BWD_REFERENCE, row_capacity=None,
-                 binning=_abi.BINNING_ELLIPSE, flags=0):
+                 binning=_abi.BINNING_ELLIPSE, flags=0, depth_cut=False):
         self.P, self.W, self.H, self.F, self.M = int(P), int(W), int(H), int(F), int(M)
         self.capacity, self.tile, self.bwd_mode = int(capacity), int(tile), int(bwd_mode)
         self.binning_mode = int(binning)
@@ -367,6 +367,12 @@ class RasterWorkspace:
         # workspace's previous frame (consecutive SLAM frames load the tiles alike); identity before the first
         ntiles = ((W + tile - 1) // tile) * ((H + tile - 1) // tile)
         self.tile_order = torch.arange(ntiles, **i32)
+        # per-tile depth cut-offs (include/olsr.h; opt-in, for sequences of nearly identical views such as the tracking
+        # iterations of a frame): in = what the previous forward left, out = this forward's; +inf = no cut.  A forward whose
+        # status is OLSR_STATUS_CUT_MISS (forward_status() == 3) must be repeated — the array has been repaired by then
+        # per-tile depth cut-offs (include/olsr.h): [0, tiles) the cut-offs in force, [tiles, 2 tiles) library scratch
+        self._depth_cut_buf = torch.full((2 * ntiles,), float("inf"), **f32) if depth_cut else None
+        self.depth_cut = self._depth_cut_buf[:ntiles] if depth_cut else None
         self.grads = dict(dL_dmeans2D=torch.empty(P, 3, **f32), dL_dconic=torch.empty(P, 4, **f32),
                           dL_dopacity=torch.empty(P, 1, **f32), dL_dcolors=torch.empty(P, 3, **f32),
                           dL_dlanguage=torch.empty(P, F, **f32), dL_ddepths=torch.empty(P, 1, **f32),
@@ -404,7 +410,7 @@ class RasterWorkspace:
             means3D=means3D, shs=shs,
             colors_precomp=colors_precomp, language_precomp=language, opacities=opacities, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix,
-            projmatrix_raw=projmatrix_raw, cam_pos=campos)
+            projmatrix_raw=projmatrix_raw, cam_pos=campos, tile_depth_cut=self._depth_cut_buf)
 
     def forward(self):
         o = self.out
@@ -504,7 +510,16 @@ class RasterWorkspace:
         """(R, overflow) — synchronises; call outside timed regions.  Raises on a device-side synchronisation error."""
         r = self.num_rendered.cpu()
         _raise_on_sync_error(int(r[1]), "forward")
-        return int(r[0]), bool(r[1])
+        return int(r[0]), int(r[1]) == 1
+
+    def forward_status(self):
+        """OLSR_STATUS_* of the last forward (0 fine, 1 capacity overflow, 2 synchronisation error, 3 a depth cut-off was
+        missed: repeat the forward) — synchronises."""
+        return int(self.num_rendered.cpu()[1])
+
+    def reset_depth_cut(self):
+        if self.depth_cut is not None:
+            self.depth_cut.fill_(float("inf"))
 
 
 class FrameLanes:

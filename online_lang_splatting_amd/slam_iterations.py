@@ -64,18 +64,24 @@ class PoseState:
         self.hp.step = 0
         self._call(None, None)  # the matrices of the start pose (no gradient: no step)
 
-    def _call(self, dL_dtau_sum, dL_dexposure):
-        check(lib().olsr_pose_step(C.byref(self.hp), dL_dtau_sum.data_ptr() if dL_dtau_sum is not None else None,
-                                   dL_dexposure.data_ptr() if dL_dexposure is not None else None,
-                                   self.proj.data_ptr(), self.state.data_ptr(), self.status.data_ptr(),
-                                   C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+    def _call(self, dL_dtau_sum, dL_dexposure, frame_status=None):
+        check(lib().olsr_pose_step_gated(C.byref(self.hp), dL_dtau_sum.data_ptr() if dL_dtau_sum is not None else None,
+                                         dL_dexposure.data_ptr() if dL_dexposure is not None else None,
+                                         self.proj.data_ptr(), self.state.data_ptr(), self.status.data_ptr(),
+                                         frame_status.data_ptr() if frame_status is not None else None,
+                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
-    def step(self, dL_dtau_sum: torch.Tensor, dL_dexposure: Optional[torch.Tensor] = None):
+    def step(self, dL_dtau_sum: torch.Tensor, dL_dexposure: Optional[torch.Tensor] = None,
+             frame_status: Optional[torch.Tensor] = None):
         """dL_dtau_sum: device float[6] = [rho | theta] as olsr_backward leaves it; dL_dexposure: device float[2] from
-        olsr_tracking_loss (ignored unless optimise_exposure)."""
+        olsr_tracking_loss (ignored unless optimise_exposure); frame_status: the forward's device int32[2] {R, status} —
+        the step is skipped on the device when that frame was not usable (olsr_pose_step_gated; the step count must then
+        live on the device too)."""
+        if frame_status is not None and not self.device_step_count:
+            raise ValueError("a gated pose step needs PoseState(device_step_count=True): the host cannot know whether it counted")
         if not self.device_step_count:
             self.hp.step += 1
-        self._call(dL_dtau_sum, dL_dexposure if self.optimise_exposure else None)
+        self._call(dL_dtau_sum, dL_dexposure if self.optimise_exposure else None, frame_status)
 
     def camera(self) -> Dict:
         return dict(viewmatrix=self.viewmatrix, projmatrix=self.projmatrix, projmatrix_raw=self.proj,
@@ -131,10 +137,20 @@ class TrackingLoop:
                                       rgb_boundary_threshold=self.thr)
         self.loss = lo["loss"]
         g = ws.backward(lo["dL_dimage"], self.zero_lang, lo["dL_ddepth"], pose_only=True)
-        self.pose.step(g["dL_dtau_sum"], lo["dL_dexposure"])
+        # Per-tile depth cut-offs (RasterWorkspace(depth_cut=True), include/olsr.h): every iteration renders with the cut-offs
+        # the previous one left.  A frame whose cut-offs hid something is flagged on the device; its backward writes zeros and
+        # the gated pose step does nothing, so the iteration is a no-op and the next one renders the offending tiles uncut:
+        # the poses are those of the loop without cut-offs, `steps_done()` says how many iterations counted.
+        self.pose.step(g["dL_dtau_sum"], lo["dL_dexposure"],
+                       frame_status=ws.num_rendered if ws.depth_cut is not None else None)
         if read_convergence:
             return bool(int(self.pose.status[0].item()))  # one 4-byte read-back, like the reference
         return False
+
+    def steps_done(self) -> int:
+        """Optimiser steps taken since PoseState.reset (device count; with depth cut-offs an iteration whose frame missed
+        does not count)."""
+        return int(self.pose.status[1].item())
 
 
 class MappingStep:
