@@ -60,7 +60,12 @@ def test_config3_line_carries_the_config4_substitute():
     trk = c4["tracking"]["ms_per_iteration"]
     assert set(trk) == {"no_language_cotangent", "no_language_cotangent_with_convergence_readback",
                         "zero_language_cotangent", "zero_language_cotangent_with_convergence_readback",
-                        "rgb_rasterizer_render", "no_language_cotangent_two_kernel_loss"}
+                        "rgb_rasterizer_render", "no_language_cotangent_two_kernel_loss", "depth_cut_offs"}
+    cut = c4["tracking_depth_cut"]   # the same loop on a workspace with per-tile depth cut-offs: its own leg, not the headline
+    assert cut["instances_last_frame"] < 0.5 * cut["instances_without_cut"]
+    assert cut["iterations_that_counted"] >= 0.8 * cut["iterations"]
+    chain = lambda st: st["depth_sort"] + st["emit"] + st["tile_sort"]
+    assert chain(cut["library_stage_ms"]) < chain(c4["tracking"]["library_stage_ms"])
     assert trk["no_language_cotangent"] <= 1.02 * trk["no_language_cotangent_two_kernel_loss"]  # the fused epilogue pays
     assert c4["tracking"]["pose_error_after"] < c4["tracking"]["pose_error_start"]  # it moved towards the target pose
     assert not c4["mapping"]["capacity_overflow"] and c4["mapping"]["views"] == 12
