@@ -167,7 +167,8 @@ typedef struct olsr_scene {
  * saturated at an entry in front of its cut-off.  If one did not (the view or the scene moved too much) the frame is flagged
  * OLSR_STATUS_CUT_MISS in num_rendered_dev[1]: its images and gradients may lack contributions in that tile, and the caller
  * re-renders (the array has been updated: the offending tile and its neighbours carry +infinity again).  Exact tile binning
- * only (OLSR_BINNING_ELLIPSE); olsr_forward (the synchronising entry) ignores the field.
+ * only (OLSR_BINNING_ELLIPSE; ignored with OLSR_BINNING_RECT), default forward accumulation only, and with a fused loss only
+ * the tracking loss (OLSR_ERR_ARG otherwise); olsr_forward (the synchronising entry) ignores the field.
  * Without a host read-back: olsr_backward on the state buffers of a CUT_MISS frame writes zero gradients (status_dev[1] = 3),
  * and olsr_pose_step_gated given that frame's num_rendered_dev takes no step — an iteration whose frame missed is a no-op on
  * the device, the next one renders the offending tiles uncut, and the sequence of poses is the one without cut-offs. */

@@ -60,7 +60,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LOSS: 0 = images only; 1 / 2 = the mapping / tracking loss evaluated in the epilogue (olsr_forward_async_loss): the pixel's
 //      colour, depth, language features and transmittance are still in registers, so the cotangents the backward consumes and
 //      the tile's partial loss sums are produced here instead of by a kernel that re-reads the images (csrc/olsr_loss_device.h).
-template <int TILE, int F, int ACC, int LOSS>
+// CUT:  the per-tile depth cut-off bookkeeping (include/olsr.h) — its own instantiation: carried as a run-time test it cost the
+//       plain kernel 4 % (0.1588 -> 0.1647 ms at config 3, two more live scalars across the entry loop).
+template <int TILE, int F, int ACC, int LOSS, bool CUT>
 __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FWD_ACC2_WAVES : 7)) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     // also the barrier that separates the previous batch's flush from this batch's staging
     if (__syncthreads_and(done_m == ~0ull)) break;
     const int cnt = min(B, n - base);
-    last_base = base;
+    if constexpr (CUT) last_base = base;
     {
       const int e = tid & (B - 1);
       if (e == cnt && (cnt & 1) && tid < B) {  // odd tail: the partner slot of the last entry can never be reached
@@ -288,6 +290,8 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
 #pragma unroll
                 for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k], w2, acc2[k]);
               } else {
+                // (the same arithmetic on scalar fp32 — mul, fma per channel instead of the packed pairs — measured equal in
+                //  round 4, 0.1648 against 0.1647 ms: op_sel broadcasts alpha and T, there are no operand moves to save)
                 const v2f a2 = {alpha, alpha}, T2 = {T, T};
 #pragma unroll
                 for (int k = 0; k < NA2; ++k) acc2[k] = __builtin_elementwise_fma(fr2[k] * a2, T2, acc2[k]);
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
             if (lane0) reinterpret_cast<uint16_t*>(s_hit)[4 * jj + w] = (uint16_t)rec;
           }
           if (done_m == ~0ull) {
-            my_stop = base + jj;
+            if constexpr (CUT) my_stop = base + jj;
             break;
           }
         }
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
   // without saturating although a cut-off was in force, the frame is flagged.  It leaves its own cut-off for the next frame in
   // the second half of the array — 1.1 x the depth of the entry at which its last pixel saturated (that entry is in the batch
   // staged last, still in LDS) + 0.01, +infinity if a wave never saturated; the tile-order kernel dilates them (k_binning.hip).
-  if (depth_cut != nullptr) {
+  if constexpr (CUT) {
     if (lane0) {
       if (done_m != ~0ull) atomicAdd(&s_undone, 1);
       else if (my_stop >= 0) atomicMax(&s_stop, my_stop);
@@ -529,12 +533,16 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
                          hipStream_t st) {
   const float* colors = s.colors_precomp ? s.colors_precomp : g.rgb;
   const FusedLossArgs none{};
+  // (depth cut-offs come with the default accumulation only: olsr_api.hip refuses the other combinations)
+  const bool cut = s.binning == OLSR_BINNING_ELLIPSE && s.tile_depth_cut != nullptr;
   if (s.flags & OLSR_FLAG_FWD_ACCUM_MFMA)
-    render_fwd_kernel<TILE, F, 1, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
+    render_fwd_kernel<TILE, F, 1, 0, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
   else if (s.flags & OLSR_FLAG_FWD_ACCUM_WEIGHT)
-    render_fwd_kernel<TILE, F, 2, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
+    render_fwd_kernel<TILE, F, 2, 0, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
+  else if (cut)
+    render_fwd_kernel<TILE, F, 0, 0, true><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
   else
-    render_fwd_kernel<TILE, F, 0, 0><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
+    render_fwd_kernel<TILE, F, 0, 0, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, none);
 }
 #else
 template <int TILE, int F>
@@ -561,10 +569,14 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
   fl.alpha = lf.params.alpha;
   fl.thr = lf.params.rgb_boundary_threshold;
   fl.lamda = lf.params.lamda_lang;
-  if (lf.tracking)
-    render_fwd_kernel<TILE, F, 0, 2><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
+  // (depth cut-offs are an option of the tracking loop: olsr_api.hip refuses them with the mapping loss)
+  const bool cut = s.binning == OLSR_BINNING_ELLIPSE && s.tile_depth_cut != nullptr;
+  if (lf.tracking && cut)
+    render_fwd_kernel<TILE, F, 0, 2, true><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
+  else if (lf.tracking)
+    render_fwd_kernel<TILE, F, 0, 2, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
   else
-    render_fwd_kernel<TILE, F, 0, 1><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
+    render_fwd_kernel<TILE, F, 0, 1, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
   olsr_loss_params p = lf.params;
   p.F = s.F;  // (the language term is normalised by the channels it sums over)
   launch_loss_final(fl.partials, d.ntiles, p, lf.tracking != 0, lang_term, fl.use_exposure != 0, lf.loss, lf.dL_dexposure, st);

@@ -589,6 +589,9 @@ int olsr_forward_async(const olsr_scene* scene, void* geometry_buffer, void* bin
   if (rc != OLSR_OK) return rc;
   if (!geometry_buffer || !binning_buffer || !image_buffer || capacity < 0)
     return fail(OLSR_ERR_ARG, "state buffers and a non-negative capacity are required");
+  if (scene->tile_depth_cut && scene->binning == OLSR_BINNING_ELLIPSE &&
+      (scene->flags & (OLSR_FLAG_FWD_ACCUM_MFMA | OLSR_FLAG_FWD_ACCUM_WEIGHT)))
+    return fail(OLSR_ERR_ARG, "tile_depth_cut: only with the default forward accumulation");
   BinningProvider bp;
   bp.fixed = binning_buffer;
   bp.capacity = capacity;
@@ -623,6 +626,9 @@ int olsr_forward_async_loss(const olsr_scene* scene, void* geometry_buffer, void
   const bool lang_term = !loss->tracking && lp.F > 0 && loss->gt_language != nullptr;
   if (lang_term && (lp.F != scene->F || !loss->dL_dlanguage || lp.lang_width <= 0 || lp.lang_height <= 0))
     return fail(OLSR_ERR_ARG, "fused loss: a language term needs params.F == scene F, dL_dlanguage and the target's size");
+  if (scene->tile_depth_cut && scene->binning == OLSR_BINNING_ELLIPSE && !loss->tracking)
+    return fail(OLSR_ERR_ARG, "tile_depth_cut: with a fused loss only for the tracking loss (a mapping step sums views; a view "
+                              "whose frame missed would change the sum)");
   if (scene->P <= 0)  // nothing is rendered (the images are the background): the stand-alone kernels define this case
     return fail(OLSR_ERR_ARG, "fused loss: P must be > 0 (use olsr_mapping_loss / olsr_tracking_loss on an empty render)");
   olsr_loss_fusion lf = *loss;

@@ -185,3 +185,24 @@ def test_tracking_loop_with_cut_offs_walks_the_same_poses(hip):
     assert iters["cut"] <= STEPS + STEPS // 4, iters     # few iterations are lost to misses
     assert Rsum["cut"] < 0.7 * Rsum["plain"], Rsum       # and the lists really are shorter
     print("tracking with cut-offs:", iters, Rsum)
+
+
+def test_combinations_without_a_cut_off_kernel_are_refused(hip):
+    """The cut-off bookkeeping exists for the default accumulation, with images or the tracking loss; the mapping loss and the
+    alternative accumulations answer OLSR_ERR_ARG instead of rendering a frame whose lists were cut and never checked."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    sc, g, cot, plain, cut, dev = _setup(P=3000, W=160, H=120)
+    cam = _cam(sc.camera, dev)
+    H, W = sc.camera.height, sc.camera.width
+    gt_image, gt_depth = torch.rand(3, H, W, device=dev), torch.rand(H, W, device=dev) + 0.5
+    gt_lang = torch.rand(sc.F, 24, 32, device=dev)
+    cut.set_scene(sh_degree=sc.sh_degree, **cam, **g)
+    with pytest.raises(RuntimeError, match="tile_depth_cut"):
+        cut.forward_loss(gt_image, gt_depth, gt_lang, None, None, tracking=False)
+    lo = cut.forward_loss(gt_image, gt_depth, None, None, None, tracking=True, skip_images=True)   # the tracking loss is fine
+    assert cut.forward_status() == 0 and float(lo["loss"][0]) > 0
+    weight = RasterWorkspace(sc.P, W, H, sc.F, sc.shs.shape[1], 500_000, dev, flags=_abi.FLAG_FWD_ACCUM_WEIGHT,
+                             depth_cut=True)
+    weight.set_scene(sh_degree=sc.sh_degree, **cam, **g)
+    with pytest.raises(RuntimeError, match="tile_depth_cut"):
+        weight.forward()
