@@ -823,7 +823,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
       const int32_t ov = ((long long)L > row_capacity || counters[2] != 0) ? 1 : 0;
       rowbase[n] = L;
       counters[6] = (int32_t)L;
-      counters[7] = ov;
+      // (a frame whose depth cut-offs hid contributions — counters[9], OLSR_STATUS_CUT_MISS — hands out no gradients either;
+      //  the backward's last kernel reports it as status 3)
+      counters[7] = (ov != 0 || counters[9] != 0) ? 1 : 0;
       if (status_dev) {
         status_dev[0] = (int32_t)L;
         status_dev[1] = ov;

@@ -12,12 +12,12 @@
 
 namespace olsr {
 
-// The backward must not trust this frame's lists / rows: the row scratch was too small or the forward overflowed its instance
-// capacity (counters[7]), or a look-back ran into its spin bound (counters[8], olsr_state.h) — every gradient is then zero.
-// or a tile's depth cut-off hid contributions (counters[9], OLSR_STATUS_CUT_MISS: the forward's images are not the frame's).
-__device__ __forceinline__ bool frame_unusable(const int32_t* counters) {
-  return (counters[7] | counters[8] | counters[9]) != 0;
-}
+// The backward must not trust this frame's lists / rows: the row scratch was too small, the forward overflowed its instance
+// capacity or a depth cut-off of the forward hid contributions (all three: counters[7], set by the row compaction), or a
+// look-back ran into its spin bound (counters[8], olsr_state.h) — every gradient is then zero.
+// (The cut-off miss, counters[9], is folded into counters[7] by the backward's first kernel instead of being tested here: one
+//  more scalar load in this predicate moved render_bwd_kernel<15,32,...> from 0.502 to 0.52 ms, round 4.)
+__device__ __forceinline__ bool frame_unusable(const int32_t* counters) { return (counters[7] | counters[8]) != 0; }
 
 
 typedef unsigned int u32;
