@@ -387,6 +387,7 @@ __device__ __forceinline__ u32 lb_block_exclusive(u32* status, u32 b, u32 total,
 constexpr int EB_T = OLSR_EB_T;
 constexpr int EB_OUT = OLSR_EB_OUT;
 constexpr int EB_ROWCAP = 16 * EB_T;   // rows per fill of the row -> Gaussian table
+static_assert((EB_OUT & (EB_OUT - 1)) == 0 && EB_OUT >= 4, "the emission window is a power of two");
 static_assert(EB_T <= 256 && EB_T % 64 == 0, "the row -> Gaussian table holds thread indices in one byte");
 constexpr u32 EB_SHORT_ROW = 8;   // rows up to this many tiles are written by their own thread
 
@@ -426,9 +427,10 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
     int P, const u32* __restrict__ order, const u32* __restrict__ inst_count, int32_t* __restrict__ counters,
     const u32* __restrict__ block_totals, uint4* __restrict__ bin_sync, int bin_sync_quads,
     u32* __restrict__ rank_off, u32* __restrict__ win_start, u32* __restrict__ inst_start,
-    uint4* __restrict__ big_list) {
+    uint4* __restrict__ big_list, u32 eb_shift) {
   __shared__ u32 s_wsum[EO_T / 64 + 1];
   __shared__ u32 s_lbase;
+  const u32 eb_out = 1u << eb_shift;  // output window of an emission block (a power of two)
   // the words the tile sort and the row compaction synchronise through live in the binning buffer, which exists only
   // from here on (the drop-in entry allocates it after the instance count is known)
   for (int q = (int)(blockIdx.x * EO_T + threadIdx.x); q < bin_sync_quads; q += (int)(gridDim.x * EO_T))
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
     if (n[k] > 0) {
       inst_start[g[k]] = off[k];
       // this rank owns the first instance of every output window [j * EB_OUT, ...) that starts inside its run
-      for (u32 j = (off[k] + (u32)EB_OUT - 1u) / (u32)EB_OUT; j * (u32)EB_OUT < off[k] + n[k]; ++j)
+      for (u32 j = (off[k] + eb_out - 1u) >> eb_shift; (j << eb_shift) < off[k] + n[k]; ++j)
         win_start[j] = (u32)(r0 + k);
     }
   }
@@ -545,7 +547,7 @@ template <int TILE>
 __global__ __launch_bounds__(EB_T) void emit_balanced_kernel(
     int P, const u32* __restrict__ order, const u32* __restrict__ rank_off, const u32* __restrict__ win_start,
     const float4* __restrict__ emit_rec, int ellipse, int W, int H, int gx, const int32_t* __restrict__ counters,
-    u32* __restrict__ keys, u32* __restrict__ inst_gid) {
+    u32* __restrict__ keys, u32* __restrict__ inst_gid, u32 eb_out) {
   __shared__ EbGauss s_gs[EB_T];
   __shared__ u32 s_g[EB_T], s_first[EB_T], s_rowoff[EB_T];
   __shared__ uint8_t s_owner[EB_ROWCAP];
@@ -553,9 +555,9 @@ __global__ __launch_bounds__(EB_T) void emit_balanced_kernel(
   __shared__ u32 s_flag;
   if (counters[2] != 0 || counters[8] != 0) return;
   const u32 R = (u32)counters[1];
-  const u32 o0 = blockIdx.x * (u32)EB_OUT;
+  const u32 o0 = blockIdx.x * eb_out;
   if (o0 >= R) return;
-  const u32 o1 = min(o0 + (u32)EB_OUT, R);
+  const u32 o1 = min(o0 + eb_out, R);
   const int tid = threadIdx.x, lane = tid & 63;
 
   // the rank that owns instance o0 (left behind by emit_offsets_kernel)
@@ -710,12 +712,19 @@ static void launch_emit_t(const olsr_scene& s, const FrameDims& d, const Geometr
   const int quads = (int)((bin_sync_words + 3) / 4);
   u32* rank_off = g.key_b;   // the depth keys are dead once the order exists
   u32* win_start = b.key_b;  // the tile sort's second key buffer is not in use yet
+  // Output window of an emission block.  With per-tile depth cut-offs most depth ranks emit nothing: a window's instances
+  // come from four times as many ranks, walked in serial batches of 256 — a quarter of the window keeps the per-block
+  // chain where it was (emit_balanced 38.9 -> see profiles/r4_experiments.json).
+  const bool cut_mode = ellipse && s.tile_depth_cut != nullptr;
+  const int eb_out = cut_mode ? EB_OUT / 4 : EB_OUT;
   emit_offsets_kernel<<<nb, EO_T, 0, st>>>(s.P, g.depth_order, g.tiles_touched, g.counters, totals, bsync, quads,
-                                                   rank_off, win_start, g.inst_start, g.big_list);
-  const int64_t nblk = (n_host + EB_OUT - 1) / EB_OUT;
+                                                   rank_off, win_start, g.inst_start, g.big_list,
+                                                   (u32)__builtin_ctz((unsigned)eb_out));
+  const int64_t nblk = (n_host + eb_out - 1) / eb_out;
   if (nblk > 0)
     emit_balanced_kernel<TILE><<<(int)nblk, EB_T, 0, st>>>(s.P, g.depth_order, rank_off, win_start, g.emit_rec,
-                                                           ellipse, d.W, d.H, d.gx, g.counters, b.key_a, b.inst_gid);
+                                                           ellipse, d.W, d.H, d.gx, g.counters, b.key_a, b.inst_gid,
+                                                           (u32)eb_out);
 }
 
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
