@@ -12,6 +12,7 @@
 // All kernels are wave64 code: per-wave ranking uses 64-bit ballots, block = 4 waves.
 #include "olsr_device.h"
 #include "olsr_kernels.h"
+#include "olsr_loss_device.h"
 
 namespace olsr {
 
@@ -962,8 +963,15 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
                                                          u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq,
                                                          const int32_t* __restrict__ counters,
                                                          int32_t* __restrict__ num_rendered_dev, int32_t* sticky,
-                                                         const u32* __restrict__ hint_slot, const CutDilate cd) {
+                                                         const u32* __restrict__ hint_slot, const CutDilate cd,
+                                                         const LossFinalArgs lfa) {
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
+  // the loss of a forward with the fused epilogue: its per-tile partial sums are reduced here, by the grid's last block
+  // (uniform branch; the block then does its share of the tile order like every other)
+  if (lfa.partials != nullptr && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) {
+    __shared__ double s_red[4][LOSS_SUMS];
+    loss_final_block(lfa, s_red);
+  }
   if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
   dilate_depth_cuts(cd, (int)((blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x),
                     (int)(gridDim.x * gridDim.y * blockDim.x));
@@ -1024,7 +1032,12 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
                                                                   u32* __restrict__ live_rows, int32_t* mailbox,
                                                                   int32_t seq, const int32_t* __restrict__ counters,
                                                                   int32_t* __restrict__ num_rendered_dev, int32_t* sticky,
-                                                                  const u32* __restrict__ hint_slot, const CutDilate cd) {
+                                                                  const u32* __restrict__ hint_slot, const CutDilate cd,
+                                                                  const LossFinalArgs lfa) {
+  if (lfa.partials != nullptr && blockIdx.x == gridDim.x - 1) {
+    __shared__ double s_red[4][LOSS_SUMS];
+    loss_final_block(lfa, s_red);
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
   dilate_depth_cuts(cd, i, (int)(gridDim.x * 256));
@@ -1045,19 +1058,19 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
                        int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, float* depth_cut,
-                       int gx, int gy, hipStream_t st) {
+                       int gx, int gy, const LossFinalArgs& loss_final, hipStream_t st) {
   if (ntiles <= 0) return;
   const CutDilate cd{depth_cut, gx, gy};
   const int len = (ntiles >> 3) + 1;
   if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
     tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_work, tile_order, order_copy, ntiles, live_rows,
                                                                      rows_mailbox, rows_seq, counters, num_rendered_dev,
-                                                                     sticky_error, hint_slot, cd);
+                                                                     sticky_error, hint_slot, cd, loss_final);
     return;
   }
   tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(
       tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq, counters, num_rendered_dev, sticky_error,
-      hint_slot, cd);
+      hint_slot, cd, loss_final);
 }
 
 }  // namespace olsr

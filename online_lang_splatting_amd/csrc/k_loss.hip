@@ -144,49 +144,28 @@ __global__ __launch_bounds__(LOSS_THREADS) void mapping_loss_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void mapping_loss_final_kernel(const float* __restrict__ partials, int nb, int W, int H,
-                                                                 int F, int has_lang, float alpha, float lamda,
-                                                                 float* __restrict__ loss,
-                                                                 float* __restrict__ d_exposure) {
+__global__ __launch_bounds__(256) void mapping_loss_final_kernel(const LossFinalArgs a) {
   __shared__ double red[4][LOSS_SUMS];
-  double acc[LOSS_SUMS] = {0, 0, 0, 0, 0};
-  for (int b = threadIdx.x; b < nb; b += 256)
-#pragma unroll
-    for (int k = 0; k < LOSS_SUMS; ++k) acc[k] += (double)partials[(size_t)b * LOSS_SUMS + k];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < LOSS_SUMS; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int mm = 32; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm);
-    if (lane == 0) red[w][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t[LOSS_SUMS];
-    for (int k = 0; k < LOSS_SUMS; ++k) t[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-    const double HW = (double)H * (double)W;
-    const double l_rgb = (double)alpha * t[0] / (3.0 * HW);
-    const double l_depth = (1.0 - (double)alpha) * t[1] / HW;
-    const double l_lang = (has_lang && F > 0) ? (double)lamda * t[2] / ((double)F * HW) : 0.0;
-    loss[0] = (float)(l_rgb + l_depth + l_lang);
-    loss[1] = (float)l_rgb;
-    loss[2] = (float)l_depth;
-    loss[3] = (float)l_lang;
-    if (d_exposure) {
-      d_exposure[0] = (float)((double)alpha * t[3] / (3.0 * HW));
-      d_exposure[1] = (float)((double)alpha * t[4] / (3.0 * HW));
-    }
-  }
+  loss_final_block(a, red);
 }
 
 // the per-tile partials of the forward composite's fused epilogue -> loss[4], dL_dexposure[2] (same final reduction)
-void launch_loss_final(const float* partials, int nb, const olsr_loss_params& p, bool tracking, bool has_lang,
-                       bool use_exposure, float* loss, float* dL_dexposure, hipStream_t st) {
-  mapping_loss_final_kernel<<<1, 256, 0, st>>>(partials, nb, p.width, p.height, tracking ? 0 : p.F,
-                                               (!tracking && has_lang) ? 1 : 0, p.alpha, p.lamda_lang, loss,
-                                               use_exposure ? dL_dexposure : nullptr);
-  if (!use_exposure && dL_dexposure) (void)hipMemsetAsync(dL_dexposure, 0, 2 * sizeof(float), st);
+LossFinalArgs loss_final_args(const float* partials, int nb, const olsr_loss_params& p, bool tracking, bool has_lang,
+                              bool use_exposure, float* loss, float* dL_dexposure) {
+  LossFinalArgs a{};
+  a.partials = partials;
+  a.nb = nb;
+  a.W = p.width;
+  a.H = p.height;
+  a.F = tracking ? 0 : p.F;
+  a.has_lang = (!tracking && has_lang) ? 1 : 0;
+  a.alpha = p.alpha;
+  a.lamda = p.lamda_lang;
+  a.loss = loss;
+  a.d_exposure = dL_dexposure;
+  a.use_exposure = use_exposure ? 1 : 0;
+  a.zero_exposure = use_exposure ? 0 : 1;
+  return a;
 }
 
 int loss_blocks(int W, int H) { return (int)(((size_t)W * H + LOSS_THREADS - 1) / LOSS_THREADS); }
@@ -229,10 +208,8 @@ void launch_mapping_loss(const olsr_loss_params& p, const float* image, const fl
   }
 #undef OLSR_LOSS
 #undef OLSR_LOSS_ARGS
-  mapping_loss_final_kernel<<<1, 256, 0, st>>>(partials, nb, p.width, p.height, tracking ? 0 : p.F,
-                                               (!tracking && gt_language != nullptr) ? 1 : 0,
-                                               p.alpha, p.lamda_lang, loss, use_exposure ? dL_dexposure : nullptr);
-  if (!use_exposure && dL_dexposure) (void)hipMemsetAsync(dL_dexposure, 0, 2 * sizeof(float), st);
+  mapping_loss_final_kernel<<<1, 256, 0, st>>>(loss_final_args(partials, nb, p, tracking, gt_language != nullptr,
+                                                               use_exposure != 0, loss, dL_dexposure));
 }
 
 }  // namespace olsr

@@ -577,9 +577,7 @@ static void launch_fwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
     render_fwd_kernel<TILE, F, 0, 2, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
   else
     render_fwd_kernel<TILE, F, 0, 1, false><<<d.ntiles, 256, 0, st>>>(OLSR_FWD_ARGS, fl);
-  olsr_loss_params p = lf.params;
-  p.F = s.F;  // (the language term is normalised by the channels it sums over)
-  launch_loss_final(fl.partials, d.ntiles, p, lf.tracking != 0, lang_term, fl.use_exposure != 0, lf.loss, lf.dL_dexposure, st);
+  // (the tiles' partial sums are reduced by one block of the tile-order kernel that follows: launch_render_forward)
 }
 #endif
 #undef OLSR_FWD_ARGS
@@ -645,9 +643,19 @@ void launch_render_forward(const olsr_scene& s, const FrameDims& d, const Geomet
   else
     launch_render_forward_images(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched,
                                  tile_order_inout, rm.hint_slot, st);
+  LossFinalArgs lfa{};
+  if (loss != nullptr) {
+    const olsr_loss_fusion& lf = *loss;
+    olsr_loss_params p = lf.params;
+    p.F = s.F;  // (the language term is normalised by the channels it sums over)
+    const bool lang_term = !lf.tracking && lf.params.F > 0 && lf.gt_language != nullptr;
+    const bool use_exposure = lf.exposure != nullptr && !lf.params.initialization;
+    lfa = loss_final_args(reinterpret_cast<const float*>(lf.scratch), d.ntiles, p, lf.tracking != 0, lang_term, use_exposure,
+                          lf.loss, lf.dL_dexposure);
+  }
   launch_tile_order(im.tile_work, im.tile_order, tile_order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, g.counters,
                     num_rendered_dev, rm.sticky, rm.hint_slot,
-                    (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), d.gx, d.gy, st);
+                    (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), d.gx, d.gy, lfa, st);
 }
 #endif
 

@@ -50,10 +50,19 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
 // tile_work: [2][ntiles] (ImageState).  rows_mailbox (may be null): device view of four host words that receive {sum of
 // tile_work[0], sum of tile_work[1], rows_seq, 0} (the drop-in path sizes its backward scratch from them without a
 // synchronisation); live_rows: ImageState::live_rows, zero on entry, the staging of those sums
+// (reduced by one block of the tile-order kernel when a forward carries the fused loss epilogue; see k_loss.hip below)
+struct LossFinalArgs {
+  const float* partials;  // [nb][LOSS_SUMS], or null: nothing to do
+  int nb, W, H, F, has_lang;
+  float alpha, lamda;
+  float* loss;
+  float* d_exposure;       // written if use_exposure, zeroed if zero_exposure, may be null
+  int use_exposure, zero_exposure;
+};
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
                        int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, float* depth_cut,
-                       int gx, int gy, hipStream_t st);
+                       int gx, int gy, const LossFinalArgs& loss_final, hipStream_t st);
 struct RowsMailbox {  // set by olsr_forward for the duration of one call (thread-local in olsr_api.hip)
   int32_t* dev = nullptr;
   int32_t seq = 0;
@@ -153,8 +162,10 @@ void launch_knn(int P, const float* points, float* mean_dist2, void* scratch, hi
 
 // k_loss.hip
 int loss_blocks(int W, int H);
-void launch_loss_final(const float* partials, int nb, const olsr_loss_params& p, bool tracking, bool has_lang,
-                       bool use_exposure, float* loss, float* dL_dexposure, hipStream_t st);
+// the final reduction of a loss's partial sums (olsr_loss_device.h: loss_final_block); for the fused epilogue of the forward
+// composite it runs in one block of the tile-order kernel (partials == nullptr: nothing to do)
+LossFinalArgs loss_final_args(const float* partials, int nb, const olsr_loss_params& p, bool tracking, bool has_lang,
+                              bool use_exposure, float* loss, float* dL_dexposure);
 void launch_mapping_loss(const olsr_loss_params& p, const float* image, const float* depth, const float* language,
                          const float* gt_image, const float* gt_depth, const float* gt_language, const float* exposure,
                          const float* opacity, const float* grad_mask, bool tracking, float* dL_dimage,

@@ -6,6 +6,7 @@
 // resize of the language target and its L1 (utils/slam_backend.py:579-597) and the autograd backward of all of them.
 #pragma once
 #include "olsr_device.h"
+#include "olsr_kernels.h"
 
 namespace olsr {
 
@@ -66,5 +67,44 @@ struct FusedLossArgs {
   int lw, lh, use_exposure, write_images;
   float alpha, thr, lamda;
 };
+
+// The final reduction of a loss's partial sums (per block of the stand-alone loss kernel, per tile of the forward composite's
+// fused epilogue) -> loss[4] = {total, rgb, depth, language}, dL_dexposure[2]: ONE 256-thread block, doubles, fixed order.
+// Called by mapping_loss_final_kernel (k_loss.hip) and, for the fused epilogue, by one block of the tile-order kernel that
+// follows the composite anyway (k_binning.hip: one launch less on the dependent chain of a tracking iteration).
+__device__ __forceinline__ void loss_final_block(const LossFinalArgs& a, double (*red)[LOSS_SUMS]) {
+  double acc[LOSS_SUMS] = {0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < a.nb; b += 256)
+#pragma unroll
+    for (int k = 0; k < LOSS_SUMS; ++k) acc[k] += (double)a.partials[(size_t)b * LOSS_SUMS + k];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < LOSS_SUMS; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm);
+    if (lane == 0) red[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[LOSS_SUMS];
+    for (int k = 0; k < LOSS_SUMS; ++k) t[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    const double HW = (double)a.H * (double)a.W;
+    const double l_rgb = (double)a.alpha * t[0] / (3.0 * HW);
+    const double l_depth = (1.0 - (double)a.alpha) * t[1] / HW;
+    const double l_lang = (a.has_lang && a.F > 0) ? (double)a.lamda * t[2] / ((double)a.F * HW) : 0.0;
+    a.loss[0] = (float)(l_rgb + l_depth + l_lang);
+    a.loss[1] = (float)l_rgb;
+    a.loss[2] = (float)l_depth;
+    a.loss[3] = (float)l_lang;
+    if (a.d_exposure != nullptr && a.use_exposure) {
+      a.d_exposure[0] = (float)((double)a.alpha * t[3] / (3.0 * HW));
+      a.d_exposure[1] = (float)((double)a.alpha * t[4] / (3.0 * HW));
+    } else if (a.d_exposure != nullptr && a.zero_exposure) {
+      a.d_exposure[0] = 0.f;
+      a.d_exposure[1] = 0.f;
+    }
+  }
+}
 
 }  // namespace olsr
