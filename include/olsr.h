@@ -272,6 +272,15 @@ typedef struct olsr_grad_bucket {
   int32_t *max_radii; /* [P] */
   int32_t assign;     /* 1: first view of a step (overwrite), 0: add */
   int32_t _pad0;
+  uint64_t *row_mask; /* NULL, or device uint64[ceil(P / 64)], in/out: bit g is set when row g of `flat` MAY be non-zero.
+                       * Saturation leaves ~98 % of a view's Gaussians without gradient (config 3), and an overwrite that
+                       * rewrites their zero rows is 150 MB of stores per view for nothing: with a mask, assign != 0 writes
+                       * only the rows that have a gradient now or whose bit was set (those are zeroed), and leaves the mask =
+                       * rows with a gradient now; assign == 0 ORs the rows it adds to into the mask.  The result in `flat`
+                       * is the same, bit for bit, provided the mask covers every non-zero row when the call is made: start
+                       * with all ones (= unknown: the first overwrite is dense), and set it to all ones again after writing
+                       * `flat` by any other means (a collective, olsr_accumulate_gradients, a sum of buckets).  `densify` and
+                       * `max_radii` are always written for every Gaussian. */
 } olsr_grad_bucket;
 size_t olsr_backward_scratch_bytes(int64_t rows, int32_t F);
 /* Exact scratch rows for the backward of an olsr_forward (the synchronising entry) without a synchronisation.  The

@@ -72,7 +72,8 @@ class OlsrScene(C.Structure):
 class OlsrGradBucket(C.Structure):
     """struct olsr_grad_bucket, include/olsr.h."""
 
-    _fields_ = [("flat", _fp), ("densify", _fp), ("max_radii", _fp), ("assign", C.c_int32), ("_pad0", C.c_int32)]
+    _fields_ = [("flat", _fp), ("densify", _fp), ("max_radii", _fp), ("assign", C.c_int32), ("_pad0", C.c_int32),
+                ("row_mask", _fp)]
 
 
 class OlsrAdamParams(C.Structure):

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dtau, float* __restrict__ tau_partials, float* __restrict__ bucket_flat,
     float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign, int act,
-    const float* __restrict__ opacities_raw, int F_out) {
+    const float* __restrict__ opacities_raw, int F_out, u64* __restrict__ bucket_row_mask) {
   // F: language channels of the partial-gradient rows; F_out: the scene's (width of dL_dlanguage and of the bucket's
   // language columns).  F == 0 < F_out: the backward ran without a language cotangent, those gradients are zero.
   constexpr int ROW = grad_row(F);
@@ -596,9 +596,39 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     const int g0 = blockIdx.x * PB_THREADS;
     const int count = min(PB_THREADS, P - g0) * width;
     float* out = bucket_flat + (size_t)g0 * width;
-    if (bucket_assign) {
+    // row mask (olsr_grad_bucket.row_mask): bit = the row may be non-zero.  One 64-bit word per wave of this block.
+    u64* mask_word = bucket_row_mask ? bucket_row_mask + ((size_t)g0 >> 6) + (threadIdx.x >> 6) : nullptr;
+    static_assert(PB_THREADS % 64 == 0, "a wave of the block owns one word of the row mask");
+    const bool wave_in_range = g0 + (int)(threadIdx.x & ~63u) < P;  // (wave-uniform: the word exists)
+    if (bucket_assign && mask_word != nullptr) {
+      // Overwrite with a mask: rows that have a gradient now are written, rows that may hold an earlier one are zeroed,
+      // the others are zero already and stay untouched (config 3: 98 % of them — 150 MB of stores per view).  A lane per row
+      // (uncoalesced, but few); blocks where more than a quarter of the rows need a store keep the coalesced pass.
+      __shared__ u32 s_nstore_blk;
+      if (threadIdx.x == 0) s_nstore_blk = 0;
+      __syncthreads();
+      const u64 now = ballot(has_rows);
+      const u64 before = wave_in_range ? *mask_word : 0ull;
+      const u64 store = now | before;
+      if (lane_id() == 0 && store != 0ull) atomicAdd(&s_nstore_blk, (u32)__popcll(store));
+      __syncthreads();
+      if (4u * s_nstore_blk <= (u32)PB_THREADS) {
+        if (((store >> lane_id()) & 1ull) != 0ull && r < P) {
+          float* o = out + (size_t)threadIdx.x * width;
+          const float* b = s_bucket + (size_t)threadIdx.x * width;  // (all zeros for a Gaussian without rows)
+          for (int k = 0; k < width; ++k) o[k] = b[k];
+        }
+      } else {
+        for (int e = threadIdx.x; e < count; e += PB_THREADS) out[e] = s_bucket[e];
+      }
+      if (lane_id() == 0 && wave_in_range) *mask_word = now;
+    } else if (bucket_assign) {
       for (int e = threadIdx.x; e < count; e += PB_THREADS) out[e] = s_bucket[e];
     } else {
+      if (mask_word != nullptr && wave_in_range) {
+        const u64 now = ballot(has_rows);
+        if (lane_id() == 0 && now != 0ull) *mask_word |= now;
+      }
       // Adding a later view of the step.  Saturation leaves most Gaussians of a view without a single gradient row
       // (config 3: 98 % of the visible ones), and adding their zero rows would read and write the whole bucket for
       // nothing: where at most a quarter of the block's Gaussians have rows, each of those adds its own row (a lane per
@@ -693,7 +723,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
       o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign,
-      s.activations, s.opacities, F_out);
+      s.activations, s.opacities, F_out, o.bucket_row_mask);
   if (o.dL_dtau_sum)
     tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, nb, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
   else if (o.status_dev || o.sticky_error)

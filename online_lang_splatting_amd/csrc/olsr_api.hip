@@ -716,6 +716,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
     o.bucket_densify = bucket->densify;
     o.bucket_max_radii = bucket->max_radii;
     o.bucket_assign = bucket->assign;
+    o.bucket_row_mask = reinterpret_cast<unsigned long long*>(bucket->row_mask);
   }
   o.status_dev = status_dev;
   // (a caller that passes status_dev reads the report there; one that does not — the reference-shaped bindings — gets it

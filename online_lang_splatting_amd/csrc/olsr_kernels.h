@@ -131,6 +131,7 @@ struct GradOut {
   float* bucket_densify = nullptr;
   int32_t* bucket_max_radii = nullptr;
   int bucket_assign = 0;
+  unsigned long long* bucket_row_mask = nullptr;  // olsr_grad_bucket.row_mask (include/olsr.h)
   int32_t* status_dev = nullptr;  // olsr_backward's {L, overflow}: the last kernel raises [1] to 2 on a synchronisation error
   int32_t* sticky_error = nullptr;  // ... and sets this mapped host word (RowsMailbox::sticky), if there is one
 };

@@ -69,7 +69,11 @@ class GradientBucket:
             return False
         return dist.get_world_size(group) > 1 or cls.exchange_single_rank
 
-    def __init__(self, P, layout: GradLayout, device):
+    def __init__(self, P, layout: GradLayout, device, track_rows=False):
+        """track_rows: keep a bit per row "may be non-zero" (olsr_grad_bucket.row_mask, include/olsr.h) so that the backward's
+        overwrite of a step's first view stores only the rows that carry a gradient or carried one before, instead of all P
+        (98 % of them zeros at config 3).  The mask follows every write this class makes to `flat`; code that writes `flat`
+        or `sum_storage` DIRECTLY must call rows_unknown() afterwards (or leave track_rows off).  GPU buckets only."""
         self.layout = layout
         # one storage for everything that is SUM-reduced, so the step's exchange is a single large all-reduce
         # (+ one small MAX all-reduce): [P x width gradients | P x 2 densification statistics]
@@ -82,11 +86,29 @@ class GradientBucket:
         self.densify = self.sum_storage[off:off + 2 * P].view(P, 2)
         self.max_radii = torch.zeros(P, dtype=torch.int32, device=device)  # max-reducible
         self._sl = layout.slices()
+        # all ones = unknown: the first overwrite is dense (the storage is zero now, but "unknown" is the safe start)
+        self.row_mask = (torch.full(((P + 63) // 64,), -1, dtype=torch.int64, device=device)
+                         if (track_rows and torch.device(device).type == "cuda") else None)
+
+    def rows_unknown(self):
+        """`flat` was written by something other than the backward's fused accumulation: every row may be non-zero."""
+        if self.row_mask is not None:
+            self.row_mask.fill_(-1)
+
+    def rows_merge(self, other):
+        """`other`'s rows were added into this bucket's `flat`."""
+        if self.row_mask is not None:
+            if other.row_mask is not None:
+                self.row_mask.bitwise_or_(other.row_mask)
+            else:
+                self.row_mask.fill_(-1)
 
     def zero_(self):
         self.flat.zero_()
         self.densify.zero_()
         self.max_radii.zero_()
+        if self.row_mask is not None:
+            self.row_mask.zero_()
 
     def view(self, name):
         return self.flat[:, self._sl[name]]
@@ -106,6 +128,7 @@ class GradientBucket:
                 p(grads.get("dL_dlanguage")), p(grads["dL_dmeans2D"]), radii.data_ptr(), self.flat.data_ptr(),
                 self.densify.data_ptr(), self.max_radii.data_ptr(),
                 C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)))
+            self.rows_unknown()
             return
         if first:
             self.zero_()
@@ -132,6 +155,7 @@ class GradientBucket:
             return []
         works = [dist.all_reduce(self.sum_storage, op=dist.ReduceOp.SUM, group=group, async_op=async_op),
                  dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group, async_op=async_op)]
+        self.rows_unknown()  # (other ranks' rows arrive)
         return works if async_op else []
 
     # ---- owner-applies exchange: rank r owns the Gaussians [r0, r1) ---------------------
@@ -151,6 +175,7 @@ class GradientBucket:
         r0, r1 = self.owned_rows(P, rank, world)
         if not self._multi(group):
             return r0, r1
+        self.rows_unknown()
         if dist.get_backend(group) == "nccl":
             per = (P + world - 1) // world
             pad = per * world - P
@@ -202,6 +227,7 @@ class GradientBucket:
         if not self._multi(group):
             return dict(active_rows=int(nonzero.sum()), bytes_dense=dense_bytes, bytes_sparse=0)
         world = dist.get_world_size(group)
+        self.rows_unknown()
         nb = (P + 7) // 8
         bits = torch.zeros(nb * 8, dtype=torch.uint8, device=nonzero.device)
         bits[:P] = nonzero
@@ -261,6 +287,7 @@ class GradientBucket:
         idx = st["idx"][:cap]
         torch.index_select(self.flat_ext, 0, idx, out=packed)
         if multi:
+            self.rows_unknown()
             tail.copy_(self.densify.reshape(-1))
             dist.all_reduce(fsum, op=dist.ReduceOp.SUM, group=group)
             self.flat_ext.index_copy_(0, idx, packed)                      # (fill slots write zeros to the spare row)
@@ -484,7 +511,8 @@ class RasterWorkspace:
         bk = None
         if bucket is not None:
             bk = _abi.OlsrGradBucket(flat=bucket.flat.data_ptr(), densify=bucket.densify.data_ptr(),
-                                     max_radii=bucket.max_radii.data_ptr(), assign=1 if first else 0)
+                                     max_radii=bucket.max_radii.data_ptr(), assign=1 if first else 0,
+                                     row_mask=bucket.row_mask.data_ptr() if bucket.row_mask is not None else None)
             if bucket_only:
                 g = {k: (v if k == "dL_dtau_sum" else None) for k, v in g.items()}
         if pose_only:
@@ -528,13 +556,15 @@ class FrameLanes:
     binning kernels of one frame leave most of the 256 CUs idle — a second and third frame on other
     streams fill them (measured on config 3: 705 -> 913 -> 1005 frames/s for 1 / 2 / 3 lanes)."""
 
-    def __init__(self, n, P, W, H, F, M, capacity, device, **kw):
+    def __init__(self, n, P, W, H, F, M, capacity, device, track_rows=True, **kw):
+        """track_rows: the lanes' buckets keep a row mask (GradientBucket): the first view a lane renders in a step rewrites
+        only the gradient rows that changed."""
         self.device = torch.device(device)
         self.lanes = []
         for i in range(max(1, int(n))):
             ws = RasterWorkspace(P, W, H, F, M, capacity, device, **kw)
             stream = torch.cuda.current_stream(self.device) if i == 0 else torch.cuda.Stream(self.device)
-            self.lanes.append((ws, GradientBucket(P, GradLayout(M, F), device), stream))
+            self.lanes.append((ws, GradientBucket(P, GradLayout(M, F), device, track_rows=track_rows), stream))
         self._next = 0
 
     def __len__(self):
@@ -609,6 +639,11 @@ class FrameShardedStep:
         for i in range(L):
             self._need[i].zero_()
             self._ovf[i].zero_()
+        # (the tile-order hints of views seen for the first time are created here, on the caller's stream, BEFORE the lanes are
+        #  ordered behind it: created inside the loop below they were written on this stream and read on a lane's)
+        for v in mine:
+            if v not in self.view_hints:
+                self.view_hints[v] = torch.arange(self.ws.tile_order.numel(), dtype=torch.int32, device=self.ws.device)
         for i, (ws, bucket, stream) in enumerate(self.lanes):
             st = stream if stream is not None else main
             if st != main:
@@ -621,8 +656,6 @@ class FrameShardedStep:
             if first:
                 used.append(i)
             cam = cameras[v]
-            if v not in self.view_hints:
-                self.view_hints[v] = torch.arange(ws.tile_order.numel(), dtype=torch.int32, device=ws.device)
             with torch.cuda.stream(st):
                 ws.tile_order = self.view_hints[v]
                 ws.set_scene(sh_degree=sh_degree, viewmatrix=cam["viewmatrix"], projmatrix=cam["projmatrix"],
@@ -647,10 +680,12 @@ class FrameShardedStep:
         else:
             if used[0] != 0:  # (never: lane 0 takes this rank's first view)
                 total.sum_storage.copy_(self.lanes[used[0]][1].sum_storage)
+                total.rows_unknown()
                 total.max_radii.copy_(self.lanes[used[0]][1].max_radii)
             for i in used[1:]:
                 b = self.lanes[i][1]
                 total.sum_storage.add_(b.sum_storage)
+                total.rows_merge(b)
                 torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
         multi = GradientBucket._multi(self.group)
         if self.exchange == "reduce_scatter":

@@ -245,6 +245,7 @@ class MappingStep:
         for b in used[1:]:
             if multi:   # an exchange follows: it needs the total in one place
                 total.sum_storage.add_(b.sum_storage)
+                total.rows_merge(b)
             else:       # one process: only the small densification statistics are summed, Adam adds the gradient rows itself
                 total.densify.add_(b.densify)
             torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)

@@ -54,6 +54,8 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(OlsrScene) == 10 * 4 + 4 * 4 + 13 * 8 + 2 * 4 + 8
     assert OlsrScene.background.offset == 56 and OlsrScene.cam_pos.offset == 56 + 12 * 8
     assert OlsrScene.tile_depth_cut.offset == 56 + 13 * 8 + 8
+    from online_lang_splatting_amd._abi import OlsrGradBucket
+    assert ctypes.sizeof(OlsrGradBucket) == 3 * 8 + 2 * 4 + 8 and OlsrGradBucket.row_mask.offset == 32
 
 
 def test_c_abi_argument_errors(L):

@@ -1,0 +1,91 @@
+"""olsr_grad_bucket.row_mask (include/olsr.h): a bucket that tracks which gradient rows may be non-zero is, after every call,
+bit for bit the bucket that rewrites all P rows — over sequences of different views, overwrite / add mixes, frames without any
+gradient, and writes to the storage from outside (announced with rows_unknown())."""
+import pytest
+import torch
+
+from online_lang_splatting_amd.scene import default_camera, make_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cam(c, dev):
+    return dict(viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev),
+                projmatrix_raw=c.projection_matrix.to(dev), campos=c.camera_center.to(dev), tanfovx=c.tanfovx,
+                tanfovy=c.tanfovy)
+
+
+def _same(a, b):
+    assert torch.equal(a.flat, b.flat)
+    assert torch.equal(a.densify, b.densify) and torch.equal(a.max_radii, b.max_radii)
+
+
+@pytest.mark.parametrize("P,F", [(30000, 15), (777, 0), (64 * 130 + 1, 3)])
+def test_tracked_bucket_equals_the_dense_one(hip, P, F):
+    from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket, RasterWorkspace
+    dev = torch.device(DEV)
+    W, H = 320, 240
+    sc = make_scene(P, W, H, F, seed=11, max_sh_degree=1)
+    M = sc.shs.shape[1]
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=None if F == 0 else sc.language.to(dev))
+    cot = [None if t is None else t.to(dev) for t in sc.cotangents(2)]
+    ws = RasterWorkspace(P, W, H, F, M, 1_500_000, dev)
+    dense = GradientBucket(P, GradLayout(M, F), dev)
+    tracked = GradientBucket(P, GradLayout(M, F), dev, track_rows=True)
+    assert tracked.row_mask is not None and tracked.row_mask.numel() == (P + 63) // 64 and dense.row_mask is None
+    views = [(0.0, 0.0), (0.0, 0.0), (6.0, 0.2), (-15.0, -0.6), (0.5, 0.0), (0.0, 500.0), (0.0, 0.0)]  # (500 m aside: nothing in view)
+    firsts = [True, True, True, False, True, True, True]
+    active = []
+    for (yaw, tx), first in zip(views, firsts):
+        ws.set_scene(sh_degree=sc.sh_degree, **_cam(default_camera(W, H, yaw, tx), dev), **g)
+        ws.forward()
+        for b in (dense, tracked):
+            ws.backward(*cot, bucket=b, first=first, bucket_only=True)
+        _same(tracked, dense)
+        nz = (dense.flat != 0).any(dim=1)
+        active.append(int(nz.sum()))
+        # the mask covers every non-zero row
+        bits = ((tracked.row_mask.view(-1, 1) >> torch.arange(64, device=dev)) & 1).reshape(-1)[:P].bool()
+        assert bool((bits | ~nz).all())
+    assert active[0] > 0 and active[5] == 0 and active[2] != active[0]
+    # a write from outside, announced: the next overwrite clears it like the dense bucket's does
+    for b in (dense, tracked):
+        b.flat.fill_(7.0)
+    tracked.rows_unknown()
+    ws.set_scene(sh_degree=sc.sh_degree, **_cam(default_camera(W, H, 1.0, 0.0), dev), **g)
+    ws.forward()
+    for b in (dense, tracked):
+        ws.backward(*cot, bucket=b, first=True, bucket_only=True)
+    _same(tracked, dense)
+    assert float(tracked.flat.max()) < 7.0
+    # zero_() knows the rows are zero; accumulate() (the stand-alone kernel) does not track
+    tracked.zero_()
+    assert int(tracked.row_mask.abs().sum()) == 0
+
+
+def test_frame_lanes_track_rows_and_sum(hip):
+    """FrameShardedStep on lanes with tracked buckets (the default of FrameLanes) against untracked ones: same total."""
+    from online_lang_splatting_amd.frame_shard import FrameLanes, FrameShardedStep
+    dev = torch.device(DEV)
+    W, H, F, P = 320, 240, 15, 20000
+    sc = make_scene(P, W, H, F, seed=4)
+    M = sc.shs.shape[1]
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    cot = [t.to(dev) for t in sc.cotangents(3)]
+    totals = {}
+    for track in (False, True):
+        lanes = FrameLanes(2, P, W, H, F, M, 600_000, dev, track_rows=track)
+        step = FrameShardedStep(lanes)
+        outs = []
+        for views in ([(0.0, 0.0), (3.0, 0.1), (-4.0, -0.1)], [(10.0, 0.3), (11.0, 0.3)], [(0.0, 0.0)]):
+            cams = [_cam(default_camera(W, H, y, t), dev) for y, t in views]
+            total = step.run(g, cams, lambda v, out: cot, sh_degree=sc.sh_degree)
+            torch.cuda.synchronize()
+            outs.append((total.flat.clone(), total.densify.clone(), total.max_radii.clone()))
+        totals[track] = outs
+    for a, b in zip(totals[False], totals[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
