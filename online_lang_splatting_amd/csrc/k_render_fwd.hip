@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
   int tile_id = xcd_remap((int)blockIdx.x, ntiles);
   // (hint_slot: the synchronising entry keeps several orders per stream, one per view it has seen; word 0 names this frame's)
   if (order_hint != nullptr)
-    tile_id = (int)order_hint[(hint_slot != nullptr ? (size_t)hint_slot[0] * (size_t)ntiles : (size_t)0) + (size_t)tile_id];
+  {
+    // (a hint is caller memory: an entry that is no tile id — an uninitialised or stale buffer — must not become an address;
+    //  such a frame renders some tiles twice and others not at all, which the caller's bug earns, but it stays in bounds)
+    const u32 hinted = order_hint[(hint_slot != nullptr ? (size_t)hint_slot[0] * (size_t)ntiles : (size_t)0) + (size_t)tile_id];
+    if (hinted < (u32)ntiles) tile_id = (int)hinted;
+  }
   const int tid = threadIdx.x;
   const int w = tid >> 6;
   const int bx = tile_id % gx, by = tile_id / gx;

@@ -89,3 +89,24 @@ def test_frame_lanes_track_rows_and_sum(hip):
     for a, b in zip(totals[False], totals[True]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_a_garbage_tile_order_hint_stays_in_bounds(hip):
+    """The launch-order hint is caller memory.  Entries that are no tile ids are ignored (the block keeps its natural tile):
+    an all-garbage hint renders the exact frame, and the forward leaves a valid order behind."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    dev = torch.device(DEV)
+    W, H, F, P = 320, 240, 15, 20000
+    sc = make_scene(P, W, H, F, seed=9)
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    ws = RasterWorkspace(P, W, H, F, sc.shs.shape[1], 600_000, dev)
+    ws.set_scene(sh_degree=sc.sh_degree, **_cam(sc.camera, dev), **g)
+    ref = {k: v.clone() for k, v in ws.forward().items()}
+    n = ws.tile_order.numel()
+    for fill in (0x7FFFFFFF, -1, n, n + 12345):
+        ws.tile_order.fill_(fill)
+        out = ws.forward()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (fill, k)
+        assert sorted(ws.tile_order.tolist()) == list(range(n))   # the order this frame measured: a permutation again
