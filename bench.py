@@ -63,6 +63,9 @@ from online_lang_splatting_amd.scene import CONFIGS, arc_cameras, make_scene  # 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+JSON_OUT = sys.stdout  # main() re-points it at a private copy of the original stdout
+
+
 def algorithmic_bytes(P, R, N, C=3, F=15, M=1):
     """SURVEY.md §8(d) / DESIGN.md §6 byte model, per frame and per dominant stage."""
     per = {
@@ -625,7 +628,7 @@ def views_mode(a, sc, dev, rank, world, dist):
                        "views_in_flight_per_gpu": len(lanes),
                        "views_of_rank0": len(views_of_rank(a.views, 0, world)), "parallelism": f"frame-shard x{world}",
                        "exchange": a.exchange, "bucket_bytes": P * width * 4,
-                       "wire": step.wire}}), flush=True)
+                       "wire": step.wire}}), file=JSON_OUT, flush=True)
 
 
 def self_launch(n):
@@ -687,13 +690,29 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.self_launch):
         sys.exit(self_launch(a.gpus))
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to the process's stdout when its first
+    # communicator is created ("RCCL version : ...", measured in round 4 on a one-rank group), and native code may print
+    # more.  File descriptor 1 is pointed at stderr for the life of the process; the line goes to the saved descriptor.
+    global JSON_OUT
+    sys.stdout.flush()
+    JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = None
-    if world > 1:
+    # OLSR_BENCH_FORCE_EXCHANGE=1 with one rank: a group of ONE over RCCL, every collective of the chosen exchange issued
+    # (identities there) - what a one-GPU box can measure of the multi-GPU step: the exchange's local kernels and launches,
+    # everything but the wire (reported as n_gpus 1 with config.exchange set)
+    forced = world == 1 and os.environ.get("OLSR_BENCH_FORCE_EXCHANGE") == "1"
+    if forced and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    if world > 1 or forced:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one process per GPU over RCCL ("nccl" on ROCm).  OLSR_BENCH_BACKEND=gloo exists only to exercise the N > 1
@@ -707,6 +726,10 @@ def main():
             local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
+        if forced:
+            from online_lang_splatting_amd.frame_shard import GradientBucket
+            GradientBucket.exchange_single_rank = True
+            GradientBucket.capped_torch_formulation = os.environ.get("OLSR_BENCH_EXCHANGE_TORCH") == "1"
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -968,8 +991,9 @@ def main():
                        "binning": a.binning, "R_binned": Rr, "forward_accumulation": a.fwd_accum,
                        "views_per_step": world, "parallelism": f"frame-shard x{world}",
                        "rccl_ranks": world if backend == "nccl" else 0, "backend": backend,
-                       "exchange": a.exchange if world > 1 else None,
-                       "exchange_bytes_per_step": None if world == 1 else
+                       "exchange": a.exchange if dist is not None else None,
+                       "exchange_forced_single_rank": forced,
+                       "exchange_bytes_per_step": None if dist is None else
                        lanes.lanes[0][1].exchange_bytes(a.exchange, sparse_cap[0]),
                        "exchange_detail": exch_detail,
                        "frames_in_flight_per_gpu": len(lanes), "untimed_setup_steps": a.setup_steps,
@@ -1001,7 +1025,7 @@ def main():
             sl = lane0[1].layout.slices()
             out["cpu_baseline"] = cpu_baseline(sc, a.config, gpu=(lane0[0].out, lane0[1].flat.cpu(), sl),
                                                single_thread=(a.config in (1, 3)))
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=JSON_OUT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

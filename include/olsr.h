@@ -505,6 +505,36 @@ int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, int32_t assign,
                               const int32_t *radii, float *flat, float *densify,
                               int32_t *max_radii, void *hip_stream);
 
+/* ---- the capacity-bound sparse exchange of the bucket (SURVEY.md section 8, rows e and f2) ---------------------------
+ * Saturation leaves ~2 % of a view's Gaussians with a gradient row (config 3: 9 471 of 500 000), so a frame-sharded
+ * step exchanges the UNION of the ranks' non-zero rows instead of the whole bucket — without a host synchronisation,
+ * so that several frames stay in flight.  The caller issues two collectives (RCCL through torch.distributed, or any
+ * other all-reduce) and these three calls around them, all on one stream:
+ *   olsr_sparse_exchange_mask    imax[0..P) = 1 where row g of `flat` holds a non-zero element (only rows whose bit
+ *                                of row_mask is set are looked at; row_mask may be NULL = look at every row),
+ *                                imax[P..2P) = max_radii
+ *   -- all-reduce MAX over imax (int32[2P]): the union of the rows, and the reduced radii --
+ *   olsr_sparse_exchange_pack    max_radii <- imax[P..2P); row_mask (if given) <- the union; the union's rows, in
+ *                                ascending row order, are copied into fsum[slot][width] for slot < capacity, unused
+ *                                slots are zero-filled, idx[slot] = the row (P for an unused slot);
+ *                                fsum[capacity * width ..) <- densify[P][2]; status_dev = {rows in the union,
+ *                                1 if they did not fit};  scratch: olsr_sparse_exchange_scratch_ints(P) int32
+ *   -- all-reduce SUM over fsum (fp32[capacity * width + 2P]) --
+ *   olsr_sparse_exchange_unpack  flat[idx[slot]] <- fsum[slot], densify <- the tail
+ * The bucket then holds what a dense all-reduce of {flat, densify} (SUM) and max_radii (MAX) would have left, bit for
+ * bit, provided the union fitted; on overflow only the first `capacity` rows of the union were exchanged and the
+ * caller must repeat the step with a larger capacity or densely (the contract of an instance overflow).  `width` is
+ * the bucket's row width 11 + 3M + F.  No reference counterpart: the reference is single-GPU and autograd's `.grad`
+ * accumulates the views of BackEnd.map (utils/slam_backend.py:510-670) in one process. */
+int olsr_sparse_exchange_mask(int32_t P, int32_t width, const float *flat, const uint64_t *row_mask,
+                              const int32_t *max_radii, int32_t *imax, void *hip_stream);
+int64_t olsr_sparse_exchange_scratch_ints(int32_t P);
+int olsr_sparse_exchange_pack(int32_t P, int32_t width, int32_t capacity, const float *flat, const int32_t *imax,
+                              int32_t *max_radii, uint64_t *row_mask, const float *densify, int32_t *idx,
+                              float *fsum, int32_t *scratch, int32_t *status_dev, void *hip_stream);
+int olsr_sparse_exchange_unpack(int32_t P, int32_t width, int32_t capacity, const int32_t *idx, const float *fsum,
+                                float *flat, float *densify, void *hip_stream);
+
 /* Near-plane visibility test.  Replaces markVisible / checkFrustum
  * (DGR/rasterize_points.cu:457-476; CR/rasterizer_impl.cu:54-66,141-153).
  * present[P] is one byte per Gaussian (bool). */

@@ -6,6 +6,8 @@
 // with ~10 separate elementwise PyTorch kernels; here it is one pass: every gradient array is
 // read once, the flat row [3 xyz | 3M sh | 1 opacity | 3 scale | 4 rot | F lang] is read-modify-
 // written once (or just written, for the first view of a step: `assign`).
+#include <algorithm>
+
 #include "olsr_device.h"
 #include "olsr_kernels.h"
 
@@ -73,6 +75,175 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
   else
     accumulate_kernel<false><<<nb, 256, 0, st>>>(P, M, F, width, dmeans3D, dsh, dopacity, dscales, drot, dlang,
                                                  dmeans2D, radii, flat, densify, max_radii);
+}
+
+
+// ---- the capacity-bound sparse exchange of the bucket (frame_shard.py: sparse_all_reduce_capped) ----
+// Saturation leaves ~2 % of a view's Gaussians with a gradient row, so a frame-sharded step exchanges the UNION of the
+// ranks' non-zero rows instead of the bucket: collective 1 (MAX over int32 [row flags | max_radii]) makes the union known
+// to every rank, collective 2 (SUM over fp32 [capacity packed rows | densification statistics]) carries the rows.  The
+// kernels below are the local work around those two collectives — four small launches per step where round 4's first
+// form spent ~15 PyTorch kernels (a scan of the whole 62 MB bucket among them).  No reference counterpart (the reference
+// is single-GPU: autograd's .grad over the views of BackEnd.map, utils/slam_backend.py:510-670).
+constexpr int EX_ROWS = 1024;  // rows per block of the count / pack kernels: 256 threads x 4, each wave on 64 consecutive rows
+
+// imax[g] = 1 when row g of `flat` holds a non-zero element, imax[P + g] = max_radii[g].  With a row mask (bit g: the row
+// MAY be non-zero) only flagged rows are looked at; a row's first element usually decides.
+__global__ __launch_bounds__(256) void exchange_mask_kernel(int P, int width, const float* __restrict__ flat,
+                                                            const unsigned long long* __restrict__ row_mask,
+                                                            const int32_t* __restrict__ max_radii, int32_t* __restrict__ imax) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= P) return;
+  int nz = 0;
+  if (row_mask == nullptr || ((row_mask[g >> 6] >> (g & 63)) & 1ull)) {
+    const float* r = flat + (size_t)g * width;
+    for (int c = 0; c < width; ++c)
+      if (r[c] != 0.0f) {  // (NaN counts as non-zero, -0 as zero: what `flat != 0` says)
+        nz = 1;
+        break;
+      }
+  }
+  imax[g] = nz;
+  imax[(size_t)P + g] = max_radii[g];
+}
+
+// after collective 1: counts[b] = rows of the union in block b's 1024 rows; max_radii <- the reduced radii; the row mask
+// becomes the union (exactly the rows that can be non-zero once the packed rows are scattered back)
+__global__ __launch_bounds__(256) void exchange_count_kernel(int P, const int32_t* __restrict__ imax,
+                                                             int32_t* __restrict__ max_radii,
+                                                             unsigned long long* __restrict__ row_mask,
+                                                             int32_t* __restrict__ counts) {
+  __shared__ int s_cnt[4];
+  const int tid = threadIdx.x, w = tid >> 6;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = blockIdx.x * EX_ROWS + k * 256 + tid;
+    const bool on = g < P && imax[g] != 0;
+    if (g < P) max_radii[g] = imax[(size_t)P + g];
+    const u64 m = ballot(on);
+    c += __popcll(m);
+    if ((tid & 63) == 0 && row_mask != nullptr && g < P) row_mask[g >> 6] = m;  // (lane 0: g is a multiple of 64)
+  }
+  if ((tid & 63) == 0) s_cnt[w] = c;
+  __syncthreads();
+  if (tid == 0) counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// slot of every union row = its rank among the union's rows (ascending row index); rows with a slot < cap are copied
+// into packed[slot]; the slots nobody took are zero-filled and point at no row (idx = P); tail <- densify;
+// status = {rows in the union, overflow}
+__global__ __launch_bounds__(256) void exchange_pack_kernel(int P, int width, int cap, int nb, const float* __restrict__ flat,
+                                                            const int32_t* __restrict__ imax,
+                                                            const int32_t* __restrict__ counts,
+                                                            const float* __restrict__ densify, int32_t* __restrict__ idx,
+                                                            float* __restrict__ packed, float* __restrict__ tail,
+                                                            int32_t* __restrict__ status) {
+  __shared__ int s_red[2][4];
+  __shared__ int s_pop[16];
+  __shared__ int s_g[EX_ROWS], s_slot[EX_ROWS];
+  __shared__ int s_nsel;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, b = blockIdx.x;
+  // rows of the union in front of this block, and in total
+  int before = 0, total = 0;
+  for (int i = tid; i < nb; i += 256) {
+    const int c = counts[i];
+    total += c;
+    before += (i < b) ? c : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o);
+    total += __shfl_xor(total, o);
+  }
+  if (lane == 0) {
+    s_red[0][w] = before;
+    s_red[1][w] = total;
+  }
+  if (tid == 0) s_nsel = 0;
+  u64 m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = b * EX_ROWS + k * 256 + tid;
+    m[k] = ballot(g < P && imax[g] != 0);
+    if (lane == 0) s_pop[k * 4 + w] = __popcll(m[k]);
+  }
+  __syncthreads();
+  before = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+  total = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int pre = before;
+    for (int i = 0; i < k * 4 + w; ++i) pre += s_pop[i];
+    if ((m[k] >> lane) & 1ull) {
+      const int slot = pre + __popcll(m[k] & ((1ull << lane) - 1ull));
+      if (slot < cap) {
+        const int g = b * EX_ROWS + k * 256 + tid;
+        idx[slot] = g;
+        const int i = atomicAdd(&s_nsel, 1);
+        s_g[i] = g;
+        s_slot[i] = slot;
+      }
+    }
+  }
+  __syncthreads();
+  const int nsel = s_nsel;
+  for (int i = w; i < nsel; i += 4) {  // a wave per selected row
+    const float* src = flat + (size_t)s_g[i] * width;
+    float* dst = packed + (size_t)s_slot[i] * width;
+    for (int c = lane; c < width; c += 64) dst[c] = src[c];
+  }
+  // the slots behind the union: zeros, so that the SUM leaves zeros and the scatter skips them
+  const int used = min(total, cap);
+  const size_t gtid = (size_t)b * 256 + tid, gsz = (size_t)nb * 256;
+  for (size_t s = (size_t)used + gtid; s < (size_t)cap; s += gsz) idx[s] = P;
+  for (size_t e = (size_t)used * width + gtid; e < (size_t)cap * width; e += gsz) packed[e] = 0.0f;
+  for (size_t e = gtid; e < 2 * (size_t)P; e += gsz) tail[e] = densify[e];
+  if (b == 0 && tid == 0) {
+    status[0] = total;
+    status[1] = total > cap ? 1 : 0;
+  }
+}
+
+// after collective 2: the summed rows go back to their rows, the summed statistics to `densify`
+__global__ __launch_bounds__(256) void exchange_unpack_kernel(int P, int width, int cap, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ packed, const float* __restrict__ tail,
+                                                              float* __restrict__ flat, float* __restrict__ densify) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * 256) >> 6;
+  for (size_t s = wave; s < (size_t)cap; s += nwaves) {
+    const int g = idx[s];
+    if ((unsigned)g >= (unsigned)P) continue;
+    const float* src = packed + s * width;
+    float* dst = flat + (size_t)g * width;
+    for (int c = lane; c < width; c += 64) dst[c] = src[c];
+  }
+  const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+  for (size_t e = gtid; e < 2 * (size_t)P; e += gsz) densify[e] = tail[e];
+}
+
+void launch_exchange_mask(int P, int width, const float* flat, const unsigned long long* row_mask, const int32_t* max_radii,
+                          int32_t* imax, hipStream_t st) {
+  if (P <= 0) return;
+  exchange_mask_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(P, width, flat, row_mask, max_radii, imax);
+}
+
+void launch_exchange_pack(int P, int width, int cap, const float* flat, const int32_t* imax, int32_t* max_radii,
+                          unsigned long long* row_mask, const float* densify, int32_t* idx, float* fsum, int32_t* counts,
+                          int32_t* status, hipStream_t st) {
+  if (P <= 0) return;
+  const int nb = (P + EX_ROWS - 1) / EX_ROWS;
+  exchange_count_kernel<<<(unsigned)nb, 256, 0, st>>>(P, imax, max_radii, row_mask, counts);
+  exchange_pack_kernel<<<(unsigned)nb, 256, 0, st>>>(P, width, cap, nb, flat, imax, counts, densify, idx, fsum,
+                                                     fsum + (size_t)cap * width, status);
+}
+
+void launch_exchange_unpack(int P, int width, int cap, const int32_t* idx, const float* fsum, float* flat, float* densify,
+                            hipStream_t st) {
+  if (P <= 0) return;
+  const size_t work = std::max((size_t)cap * 64, (size_t)2 * P);
+  const unsigned nb = (unsigned)std::min<size_t>((work + 255) / 256, 4096);
+  exchange_unpack_kernel<<<nb, 256, 0, st>>>(P, width, cap, idx, fsum, fsum + (size_t)cap * width, flat, densify);
 }
 
 }  // namespace olsr

@@ -872,6 +872,45 @@ int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, int32_t assign, c
   return OLSR_OK;
 }
 
+int olsr_sparse_exchange_mask(int32_t P, int32_t width, const float* flat, const uint64_t* row_mask, const int32_t* max_radii,
+                              int32_t* imax, void* hip_stream) {
+  if (P < 0 || width <= 0) return fail(OLSR_ERR_ARG, "P must be >= 0, width > 0");
+  if (P == 0) return OLSR_OK;
+  if (!flat || !max_radii || !imax) return fail(OLSR_ERR_ARG, "flat, max_radii and imax must not be NULL");
+  launch_exchange_mask(P, width, flat, reinterpret_cast<const unsigned long long*>(row_mask), max_radii, imax,
+                       (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("sparse exchange (mask) launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
+int64_t olsr_sparse_exchange_scratch_ints(int32_t P) { return P <= 0 ? 0 : ((int64_t)P + 1023) / 1024; }
+
+int olsr_sparse_exchange_pack(int32_t P, int32_t width, int32_t capacity, const float* flat, const int32_t* imax,
+                              int32_t* max_radii, uint64_t* row_mask, const float* densify, int32_t* idx, float* fsum,
+                              int32_t* scratch, int32_t* status_dev, void* hip_stream) {
+  if (P < 0 || width <= 0 || capacity <= 0) return fail(OLSR_ERR_ARG, "P must be >= 0, width and capacity > 0");
+  if (P == 0) return OLSR_OK;
+  if (!flat || !imax || !max_radii || !densify || !idx || !fsum || !scratch || !status_dev)
+    return fail(OLSR_ERR_ARG, "sparse exchange (pack): only row_mask may be NULL");
+  launch_exchange_pack(P, width, capacity, flat, imax, max_radii, reinterpret_cast<unsigned long long*>(row_mask), densify, idx,
+                       fsum, scratch, status_dev, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("sparse exchange (pack) launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
+int olsr_sparse_exchange_unpack(int32_t P, int32_t width, int32_t capacity, const int32_t* idx, const float* fsum, float* flat,
+                                float* densify, void* hip_stream) {
+  if (P < 0 || width <= 0 || capacity <= 0) return fail(OLSR_ERR_ARG, "P must be >= 0, width and capacity > 0");
+  if (P == 0) return OLSR_OK;
+  if (!idx || !fsum || !flat || !densify) return fail(OLSR_ERR_ARG, "sparse exchange (unpack): pointers must not be NULL");
+  launch_exchange_unpack(P, width, capacity, idx, fsum, flat, densify, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("sparse exchange (unpack) launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
 const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t F, const char* name) {
   size_t bytes;
   const GeometryState g =

@@ -142,6 +142,13 @@ void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims
 int tau_partial_blocks(int P);
 
 // k_accumulate.hip
+void launch_exchange_mask(int P, int width, const float* flat, const unsigned long long* row_mask, const int32_t* max_radii,
+                          int32_t* imax, hipStream_t st);
+void launch_exchange_pack(int P, int width, int cap, const float* flat, const int32_t* imax, int32_t* max_radii,
+                          unsigned long long* row_mask, const float* densify, int32_t* idx, float* fsum, int32_t* counts,
+                          int32_t* status, hipStream_t st);
+void launch_exchange_unpack(int P, int width, int cap, const int32_t* idx, const float* fsum, float* flat, float* densify,
+                            hipStream_t st);
 void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, const float* dsh,
                        const float* dopacity, const float* dscales, const float* drot, const float* dlang,
                        const float* dmeans2D, const int32_t* radii, float* flat, float* densify, int32_t* max_radii,

@@ -61,6 +61,9 @@ class GradientBucket:
     # True: issue the collectives also in a group of ONE rank (they are identities there).  Only tests set it: it lets a
     # one-GPU box execute every RCCL call of the exchanges (dtype / op / shape support of the "nccl" backend).
     exchange_single_rank = False
+    # True: sparse_all_reduce_capped runs its torch formulation (the CPU specification) on GPU buckets too - the A/B leg of
+    # the exchange-overhead measurement and of tests/test_gpu_sparse_exchange.py, never the default
+    capped_torch_formulation = False
 
     @classmethod
     def _multi(cls, group=None):
@@ -252,10 +255,13 @@ class GradientBucket:
         """The sparse exchange WITHOUT a host synchronisation, for callers that keep several frames in flight
         (bench.py's weak-scaling mode): the packed buffer has a fixed `capacity` of rows instead of the exact count, and the
         step is TWO collectives (each costs a launch and a latency on every rank, whatever its size):
-        1. all-reduce (MAX) of one int32 buffer [byte mask of this rank's non-zero gradient rows | max_radii] (8 P bytes) —
+        1. all-reduce (MAX) of one int32 buffer [flags of this rank's non-zero gradient rows | max_radii] (8 P bytes) —
            afterwards every rank holds the same union of rows, and max_radii is done;
         2. all-reduce (SUM) of one fp32 buffer [the union's rows, packed in ascending order into capacity x width (unused
-           slots point at the spare zero row P) | the two densification statistics], scattered back afterwards.
+           slots are zero and belong to no row) | the two densification statistics], scattered back afterwards.
+        The local work around the collectives is four launches of the library (olsr_sparse_exchange_mask / _pack / _unpack,
+        include/olsr.h); with track_rows the backward's row mask tells the first of them which rows to look at and the second
+        leaves the union in it, so the mask stays exact across the exchange (a dense collective has to mark it unknown).
         Everything is enqueued on the current stream.  Returns a device int32[2] {rows in the union, overflow flag}: with more
         than `capacity` rows in the union only the first `capacity` of them were exchanged - the step's gradients are then
         incomplete and the caller must repeat it with a larger capacity (or densely), the same contract as an instance
@@ -264,6 +270,35 @@ class GradientBucket:
         P, width = self.flat.shape
         cap = int(capacity)
         dev = self.flat.device
+        multi = self._multi(group)
+        if self.flat.is_cuda and not self.capped_torch_formulation:
+            # the product path: four launches of the library around the two collectives (include/olsr.h, "the capacity-bound
+            # sparse exchange"); the row mask the backward keeps says which rows to look at, and comes back as the union
+            st = getattr(self, "_capped", None)
+            if st is None or st["cap"] != cap:
+                st = dict(cap=cap, idx=torch.empty(cap, dtype=torch.int32, device=dev),
+                          fsum=torch.empty(cap * width + 2 * P, dtype=torch.float32, device=dev),
+                          imax=torch.empty(2 * P, dtype=torch.int32, device=dev),
+                          scratch=torch.empty(max(1, int(lib().olsr_sparse_exchange_scratch_ints(P))), dtype=torch.int32,
+                                              device=dev),
+                          status=torch.zeros(2, dtype=torch.int32, device=dev))
+                self._capped = st
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            mask_p = self.row_mask.data_ptr() if self.row_mask is not None else None
+            check(lib().olsr_sparse_exchange_mask(P, width, self.flat.data_ptr(), mask_p, self.max_radii.data_ptr(),
+                                                  st["imax"].data_ptr(), stream))
+            if multi:
+                dist.all_reduce(st["imax"], op=dist.ReduceOp.MAX, group=group)  # the union, identical on every rank; the radii
+            check(lib().olsr_sparse_exchange_pack(P, width, cap, self.flat.data_ptr(), st["imax"].data_ptr(),
+                                                  self.max_radii.data_ptr(), mask_p, self.densify.data_ptr(),
+                                                  st["idx"].data_ptr(), st["fsum"].data_ptr(), st["scratch"].data_ptr(),
+                                                  st["status"].data_ptr(), stream))
+            if multi:
+                dist.all_reduce(st["fsum"], op=dist.ReduceOp.SUM, group=group)
+                check(lib().olsr_sparse_exchange_unpack(P, width, cap, st["idx"].data_ptr(), st["fsum"].data_ptr(),
+                                                        self.flat.data_ptr(), self.densify.data_ptr(), stream))
+            return st["status"]
+        # CPU tensors (the gloo tests): the same exchange in torch operations - the specification of the kernels above
         st = getattr(self, "_capped", None)
         if st is None or st["cap"] != cap:
             st = dict(cap=cap, idx=torch.empty(cap + 1, dtype=torch.int64, device=dev),
@@ -272,7 +307,6 @@ class GradientBucket:
                       arange=torch.arange(P, dtype=torch.int64, device=dev),
                       status=torch.zeros(2, dtype=torch.int32, device=dev))
             self._capped = st
-        multi = self._multi(group)
         imax, fsum = st["imax"], st["fsum"]
         mask, packed, tail = imax[:P], fsum[: cap * width].view(cap, width), fsum[cap * width:]
         mask.copy_((self.flat != 0).any(dim=1))
