@@ -58,7 +58,7 @@ sys.path.insert(0, ROOT)
 
 from online_lang_splatting_amd import _abi, _lib  # noqa: E402
 from online_lang_splatting_amd.frame_shard import FrameLanes  # noqa: E402
-from online_lang_splatting_amd.scene import CONFIGS, arc_cameras, make_scene  # noqa: E402
+from online_lang_splatting_amd.scene import CONFIGS, arc_cameras, make_scene, shard_cameras  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -682,6 +682,9 @@ def main():
     ap.add_argument("--self-launch", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (N > 1 does so by itself when "
                          "WORLD_SIZE is not set)")
+    ap.add_argument("--rank-view", default="", help="K,N[,arc]: with one rank, render what rank K of an N-GPU run renders instead of "
+                                                    "the identity pose (the per-rank cost of a weak-scaling point); ',arc': "
+                                                    "pose K of the N-pose arc of the mapping mode")
     ap.add_argument("--repeats", type=int, default=5,
                     help="how many times the contract's K-step region is run; the value is the median run (all in value_runs)")
     ap.add_argument("--setup-steps", type=int, default=40, help="untimed frames before the W warm-up steps (steady state)")
@@ -745,7 +748,12 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    cams = arc_cameras(W, H, n=max(world, 1))  # n == 1 -> the identity pose of config 3
+    # weak scaling = the same work per GPU whatever N: rank r renders pose r of N poses 3 cm apart without rotation, whose
+    # cost equals the identity pose's (n == 1 -> the identity pose of config 3); the arc's rotated poses cost up to 12 % more
+    cams = shard_cameras(W, H, n=max(world, 1))
+    if a.rank_view and world == 1:
+        k_, n_ = (int(x) for x in a.rank_view.split(",")[:2])
+        cams = [(arc_cameras if a.rank_view.endswith("arc") else shard_cameras)(W, H, n=n_)[k_]]
     g_dev, _ = device_inputs(sc, cams[0], dev)
     cam_dev = [device_inputs(sc, c, dev)[1] for c in cams]
     dc, dl, dd = [None if t is None else t.to(dev) for t in sc.cotangents(a.config)]
