@@ -928,6 +928,47 @@ def main():
             stt = torch.stack([lane_[1]._capped["status"] for lane_ in lanes.lanes if getattr(lane_[1], "_capped", None)])
             exch_detail.update({"packed_capacity_rows": sparse_cap[0], "rows_in_union_last_step": int(stt[:, 0].max()),
                                 "overflow": bool(int(stt[:, 1].max()))})
+        # The exchange, checked where it ran (outside every timed region): one more frame of this rank's view into lane 0's
+        # bucket, the chosen exchange on it, against the dense all-reduce (SUM of gradients and statistics, MAX of the radii)
+        # of a copy of the same partial sums.  Two statements come back in the line: every rank holds the SAME bucket
+        # afterwards (checksums of the bits, up to the sign of zeros), and it is the dense result (bit for bit with two ranks; beyond two the
+        # collectives may associate the ranks' terms differently for buffers of different size, so the largest difference
+        # relative to the tensor's largest element is reported and held to 1e-5).
+        ws_, bucket_, stream_ = lanes.lanes[0]
+        with torch.cuda.stream(stream_):
+            for w_ in pending.pop(id(bucket_), ()):
+                w_.wait()
+            ws_.set_scene(sh_degree=sc.sh_degree, **c0, **g_dev)
+            ws_.forward()
+            ws_.backward(dc, dl, dd, bucket=bucket_, first=True, bucket_only=True)
+            ref_sum, ref_rad = bucket_.sum_storage.clone(), bucket_.max_radii.clone()
+            if world > 1:
+                dist.all_reduce(ref_sum, op=dist.ReduceOp.SUM)
+                dist.all_reduce(ref_rad, op=dist.ReduceOp.MAX)
+            exchange(bucket_)
+            for w_ in pending.pop(id(bucket_), ()):
+                w_.wait()
+            got = bucket_.sum_storage
+            scale_ = ref_sum.abs().max().clamp_min(1e-30)
+            diff = ((got - ref_sum).abs().max() / scale_).to(torch.float64).reshape(1)
+            same_rad = (bucket_.max_radii == ref_rad).all().to(torch.float64).reshape(1)
+            # identical on every rank: compare the bits through an order-independent integer checksum
+            # (-0.0 + 0.0 = +0.0: a row outside the union keeps this rank's own zeros, whose sign the dense sum would erase)
+            csum = (got + 0.0).view(torch.int32).to(torch.int64).sum().reshape(1)
+            cmax, cmin = csum.clone(), csum.clone()
+            if world > 1:
+                dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+                dist.all_reduce(same_rad, op=dist.ReduceOp.MIN)
+                dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize(dev)
+        exch_detail["check"] = {"what": "one frame per rank after the timed regions: the chosen exchange against the dense "
+                                        "all-reduce of the same partial sums",
+                                "max_abs_diff_over_max_abs": float(diff.item()),
+                                "equals_dense": bool(float(diff.item()) <= (0.0 if world <= 2 else 1e-5)),
+                                "radii_equal": bool(same_rad.item() == 1.0),
+                                "identical_on_every_rank": bool(int(cmax.item()) == int(cmin.item())),
+                                "nonzero_gradient_rows_after": int((bucket_.flat != 0).any(dim=1).sum().item())}
     Rr, overflow = ws0.rendered()
     # the reference's num_rendered (bounding-square instances) of this view: the R of the byte model
     R_ref = int(_C.state_field("geometry", ws0.geom, "counters", P=P, F=F, dtype=torch.int32, count=8)[3])

@@ -143,6 +143,9 @@ def test_gpus_flag_launches_its_own_ranks():
         assert d["n_gpus"] == 2 and c["views_per_step"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
         assert c["backend"] == "gloo" and c["rccl_ranks"] == 0 and c["exchange"] == exchange
         assert c["exchange_bytes_per_step"] > 0 and c["exchange_detail"]["rows_nonzero_per_view_max_over_ranks"] > 0
+        chk = c["exchange_detail"]["check"]  # the exchange against the dense all-reduce of the same partial sums, where it ran
+        assert chk["equals_dense"] and chk["max_abs_diff_over_max_abs"] == 0.0 and chk["radii_equal"]
+        assert chk["identical_on_every_rank"] and chk["nonzero_gradient_rows_after"] > 0
         if exchange == "sparse":
             det = c["exchange_detail"]
             assert not det["overflow"] and 0 < det["rows_in_union_last_step"] <= det["packed_capacity_rows"]
@@ -161,3 +164,23 @@ def test_self_launched_single_rank_matches_the_plain_line():
     d = _last_json(p.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["value"] > 0
     assert d["config"]["exchange"] is None and d["config"]["rccl_ranks"] == 0 and d["config"]["backend"] is None
+
+
+def test_forced_single_rank_exchange_over_rccl_and_a_clean_stdout():
+    """OLSR_BENCH_FORCE_EXCHANGE=1: a group of ONE rank over RCCL with every collective of the exchange issued - what a one-GPU
+    box can run of the multi-GPU step.  RCCL prints a version banner to the process's stdout when its first communicator is
+    created; the line must stay the ONLY thing on stdout (the driver parses it), whatever native code prints."""
+    for exchange in ("sparse", "all_reduce", "reduce_scatter"):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OLSR_BENCH_BACKEND")}
+        p = subprocess.run([sys.executable, "bench.py", "--config", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                            "--no-extra-legs", "--isolated-steps", "0", "--exchange", exchange], cwd=ROOT,
+                           env=dict(env, OLSR_BENCH_FORCE_EXCHANGE="1"), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (exchange, p.stdout[-1500:], p.stderr[-1500:])
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        c = d["config"]
+        assert d["n_gpus"] == 1 and c["exchange"] == exchange and c["exchange_forced_single_rank"] and c["backend"] == "nccl"
+        chk = c["exchange_detail"]["check"]
+        assert chk["equals_dense"] and chk["radii_equal"] and chk["identical_on_every_rank"]
+        assert chk["nonzero_gradient_rows_after"] > 0
