@@ -882,6 +882,12 @@ def main():
         dist.all_reduce(nz, op=dist.ReduceOp.MAX)
         active_rows = int(nz.item())
         sparse_cap[0] = min(P, int(1.25 * world * active_rows) + 4096)
+        if a.exchange == "sparse":
+            # ... and the union itself: neighbouring views share most of their front layer (the overlapping keyframes of a
+            # mapping window do too), so the union is far smaller than world x rows.  One exchange at the safe capacity,
+            # its row count read back (set-up: the one host synchronisation of this path), 25 % head-room on that.
+            union_rows = int(bucket_.sparse_all_reduce_capped(sparse_cap[0])[0].item())  # identical on every rank
+            sparse_cap[0] = min(P, int(1.25 * union_rows) + 4096)
     for _ in range(a.setup_steps):
         one_step(lanes.next_lane())
     for lane_ in lanes.lanes:

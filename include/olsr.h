@@ -23,7 +23,7 @@
  * Contents: the rasterizer itself (olsr_forward, olsr_forward_async, olsr_backward, olsr_mark_visible and
  * their size / introspection / profiling helpers — SURVEY.md section 8 rows a-e), then the callers and
  * data either side of it (rows f1-f3): olsr_mapping_loss, olsr_tracking_loss, olsr_pose_step,
- * olsr_accumulate_gradients, olsr_adam_step, olsr_knn_mean_dist2.
+ * olsr_accumulate_gradients, olsr_sparse_exchange_mask / _pack / _unpack, olsr_adam_step, olsr_knn_mean_dist2.
  */
 #ifndef OLSR_H_INCLUDED
 #define OLSR_H_INCLUDED
