@@ -518,7 +518,10 @@ int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, int32_t assign,
  *                                ascending row order, are copied into fsum[slot][width] for slot < capacity, unused
  *                                slots are zero-filled, idx[slot] = the row (P for an unused slot);
  *                                fsum[capacity * width ..) <- densify[P][2]; status_dev = {rows in the union,
- *                                1 if they did not fit};  scratch: olsr_sparse_exchange_scratch_ints(P) int32
+ *                                1 if they did not fit};  scratch: olsr_sparse_exchange_scratch_ints(P) int32.
+ *                                With idx == fsum == NULL nothing is packed: the call only counts (status_dev, max_radii
+ *                                and row_mask as above) — for a caller that reads the count back and sizes the packed
+ *                                buffer exactly (FrameShardedStep's "sparse" exchange, one host synchronisation per step)
  *   -- all-reduce SUM over fsum (fp32[capacity * width + 2P]) --
  *   olsr_sparse_exchange_unpack  flat[idx[slot]] <- fsum[slot], densify <- the tail
  * The bucket then holds what a dense all-reduce of {flat, densify} (SUM) and max_radii (MAX) would have left, bit for

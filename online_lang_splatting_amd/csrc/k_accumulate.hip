@@ -228,12 +228,33 @@ void launch_exchange_mask(int P, int width, const float* flat, const unsigned lo
   exchange_mask_kernel<<<(unsigned)((P + 255) / 256), 256, 0, st>>>(P, width, flat, row_mask, max_radii, imax);
 }
 
+// a count without a pack (idx == NULL): status = {rows in the union, whether they exceed cap}
+__global__ __launch_bounds__(256) void exchange_total_kernel(int nb, int cap, const int32_t* __restrict__ counts,
+                                                             int32_t* __restrict__ status) {
+  __shared__ int s_t[4];
+  int total = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) total += counts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+  if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    total = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+    status[0] = total;
+    status[1] = total > cap ? 1 : 0;
+  }
+}
+
 void launch_exchange_pack(int P, int width, int cap, const float* flat, const int32_t* imax, int32_t* max_radii,
                           unsigned long long* row_mask, const float* densify, int32_t* idx, float* fsum, int32_t* counts,
                           int32_t* status, hipStream_t st) {
   if (P <= 0) return;
   const int nb = (P + EX_ROWS - 1) / EX_ROWS;
   exchange_count_kernel<<<(unsigned)nb, 256, 0, st>>>(P, imax, max_radii, row_mask, counts);
+  if (idx == nullptr) {
+    exchange_total_kernel<<<1, 256, 0, st>>>(nb, cap, counts, status);
+    return;
+  }
   exchange_pack_kernel<<<(unsigned)nb, 256, 0, st>>>(P, width, cap, nb, flat, imax, counts, densify, idx, fsum,
                                                      fsum + (size_t)cap * width, status);
 }

@@ -891,8 +891,8 @@ int olsr_sparse_exchange_pack(int32_t P, int32_t width, int32_t capacity, const 
                               int32_t* scratch, int32_t* status_dev, void* hip_stream) {
   if (P < 0 || width <= 0 || capacity <= 0) return fail(OLSR_ERR_ARG, "P must be >= 0, width and capacity > 0");
   if (P == 0) return OLSR_OK;
-  if (!flat || !imax || !max_radii || !densify || !idx || !fsum || !scratch || !status_dev)
-    return fail(OLSR_ERR_ARG, "sparse exchange (pack): only row_mask may be NULL");
+  if (!flat || !imax || !max_radii || !densify || !scratch || !status_dev || ((idx == nullptr) != (fsum == nullptr)))
+    return fail(OLSR_ERR_ARG, "sparse exchange (pack): only row_mask may be NULL, or idx and fsum together (count only)");
   launch_exchange_pack(P, width, capacity, flat, imax, max_radii, reinterpret_cast<unsigned long long*>(row_mask), densify, idx,
                        fsum, scratch, status_dev, (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();

@@ -219,13 +219,47 @@ class GradientBucket:
         """Exchange only the gradient rows that are non-zero on at least one rank: every other row is zero everywhere, so
         its sum is the zero it already holds.  Saturation ends most tile lists early, so only the front layer of Gaussians
         receives gradients at all (config 3: 2 % of the visible ones per view) — far fewer rows than the ones a rank merely
-        SAW, which is what round 2 exchanged.  Step 1: all-gather of the per-rank BITMASKS of non-zero rows (P / 8 bytes);
-        step 2: all-reduce (SUM) of the packed [n_active, width] rows; step 3: the small side buffers — the two
-        densification statistics (SUM, [P, 2]) and max_radii (MAX, [P]) — dense.  Same values as all_reduce().
+        SAW, which is what round 2 exchanged.  On the GPU: the two collectives and the library launches of
+        sparse_all_reduce_capped, with the packed buffer sized EXACTLY from the union's row count, which is read back (one
+        host synchronisation per exchange; a mapping step has one exchange).  On CPU tensors (the specification): all-gather
+        of the per-rank bitmasks of non-zero rows (P / 8 bytes), all-reduce (SUM) of the packed [n_active, width] rows, and
+        the small side buffers — the two densification statistics (SUM, [P, 2]) and max_radii (MAX, [P]) — dense.
+        Same values as all_reduce().
         Returns dict(active_rows, bytes_dense, bytes_sparse) — the bytes each rank contributes to the wire."""
         import torch.distributed as dist
         P, width = self.flat.shape
         dense_bytes = self.sum_storage.numel() * 4 + self.max_radii.numel() * 4
+        if self.flat.is_cuda and not self.capped_torch_formulation:
+            # the product path: the library's launches around TWO collectives (the capacity-bound form's, include/olsr.h), the
+            # packed buffer sized exactly from a count that is read back - this exchange's one host synchronisation
+            L, dev = lib(), self.flat.device
+            multi = self._multi(group)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            mask_p = self.row_mask.data_ptr() if self.row_mask is not None else None
+            imax = torch.empty(2 * P, dtype=torch.int32, device=dev)
+            scratch = torch.empty(max(1, int(L.olsr_sparse_exchange_scratch_ints(P))), dtype=torch.int32, device=dev)
+            status = torch.zeros(2, dtype=torch.int32, device=dev)
+            check(L.olsr_sparse_exchange_mask(P, width, self.flat.data_ptr(), mask_p, self.max_radii.data_ptr(),
+                                              imax.data_ptr(), stream))
+            if multi:
+                dist.all_reduce(imax, op=dist.ReduceOp.MAX, group=group)
+            check(L.olsr_sparse_exchange_pack(P, width, 1, self.flat.data_ptr(), imax.data_ptr(), self.max_radii.data_ptr(),
+                                              mask_p, self.densify.data_ptr(), None, None, scratch.data_ptr(),
+                                              status.data_ptr(), stream))                      # count only
+            n = int(status[0].item())                                                           # identical on every rank
+            if not multi:
+                return dict(active_rows=n, bytes_dense=dense_bytes, bytes_sparse=0)
+            cap = max(n, 1)
+            idx = torch.empty(cap, dtype=torch.int32, device=dev)
+            fsum = torch.empty(cap * width + 2 * P, dtype=torch.float32, device=dev)
+            check(L.olsr_sparse_exchange_pack(P, width, cap, self.flat.data_ptr(), imax.data_ptr(), self.max_radii.data_ptr(),
+                                              mask_p, self.densify.data_ptr(), idx.data_ptr(), fsum.data_ptr(),
+                                              scratch.data_ptr(), status.data_ptr(), stream))
+            dist.all_reduce(fsum, op=dist.ReduceOp.SUM, group=group)
+            check(L.olsr_sparse_exchange_unpack(P, width, cap, idx.data_ptr(), fsum.data_ptr(), self.flat.data_ptr(),
+                                                self.densify.data_ptr(), stream))
+            return dict(active_rows=n, bytes_dense=dense_bytes, bytes_sparse=int(8 * P + (n * width + 2 * P) * 4))
+        # CPU tensors (the gloo tests): torch operations, four collectives - the specification of the path above
         nonzero = (self.flat != 0).any(dim=1)
         if not self._multi(group):
             return dict(active_rows=int(nonzero.sum()), bytes_dense=dense_bytes, bytes_sparse=0)

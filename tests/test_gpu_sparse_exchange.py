@@ -125,3 +125,26 @@ def test_bucket_method_matches_its_cpu_specification(hip):
             assert torch.equal(_bits(b.row_mask, P).cpu(), (flat != 0).any(1))
     n = int((flat != 0).any(1).sum())
     assert out[("cpu", 500)] == out[("gpu", 500)] == [n, 0] and out[("cpu", 123)] == out[("gpu", 123)] == [n, 1]
+
+
+def test_count_only_pack_leaves_the_count_and_nothing_else(hip):
+    """idx == fsum == NULL: the pack call only counts (what the exact form of the exchange reads back to size its buffer)."""
+    from online_lang_splatting_amd._lib import check, lib
+    L = lib()
+    dev = torch.device(DEV)
+    P, width = 70001, 29
+    flat, den, rad, mask = _bucket(P, width, 1234, 9, dev, "superset")
+    n = int((flat != 0).any(1).sum())
+    imax = torch.empty(2 * P, dtype=torch.int32, device=dev)
+    scr = torch.empty(int(L.olsr_sparse_exchange_scratch_ints(P)), dtype=torch.int32, device=dev)
+    status = torch.full((2,), -7, dtype=torch.int32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    before = flat.clone()
+    check(L.olsr_sparse_exchange_mask(P, width, flat.data_ptr(), mask.data_ptr(), rad.data_ptr(), imax.data_ptr(), stream))
+    for cap, over in ((n, 0), (n - 1, 1), (1, 1)):
+        check(L.olsr_sparse_exchange_pack(P, width, cap, flat.data_ptr(), imax.data_ptr(), rad.data_ptr(), mask.data_ptr(),
+                                          den.data_ptr(), None, None, scr.data_ptr(), status.data_ptr(), stream))
+        assert status.tolist() == [n, over]
+    assert torch.equal(flat.nan_to_num(7.0), before.nan_to_num(7.0)) and torch.equal(_bits(mask, P), (flat != 0).any(1))
+    assert L.olsr_sparse_exchange_pack(P, width, 5, flat.data_ptr(), imax.data_ptr(), rad.data_ptr(), None, den.data_ptr(),
+                                       None, imax.data_ptr(), scr.data_ptr(), status.data_ptr(), stream) != 0  # one of the pair
