@@ -7,7 +7,7 @@
 // The reference spends, per splat per tile, 3 block barriers + a shared-memory atomic per
 // skipping thread + an 8-barrier shared-memory tree over 225 threads + up to 25 global float
 // atomics.  MI355X mapping (same as the forward: one workgroup per tile, 4 wave64s, one pixel
-// per lane, wave w = the 64-pixel slot of ranks 64w..64w+63):
+// per lane, wave w = the forward's slot w — one quadrant of the tile, slot_rank in olsr_device.h):
 //   * no barrier per splat: the forward composite recorded, per (tile, splat) instance, which
 //     slots blended it (flags[] bit w).  A wave skips instances its slot never touched with a
 //     uniform branch, and the four waves of a tile only meet when the next batch of 128 list
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
   //   accum_rec_F <- last_alpha * last_F + (1 - last_alpha) * accum_rec_F     (CR/backward.cu:1132)
   // becomes A <- last_alpha * D_last + (1 - last_alpha) * A and the contribution is D - A.
   // Algebraically identical, 2 registers per pixel instead of 2F.
-  const int rank = PACKED ? ref15_rank_of_packed(tid) : tid;
+  const int rank = PACKED ? ref15_rank_of_packed(tid) : slot_rank<TILE>(tid);  // (unpacked: the forward's slots)
   const int px = bx * TILE + rank % TILE, py = by * TILE + rank / TILE;
   const bool inside = (rank < BS) && (px < W) && (py < H);
   const bool surv = (REF && !PACKED) ? ref_survives<TILE>(rank) : true;

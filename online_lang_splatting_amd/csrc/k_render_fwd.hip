@@ -3,8 +3,8 @@
 // Replaces renderCUDA / language_renderCUDA (CR/forward.cu:515-644, 377-513).
 //
 // MI355X mapping: one workgroup per logical TILE x TILE tile, 4 wave64s, one pixel per lane
-// (thread rank = ty*TILE + tx exactly as in the reference; wave w owns ranks 64w..64w+63, the
-// last wave of a 15x15 tile has 33 live lanes).  What differs from the reference:
+// (thread rank = ty*TILE + tx as in the reference; wave w owns one QUADRANT of the tile — slot_rank, olsr_device.h:
+// 64 / 56 / 56 / 49 pixels of a 15x15 tile; until late in round 4 the ranks 64w..64w+63, a strip).  What differs from the reference:
 //   * splat data is staged through LDS in batches of 128 with ONE coalesced gather per thread
 //     (half the threads fetch geometry, half fetch the colour/depth/language row), and the
 //     per-splat colour + language features are read from LDS as wave-uniform broadcasts — the
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
   }
   const int n = (int)(r1 - r0);
 
-  const int rank = tid;
+  const int rank = slot_rank<TILE>(tid);  // wave w = one quadrant of the tile (olsr_device.h)
   const int px = bx * TILE + rank % TILE, py = by * TILE + rank / TILE;
   const bool inside = (rank < BS) && (px < W) && (py < H);
   const float pixfx = (float)px, pixfy = (float)py;

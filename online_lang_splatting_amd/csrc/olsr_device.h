@@ -512,6 +512,39 @@ __device__ __forceinline__ int ref15_packed_of_rank(int rank) {  // survivors on
   return 4 * (rank / 7) + m - (m >= 3 ? 1 : 0);  // 0->0, 1->1, 3->2, 4->3
 }
 
+// Which pixel of its tile a thread of a 256-thread composite workgroup owns (the forward composite and the backward composites
+// that are not survivor-packed; both must agree, the forward's slot bits in flags[] say which WAVE blended an instance).
+// Round 1-4: wave w = the 64 consecutive ranks 64 w .. 64 w + 63, i.e. a strip 15 (16) pixels wide and ~4 rows tall — and, for
+// 15x15 tiles, a fourth wave with 33 pixels.  Since late round 4: wave w = one QUADRANT of the tile (8x8, 7x8, 8x7, 7x7 for
+// 15x15 tiles; four 8x8 for 16x16).  A splat's footprint edge crosses a compact region less often than a strip, so fewer
+// (entry, wave) pairs are visited and more lanes of a visit blend; the waves' pixel counts are 64 / 56 / 56 / 49 instead of
+// 64 / 64 / 64 / 33.  Per-pixel results do not depend on the assignment (each pixel composites its list in order); tile rank 0
+// stays thread 0.  Returns TILE * TILE for a lane without a pixel.  OLSR_SLOT_QUADRANTS=0 restores the strips.
+#ifndef OLSR_SLOT_QUADRANTS
+#define OLSR_SLOT_QUADRANTS 1
+#endif
+template <int TILE>
+__device__ __forceinline__ int slot_rank(int tid) {
+#if OLSR_SLOT_QUADRANTS
+  const int w = tid >> 6, l = tid & 63;
+  const int qx = w & 1, qy = w >> 1;
+  int lx, ly;
+  bool valid = true;
+  if constexpr (TILE == 16) {
+    lx = l & 7;
+    ly = l >> 3;
+  } else {
+    const int qw = qx ? TILE - 8 : 8, qh = qy ? TILE - 8 : 8;
+    ly = l / qw;
+    lx = l - ly * qw;
+    valid = ly < qh;
+  }
+  return valid ? (qy * 8 + ly) * TILE + qx * 8 + lx : TILE * TILE;
+#else
+  return tid;
+#endif
+}
+
 constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // staged per-Gaussian feature row: [r, g, b, depth, lang[F]] padded to a multiple of 4 floats
 constexpr int feat_row(int F) { return round_up(4 + F, 4); }
