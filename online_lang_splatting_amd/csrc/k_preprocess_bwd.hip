@@ -31,6 +31,10 @@ namespace olsr {
 #ifndef OLSR_PB_THREADS
 #define OLSR_PB_THREADS 128
 #endif
+#ifndef OLSR_PB_SPLIT
+#define OLSR_PB_SPLIT 0  // 1: row sums for every Gaussian, the chain only for those with rows (three kernels: built and measured
+                         // late in round 4 - same headline, the isolated stage 63 -> 84 us; profiles/r4_experiments.json); 0: one kernel
+#endif
 constexpr int PB_THREADS = OLSR_PB_THREADS;
 int tau_partial_blocks(int P) { return (P + PB_THREADS - 1) / PB_THREADS; }
 
@@ -270,7 +274,193 @@ __device__ __forceinline__ void cov3d_backward(const float* scale, float mod, co
           4.f * z * (dR[0][0] + dR[1][1]);
 }
 
-template <int F>
+// The analytic chain of ONE Gaussian from its composite-level gradient sums acc[0..9] = {mean2D.x, mean2D.y, conic.x, conic.y,
+// conic.w, (opacity), colour r g b, depth} to dL_dmean3D, dL_dcov3D, dL_dscale, dL_drotation, the SH rows and the pose
+// (computeCov2DCUDA, preprocessCUDA / language_preprocessCUDA, computeCov3D, computeColorFromSH backward: CR/backward.cu:21-145,
+// 150-346, 350-413, 418-682).  dmean / dcov / dscale / drot must come in zeroed; tau is accumulated into; sh_row is the
+// Gaussian's row of 3 M SH gradients (NULL: not wanted), written or — sh_add — added to.  Used by the one-kernel form and by
+// the compacted chain kernel below.
+template <int N>
+__device__ __forceinline__ void pb_chain(u32 idx, const float (&acc)[N], int D, int M, const float* __restrict__ means3D,
+                                         const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
+                                         const float* __restrict__ scales, const float* __restrict__ rotations,
+                                         float scale_modifier, const float* __restrict__ cov3Ds,
+                                         const float* __restrict__ view, const float* __restrict__ proj,
+                                         const float* __restrict__ proj_raw, const float* __restrict__ campos, float h_x,
+                                         float h_y, float tan_fovx, float tan_fovy, int act, float* sh_row, bool sh_add,
+                                         float (&dmean)[3], float (&dcov)[6], float (&dscale)[3], float (&drot)[4],
+                                         float (&tau)[6], bool& sh_written) {
+  static_assert(N >= 10, "acc holds the ten composite-level sums");
+    const f3 mean = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+    // ---- EWA splat, backward (what computeCov2DCUDA computes, CR/backward.cu:150-346), in matrix form.
+    // Forward (cov2d_common):  t = R m + T (x, y clamped to the guard frustum),  J = d(pixel)/dt (2x3),
+    //   M = J R (2x3),  Sigma' = M V M^T + 0.3 I = [[a, b], [b, c]],  conic K = Sigma'^-1 = adj / det.
+    // Backward, with G = [[g_x, g_y], [g_y, g_w]] the gradient of the loss with respect to the entries of K (the
+    // composite accumulates the off-diagonal one per entry, CR/backward.cu:1150-1153):
+    //   S    = dL/dSigma' = -K G K = -adj G adj / det^2            (the reference regularises 1 / (det^2 + 1e-7))
+    //   dL/dV = M^T S M        (off-diagonals of the packed symmetric V count twice)
+    //   dL/dM = 2 S M V,   dL/dJ = dL/dM R^T,   dL/dR = J^T dL/dM
+    //   dL/dt from the four non-constant entries of J;  dL/dm += R^T dL/dt
+    //   pose (left perturbation, tau = [rho | theta]):  rho += dL/dt,  theta += t x dL/dt + sum_c R_c x (dL/dR)_c
+    {
+      float cov3D[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) cov3D[i] = cov3Ds[6 * (size_t)idx + i];
+      Cov2D ci;
+      cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, ci);
+      const f3 t = ci.t;
+      const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+      const float keep_x = (ci.txtz < -limx || ci.txtz > limx) ? 0.f : 1.f;  // a clamped coordinate passes no gradient
+      const float keep_y = (ci.tytz < -limy || ci.tytz > limy) ? 0.f : 1.f;
+      // M(i, k) = (J R)(i, k) is what the forward keeps as T.c[i][k]; R(j, k) = view[4 k + j]
+      float Mx[3] = {ci.T.c[0][0], ci.T.c[0][1], ci.T.c[0][2]}, My[3] = {ci.T.c[1][0], ci.T.c[1][1], ci.T.c[1][2]};
+      const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}};
+      const float a = ci.cov.c[0][0] + 0.3f, b = ci.cov.c[0][1], c = ci.cov.c[1][1] + 0.3f;
+      const float det = a * c - b * b;
+      const float inv_det2 = 1.0f / ((det * det) + 0.0000001f);
+      const float gx = acc[2], gy = acc[3], gw = acc[4];
+      // The three entries of -adj G adj, adj = [[c, -b], [-b, a]].  For a large splat a c and b^2 agree to two digits
+      // and each entry is what is left after three terms of order 1e8 cancel: ANY association differs from any other by
+      // that amplified rounding (1e-5 .. 1e-4 relative, found by scripts/oracle_stress.py), so these three — and only
+      // these — keep the association of the reference's source (CR/backward.cu:220-228), with det - a c standing for
+      // -b^2 and S01 being half of its dL_db.
+      float S00 = inv_det2 * (-c * c * gx + 2 * b * c * gy + (det - a * c) * gw);
+      float S11 = inv_det2 * (-a * a * gw + 2 * a * b * gy + (det - a * c) * gx);
+      float S01 = inv_det2 * (b * c * gx - (det + 2 * b * b) * gy + a * b * gw);
+      if (inv_det2 == 0.f) S00 = S01 = S11 = 0.f;  // (det^2 overflowed: the reference leaves these gradients zero)
+      // dL/dV = M^T S M
+      float SMx[3], SMy[3];  // rows of S M (2x3)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        SMx[k] = S00 * Mx[k] + S01 * My[k];
+        SMy[k] = S01 * Mx[k] + S11 * My[k];
+      }
+      if (inv_det2 != 0.f) {
+        dcov[0] = Mx[0] * SMx[0] + My[0] * SMy[0];
+        dcov[3] = Mx[1] * SMx[1] + My[1] * SMy[1];
+        dcov[5] = Mx[2] * SMx[2] + My[2] * SMy[2];
+        dcov[1] = 2.f * (Mx[0] * SMx[1] + My[0] * SMy[1]);
+        dcov[2] = 2.f * (Mx[0] * SMx[2] + My[0] * SMy[2]);
+        dcov[4] = 2.f * (Mx[1] * SMx[2] + My[1] * SMy[2]);
+      }
+      // dL/dM = 2 (S M) V
+      float dMx[3], dMy[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dMx[k] = 2.f * (SMx[0] * V[0][k] + SMx[1] * V[1][k] + SMx[2] * V[2][k]);
+        dMy[k] = 2.f * (SMy[0] * V[0][k] + SMy[1] * V[1][k] + SMy[2] * V[2][k]);
+      }
+      // the entries of J that depend on t: J00 = fx / tz, J02 = -fx tx / tz^2, J11 = fy / tz, J12 = -fy ty / tz^2
+      // dL/dJ(i, j) = sum_k dL/dM(i, k) R(j, k)
+      const float dJ00 = dMx[0] * view[0] + dMx[1] * view[4] + dMx[2] * view[8];
+      const float dJ02 = dMx[0] * view[2] + dMx[1] * view[6] + dMx[2] * view[10];
+      const float dJ11 = dMy[0] * view[1] + dMy[1] * view[5] + dMy[2] * view[9];
+      const float dJ12 = dMy[0] * view[2] + dMy[1] * view[6] + dMy[2] * view[10];
+      const float rz = 1.f / t.z, rz2 = rz * rz, rz3 = rz2 * rz;
+      const f3 dt = {keep_x * (-h_x * rz2) * dJ02, keep_y * (-h_y * rz2) * dJ12,
+                     -h_x * rz2 * dJ00 - h_y * rz2 * dJ11 + (2.f * h_x * t.x) * rz3 * dJ02 + (2.f * h_y * t.y) * rz3 * dJ12};
+      // dL/dR(j, k) = sum_i J(i, j) dL/dM(i, k): column c of it, crossed with column c of R
+      const float J00 = ci.J.c[0][0], J02 = ci.J.c[0][2], J11 = ci.J.c[1][1], J12 = ci.J.c[1][2];
+      f3 theta = cross3(t, dt);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f3 Rk = {view[4 * k], view[4 * k + 1], view[4 * k + 2]};
+        const f3 dRk = {J00 * dMx[k], J11 * dMy[k], J02 * dMx[k] + J12 * dMy[k]};
+        const f3 x = cross3(Rk, dRk);
+        theta.x += x.x;
+        theta.y += x.y;
+        theta.z += x.z;
+      }
+      tau[0] += dt.x;
+      tau[1] += dt.y;
+      tau[2] += dt.z;
+      tau[3] += theta.x;
+      tau[4] += theta.y;
+      tau[5] += theta.z;
+      const f3 dm = transformVec4x3Transpose(dt, view);  // R^T dL/dt (assigned: the reference's first writer, :292-297)
+      dmean[0] = dm.x;
+      dmean[1] = dm.y;
+      dmean[2] = dm.z;
+    }
+    // ---- projected mean and depth, backward (preprocessCUDA / language_preprocessCUDA, CR/backward.cu:569-656).
+    // pixel = ndc2Pix(P m / (w + eps)): the 0.5 W / 0.5 H of ndc2Pix are already folded into dL_dmean2D by the
+    // composite.  With hom = P m, r = 1 / (hom.w + eps):  d(hom.x r)/dm = r P_row0 - hom.x r^2 P_row3 (same for y).
+    // The pose sees the mean through p_C = R m + T with the pinhole part of P only (P_raw[0] = 2 fx / W,
+    // P_raw[5] = 2 fy / H, P_raw[11] = 1): q = dL/dp_C, then rho += q, theta += p_C x q.  Depth adds dL/dz to q.z.
+    {
+      const f3 m = mean;
+      const f4 hom = transformPoint4x4(m, proj);
+      const float r = 1.0f / (hom.w + 0.0000001f);
+      const float g2x = acc[0], g2y = acc[1], gz = acc[9];
+      const float sx = g2x * r, sy = g2y * r;                              // gradient of (hom.x, hom.y) ...
+      const float sw = -((hom.x * r) * sx + (hom.y * r) * sy);             // ... and of hom.w
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dmean[k] += proj[4 * k] * sx + proj[4 * k + 1] * sy + proj[4 * k + 3] * sw;
+      const f3 p_C = transformPoint4x3(m, view);
+      const f3 q = {proj_raw[0] * sx, proj_raw[5] * sy, proj_raw[11] * sw + gz};
+      const f3 th = cross3(p_C, q);
+      tau[0] += q.x;
+      tau[1] += q.y;
+      tau[2] += q.z;
+      tau[3] += th.x;
+      tau[4] += th.y;
+      tau[5] += th.z;
+      dmean[0] += gz * view[2];
+      dmean[1] += gz * view[6];
+      dmean[2] += gz * view[10];
+      if (shs) {
+        const float dcol[3] = {acc[6], acc[7], acc[8]};
+        // one evaluation: into the caller's dL_dsh row if there is one (copied to the bucket below),
+        // else straight into the bucket row
+        const f3 dm_sh = sh_backward((int)idx, D, M, mean, campos, shs, clamped, dcol, sh_row, sh_add);
+        sh_written = true;
+        dmean[0] += dm_sh.x;
+        dmean[1] += dm_sh.y;
+        dmean[2] += dm_sh.z;
+        tau[0] += -dm_sh.x;
+        tau[1] += -dm_sh.y;
+        tau[2] += -dm_sh.z;
+      }
+      if (scales) {
+        // the activated scale / rotation are recomputed from the raw parameters (OLSR_ACT_*), and the
+        // gradients chained back through exp / normalize
+        float sc3[3], q4[4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float v = scales[3 * (size_t)idx + k];
+          sc3[k] = (act & OLSR_ACT_SCALE_EXP) ? expf(v) : v;
+        }
+        if (act & OLSR_ACT_ROTATION_NORMALIZE) {
+          act_normalize4(rotations + 4 * (size_t)idx, q4);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * (size_t)idx + k];
+        }
+        cov3d_backward(sc3, scale_modifier, q4, dcov, dscale, drot);
+        if (act & OLSR_ACT_SCALE_EXP) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dscale[k] *= sc3[k];  // d exp(x) / dx = exp(x)
+        }
+        if (act & OLSR_ACT_ROTATION_NORMALIZE) {
+          float graw[4];
+          act_normalize4_backward(rotations + 4 * (size_t)idx, drot, graw);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) drot[k] = graw[k];
+        }
+      }
+    }
+  
+}
+
+// SPLIT (OLSR_PB_SPLIT=1, an experiment that is OFF: see the macro): the chain does not run here.  Saturation leaves ~2 % of a view's Gaussians with a
+// partial-gradient row (config 3: 9 471 of 500 000) and every other Gaussian's chain is a product with zeros, yet in index
+// order nearly every wave holds one of the 2 % and issued the chain's ~800 instructions for all 64 lanes.  With SPLIT this
+// kernel sums the rows, writes the composite-level gradients, the statistics, the bucket's opacity / language columns and zeros
+// everywhere else, parks the ten sums of a Gaussian WITH rows in its gacc row and lists it (per block, ascending);
+// pb_compact_kernel concatenates the blocks' lists and pb_chain_kernel runs the chain for the listed Gaussians only, a lane
+// each, overwriting (or adding to) what this kernel left.  Same operations on the same values: the results are the one-kernel
+// form's, bit for bit, up to the sign of zeros; dL_dtau's device-side sum is taken over the listed Gaussians in ascending order.
+template <int F, bool SPLIT>
 __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     int P, int D, int M, const float* __restrict__ gacc, const u32* __restrict__ tiles_touched,
     const u32* __restrict__ inst_start, const u32* __restrict__ rowbase, const float* __restrict__ rows,
@@ -284,7 +474,8 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscales, float* __restrict__ dL_drotations,
     float* __restrict__ dL_dtau, float* __restrict__ tau_partials, float* __restrict__ bucket_flat,
     float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign, int act,
-    const float* __restrict__ opacities_raw, int F_out, u64* __restrict__ bucket_row_mask) {
+    const float* __restrict__ opacities_raw, int F_out, u64* __restrict__ bucket_row_mask, float* gacc_park,
+    u32* __restrict__ act_list, u32* __restrict__ act_count) {
   // F: language channels of the partial-gradient rows; F_out: the scene's (width of dL_dlanguage and of the bucket's
   // language columns).  F == 0 < F_out: the backward ran without a language cotangent, those gradients are zero.
   constexpr int ROW = grad_row(F);
@@ -302,8 +493,10 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     for (int v = 0; v < NVAL; ++v) acc[v] = 0.f;
     const u32 ntiles_g = vis ? tiles_touched[idx] : 0u;  // (a Gaussian listed in no tile has no rows: all zeros)
     if (ntiles_g > OLSR_MID_FOOTPRINT) {
-      has_rows = true;  // (not looked up: listed Gaussians are few)
       if (!frame_unusable(counters)) {  // summed by row_reduce_big_kernel
+        // (looked up since the chain below is skipped without rows: a large footprint behind the saturation depth has none)
+        const u32 u0 = inst_start[idx];
+        has_rows = rowbase[u0 + ntiles_g] != rowbase[u0];
         const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
 #pragma unroll
         for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
@@ -388,166 +581,21 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
     bool sh_written = false;
-    if (vis) {
-      const f3 mean = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
-      // ---- EWA splat, backward (what computeCov2DCUDA computes, CR/backward.cu:150-346), in matrix form.
-      // Forward (cov2d_common):  t = R m + T (x, y clamped to the guard frustum),  J = d(pixel)/dt (2x3),
-      //   M = J R (2x3),  Sigma' = M V M^T + 0.3 I = [[a, b], [b, c]],  conic K = Sigma'^-1 = adj / det.
-      // Backward, with G = [[g_x, g_y], [g_y, g_w]] the gradient of the loss with respect to the entries of K (the
-      // composite accumulates the off-diagonal one per entry, CR/backward.cu:1150-1153):
-      //   S    = dL/dSigma' = -K G K = -adj G adj / det^2            (the reference regularises 1 / (det^2 + 1e-7))
-      //   dL/dV = M^T S M        (off-diagonals of the packed symmetric V count twice)
-      //   dL/dM = 2 S M V,   dL/dJ = dL/dM R^T,   dL/dR = J^T dL/dM
-      //   dL/dt from the four non-constant entries of J;  dL/dm += R^T dL/dt
-      //   pose (left perturbation, tau = [rho | theta]):  rho += dL/dt,  theta += t x dL/dt + sum_c R_c x (dL/dR)_c
-      {
-        float cov3D[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) cov3D[i] = cov3Ds[6 * (size_t)idx + i];
-        Cov2D ci;
-        cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, ci);
-        const f3 t = ci.t;
-        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-        const float keep_x = (ci.txtz < -limx || ci.txtz > limx) ? 0.f : 1.f;  // a clamped coordinate passes no gradient
-        const float keep_y = (ci.tytz < -limy || ci.tytz > limy) ? 0.f : 1.f;
-        // M(i, k) = (J R)(i, k) is what the forward keeps as T.c[i][k]; R(j, k) = view[4 k + j]
-        float Mx[3] = {ci.T.c[0][0], ci.T.c[0][1], ci.T.c[0][2]}, My[3] = {ci.T.c[1][0], ci.T.c[1][1], ci.T.c[1][2]};
-        const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}};
-        const float a = ci.cov.c[0][0] + 0.3f, b = ci.cov.c[0][1], c = ci.cov.c[1][1] + 0.3f;
-        const float det = a * c - b * b;
-        const float inv_det2 = 1.0f / ((det * det) + 0.0000001f);
-        const float gx = acc[2], gy = acc[3], gw = acc[4];
-        // The three entries of -adj G adj, adj = [[c, -b], [-b, a]].  For a large splat a c and b^2 agree to two digits
-        // and each entry is what is left after three terms of order 1e8 cancel: ANY association differs from any other by
-        // that amplified rounding (1e-5 .. 1e-4 relative, found by scripts/oracle_stress.py), so these three — and only
-        // these — keep the association of the reference's source (CR/backward.cu:220-228), with det - a c standing for
-        // -b^2 and S01 being half of its dL_db.
-        float S00 = inv_det2 * (-c * c * gx + 2 * b * c * gy + (det - a * c) * gw);
-        float S11 = inv_det2 * (-a * a * gw + 2 * a * b * gy + (det - a * c) * gx);
-        float S01 = inv_det2 * (b * c * gx - (det + 2 * b * b) * gy + a * b * gw);
-        if (inv_det2 == 0.f) S00 = S01 = S11 = 0.f;  // (det^2 overflowed: the reference leaves these gradients zero)
-        // dL/dV = M^T S M
-        float SMx[3], SMy[3];  // rows of S M (2x3)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          SMx[k] = S00 * Mx[k] + S01 * My[k];
-          SMy[k] = S01 * Mx[k] + S11 * My[k];
-        }
-        if (inv_det2 != 0.f) {
-          dcov[0] = Mx[0] * SMx[0] + My[0] * SMy[0];
-          dcov[3] = Mx[1] * SMx[1] + My[1] * SMy[1];
-          dcov[5] = Mx[2] * SMx[2] + My[2] * SMy[2];
-          dcov[1] = 2.f * (Mx[0] * SMx[1] + My[0] * SMy[1]);
-          dcov[2] = 2.f * (Mx[0] * SMx[2] + My[0] * SMy[2]);
-          dcov[4] = 2.f * (Mx[1] * SMx[2] + My[1] * SMy[2]);
-        }
-        // dL/dM = 2 (S M) V
-        float dMx[3], dMy[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          dMx[k] = 2.f * (SMx[0] * V[0][k] + SMx[1] * V[1][k] + SMx[2] * V[2][k]);
-          dMy[k] = 2.f * (SMy[0] * V[0][k] + SMy[1] * V[1][k] + SMy[2] * V[2][k]);
-        }
-        // the entries of J that depend on t: J00 = fx / tz, J02 = -fx tx / tz^2, J11 = fy / tz, J12 = -fy ty / tz^2
-        // dL/dJ(i, j) = sum_k dL/dM(i, k) R(j, k)
-        const float dJ00 = dMx[0] * view[0] + dMx[1] * view[4] + dMx[2] * view[8];
-        const float dJ02 = dMx[0] * view[2] + dMx[1] * view[6] + dMx[2] * view[10];
-        const float dJ11 = dMy[0] * view[1] + dMy[1] * view[5] + dMy[2] * view[9];
-        const float dJ12 = dMy[0] * view[2] + dMy[1] * view[6] + dMy[2] * view[10];
-        const float rz = 1.f / t.z, rz2 = rz * rz, rz3 = rz2 * rz;
-        const f3 dt = {keep_x * (-h_x * rz2) * dJ02, keep_y * (-h_y * rz2) * dJ12,
-                       -h_x * rz2 * dJ00 - h_y * rz2 * dJ11 + (2.f * h_x * t.x) * rz3 * dJ02 + (2.f * h_y * t.y) * rz3 * dJ12};
-        // dL/dR(j, k) = sum_i J(i, j) dL/dM(i, k): column c of it, crossed with column c of R
-        const float J00 = ci.J.c[0][0], J02 = ci.J.c[0][2], J11 = ci.J.c[1][1], J12 = ci.J.c[1][2];
-        f3 theta = cross3(t, dt);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const f3 Rk = {view[4 * k], view[4 * k + 1], view[4 * k + 2]};
-          const f3 dRk = {J00 * dMx[k], J11 * dMy[k], J02 * dMx[k] + J12 * dMy[k]};
-          const f3 x = cross3(Rk, dRk);
-          theta.x += x.x;
-          theta.y += x.y;
-          theta.z += x.z;
-        }
-        tau[0] += dt.x;
-        tau[1] += dt.y;
-        tau[2] += dt.z;
-        tau[3] += theta.x;
-        tau[4] += theta.y;
-        tau[5] += theta.z;
-        const f3 dm = transformVec4x3Transpose(dt, view);  // R^T dL/dt (assigned: the reference's first writer, :292-297)
-        dmean[0] = dm.x;
-        dmean[1] = dm.y;
-        dmean[2] = dm.z;
+    // A Gaussian without a partial-gradient row has acc == 0 and every gradient below is a product with it: an exact zero (for
+    // finite parameters), which is what the defaults above and the zero fill of dL_dsh below leave.  Saturation leaves 98 % of
+    // a view's visible Gaussians without a row (config 3), so a wave whose 64 Gaussians are all such skips the chain's ~800
+    // instructions (three waves in ten do; the branch is uniform for them, the other lanes ride along as before).
+    if constexpr (SPLIT) {
+      if (vis && has_rows) {  // park the sums for pb_chain_kernel (a large footprint's row already holds them: same values)
+        float4* park = reinterpret_cast<float4*>(gacc_park + (size_t)idx * ROW);
+        park[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        park[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        park[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
       }
-      // ---- projected mean and depth, backward (preprocessCUDA / language_preprocessCUDA, CR/backward.cu:569-656).
-      // pixel = ndc2Pix(P m / (w + eps)): the 0.5 W / 0.5 H of ndc2Pix are already folded into dL_dmean2D by the
-      // composite.  With hom = P m, r = 1 / (hom.w + eps):  d(hom.x r)/dm = r P_row0 - hom.x r^2 P_row3 (same for y).
-      // The pose sees the mean through p_C = R m + T with the pinhole part of P only (P_raw[0] = 2 fx / W,
-      // P_raw[5] = 2 fy / H, P_raw[11] = 1): q = dL/dp_C, then rho += q, theta += p_C x q.  Depth adds dL/dz to q.z.
-      {
-        const f3 m = mean;
-        const f4 hom = transformPoint4x4(m, proj);
-        const float r = 1.0f / (hom.w + 0.0000001f);
-        const float g2x = acc[0], g2y = acc[1], gz = acc[9];
-        const float sx = g2x * r, sy = g2y * r;                              // gradient of (hom.x, hom.y) ...
-        const float sw = -((hom.x * r) * sx + (hom.y * r) * sy);             // ... and of hom.w
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dmean[k] += proj[4 * k] * sx + proj[4 * k + 1] * sy + proj[4 * k + 3] * sw;
-        const f3 p_C = transformPoint4x3(m, view);
-        const f3 q = {proj_raw[0] * sx, proj_raw[5] * sy, proj_raw[11] * sw + gz};
-        const f3 th = cross3(p_C, q);
-        tau[0] += q.x;
-        tau[1] += q.y;
-        tau[2] += q.z;
-        tau[3] += th.x;
-        tau[4] += th.y;
-        tau[5] += th.z;
-        dmean[0] += gz * view[2];
-        dmean[1] += gz * view[6];
-        dmean[2] += gz * view[10];
-        if (shs) {
-          const float dcol[3] = {acc[6], acc[7], acc[8]};
-          // one evaluation: into the caller's dL_dsh row if there is one (copied to the bucket below),
-          // else straight into the bucket row
-          float* sh_row = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : (brow ? brow + 3 : nullptr);
-          const f3 dm_sh = sh_backward((int)idx, D, M, mean, campos, shs, clamped, dcol, sh_row, !dL_dsh && badd);
-          sh_written = true;
-          dmean[0] += dm_sh.x;
-          dmean[1] += dm_sh.y;
-          dmean[2] += dm_sh.z;
-          tau[0] += -dm_sh.x;
-          tau[1] += -dm_sh.y;
-          tau[2] += -dm_sh.z;
-        }
-        if (scales) {
-          // the activated scale / rotation are recomputed from the raw parameters (OLSR_ACT_*), and the
-          // gradients chained back through exp / normalize
-          float sc3[3], q4[4];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const float v = scales[3 * (size_t)idx + k];
-            sc3[k] = (act & OLSR_ACT_SCALE_EXP) ? expf(v) : v;
-          }
-          if (act & OLSR_ACT_ROTATION_NORMALIZE) {
-            act_normalize4(rotations + 4 * (size_t)idx, q4);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * (size_t)idx + k];
-          }
-          cov3d_backward(sc3, scale_modifier, q4, dcov, dscale, drot);
-          if (act & OLSR_ACT_SCALE_EXP) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dscale[k] *= sc3[k];  // d exp(x) / dx = exp(x)
-          }
-          if (act & OLSR_ACT_ROTATION_NORMALIZE) {
-            float graw[4];
-            act_normalize4_backward(rotations + 4 * (size_t)idx, drot, graw);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) drot[k] = graw[k];
-          }
-        }
-      }
+    } else if (vis && has_rows) {
+      float* sh_row = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : (brow ? brow + 3 : nullptr);
+      pb_chain(idx, acc, D, M, means3D, shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, proj_raw, campos,
+               h_x, h_y, tan_fovx, tan_fovy, act, sh_row, !dL_dsh && badd, dmean, dcov, dscale, drot, tau, sh_written);
     }
     if (M > 0 && !sh_written) {
       if (dL_dsh) {
@@ -651,6 +699,23 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     }
   }
 
+  if constexpr (SPLIT) {
+    // this block's Gaussians with rows, ascending: act_list[block * PB_THREADS + 0 .. count)
+    __shared__ u32 s_listed[PB_THREADS / 64];
+    const u64 lm = ballot(has_rows);
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    if (lane == 0) s_listed[w] = (u32)__popcll(lm);
+    __syncthreads();
+    u32 before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < PB_THREADS / 64; ++k) {
+      before += (k < w) ? s_listed[k] : 0u;
+      total += s_listed[k];
+    }
+    if (has_rows) act_list[(size_t)blockIdx.x * PB_THREADS + before + (u32)__popcll(lm & ((1ull << lane) - 1ull))] = (u32)r;
+    if (threadIdx.x == 0) act_count[blockIdx.x] = total;
+    return;  // (dL_dtau's partial sums come from pb_chain_kernel)
+  }
   // deterministic block partial of tau (fixed butterfly order, then waves in order)
   if (tau_partials) {
     __shared__ float wsum[PB_THREADS / 64][6];
@@ -666,6 +731,132 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     if (threadIdx.x < 6) {
       float v = 0.f;
       for (int k = 0; k < PB_THREADS / 64; ++k) v += wsum[k][threadIdx.x];
+      tau_partials[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+  }
+}
+
+// The blocks' lists concatenated, in block order (= ascending Gaussian index): compact[0 .. *total).  One block: every thread
+// sums the counts of its contiguous share of the blocks, one block-wide scan, then copies its blocks' entries.
+constexpr int PC_THREADS = 1024;
+__global__ __launch_bounds__(PC_THREADS) void pb_compact_kernel(int nb, const u32* __restrict__ act_count,
+                                                                const u32* __restrict__ act_list, u32* __restrict__ compact,
+                                                                int32_t* __restrict__ total_out) {
+  __shared__ u32 s_w[PC_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int per = (nb + PC_THREADS - 1) / PC_THREADS;
+  const int b0 = min(tid * per, nb), b1 = min(b0 + per, nb);
+  u32 mine = 0;
+  for (int b = b0; b < b1; ++b) mine += act_count[b];
+  u32 incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  u32 off = incl - mine, total = 0;
+#pragma unroll
+  for (int k = 0; k < PC_THREADS / 64; ++k) {
+    off += (k < w) ? s_w[k] : 0u;
+    total += s_w[k];
+  }
+  for (int b = b0; b < b1; ++b) {
+    const u32 c = act_count[b];
+    for (u32 i = 0; i < c; ++i) compact[off + i] = act_list[(size_t)b * PB_THREADS + i];
+    off += c;
+  }
+  if (tid == 0) *total_out = (int32_t)total;
+}
+
+// The chain for the listed Gaussians, a lane each (pb_chain), over what the SPLIT form of preprocess_bwd_kernel left: per-Gaussian
+// outputs are overwritten, the bucket's chain columns written (assign) or added to.  Persistent grid; block partials of dL_dtau.
+constexpr int CH_THREADS = 128;
+__global__ __launch_bounds__(CH_THREADS) void pb_chain_kernel(
+    const int32_t* __restrict__ total_p, const u32* __restrict__ compact, const float* __restrict__ gacc, int ROW, int D, int M,
+    const float* __restrict__ means3D, const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
+    const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
+    const float* __restrict__ cov3Ds, const float* __restrict__ view, const float* __restrict__ proj,
+    const float* __restrict__ proj_raw, const float* __restrict__ campos, float h_x, float h_y, float tan_fovx,
+    float tan_fovy, int act, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dtau,
+    float* __restrict__ tau_partials, float* __restrict__ bucket_flat, int bucket_assign, int width) {
+  const int total = *total_p;
+  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int base = blockIdx.x * CH_THREADS; base < total; base += gridDim.x * CH_THREADS) {
+    const int pos = base + threadIdx.x;
+    if (pos >= total) continue;
+    const u32 idx = compact[pos];
+    float acc[12];
+    {
+      const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
+      const float4 x0 = row[0], x1 = row[1], x2 = row[2];
+      acc[0] = x0.x; acc[1] = x0.y; acc[2] = x0.z; acc[3] = x0.w;
+      acc[4] = x1.x; acc[5] = x1.y; acc[6] = x1.z; acc[7] = x1.w;
+      acc[8] = x2.x; acc[9] = x2.y; acc[10] = 0.f; acc[11] = 0.f;
+    }
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float gtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool sh_written = false;
+    float* brow = bucket_flat ? bucket_flat + (size_t)idx * width : nullptr;
+    const bool badd = bucket_flat != nullptr && bucket_assign == 0;
+    float* sh_row = dL_dsh ? dL_dsh + (size_t)idx * M * 3 : (brow ? brow + 3 : nullptr);
+    pb_chain(idx, acc, D, M, means3D, shs, clamped, scales, rotations, scale_modifier, cov3Ds, view, proj, proj_raw, campos, h_x,
+             h_y, tan_fovx, tan_fovy, act, sh_row, !dL_dsh && badd, dmean, dcov, dscale, drot, gtau, sh_written);
+    if (M > 0 && sh_written && brow && dL_dsh) {
+      const float* o = dL_dsh + (size_t)idx * M * 3;  // just written by this thread
+      for (int k = 0; k < 3 * M; ++k) brow[3 + k] = badd ? brow[3 + k] + o[k] : o[k];
+    }
+    if (dL_dmeans3D) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dL_dmeans3D[3 * (size_t)idx + i] = dmean[i];
+    }
+    if (dL_dcov3D) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    }
+    if (dL_dscales) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dL_dscales[3 * (size_t)idx + i] = dscale[i];
+    }
+    if (dL_drotations) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dL_drotations[4 * (size_t)idx + i] = drot[i];
+    }
+    if (dL_dtau) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dL_dtau[6 * (size_t)idx + i] = gtau[i];
+    }
+    if (brow) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) brow[i] = badd ? brow[i] + dmean[i] : dmean[i];
+      float* o = brow + 4 + 3 * M;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[i] = badd ? o[i] + dscale[i] : dscale[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[3 + i] = badd ? o[3 + i] + drot[i] : drot[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tau[i] += gtau[i];
+  }
+  if (tau_partials) {  // deterministic block partial (fixed butterfly order, then waves in order); every block writes one
+    __shared__ float wsum[CH_THREADS / 64][6];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float v = tau[i];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+      if (lane == 0) wsum[w][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      float v = 0.f;
+      for (int k = 0; k < CH_THREADS / 64; ++k) v += wsum[k][threadIdx.x];
       tau_partials[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
     }
   }
@@ -716,16 +907,34 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
   row_reduce_big_kernel<F><<<rr_blocks, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, s.P, b.rowbase, g.counters);
   const int F_out = s.F;
   const size_t bucket_lds = o.bucket_flat ? sizeof(float) * PB_THREADS * (size_t)(11 + 3 * s.M + F_out) : 0;
-  preprocess_bwd_kernel<F><<<nb, PB_THREADS, bucket_lds, st>>>(
-      s.P, s.D, s.M, g.gacc, g.tiles_touched, g.inst_start, b.rowbase, rows, g.counters, s.means3D, radii, s.shs,
-      g.clamped,
-      s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,
-      d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,
-      o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
-      o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign,
-      s.activations, s.opacities, F_out, o.bucket_row_mask);
+#define OLSR_PB_ARGS                                                                                                      \
+  s.P, s.D, s.M, g.gacc, g.tiles_touched, g.inst_start, b.rowbase, rows, g.counters, s.means3D, radii, s.shs, g.clamped,  \
+      s.scales, s.rotations, s.scale_modifier, cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos,        \
+      d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,              \
+      o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau
+  int n_partials = nb;
+  if (OLSR_PB_SPLIT) {
+    // scratch: the depth sort's key / value buffers are dead once the forward's emission has run (olsr_state.h)
+    u32 *act_list = g.key_a, *act_count = g.key_b, *compact = g.val_b;
+    int32_t* total = &g.counters[10];
+    preprocess_bwd_kernel<F, true><<<nb, PB_THREADS, bucket_lds, st>>>(
+        OLSR_PB_ARGS, nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign, s.activations,
+        s.opacities, F_out, o.bucket_row_mask, g.gacc, act_list, act_count);
+    pb_compact_kernel<<<1, PC_THREADS, 0, st>>>(nb, act_count, act_list, compact, total);
+    n_partials = std::min(nb, 256);
+    pb_chain_kernel<<<n_partials, CH_THREADS, 0, st>>>(
+        total, compact, g.gacc, grad_row(F), s.D, s.M, s.means3D, s.shs, g.clamped, s.scales, s.rotations, s.scale_modifier,
+        cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos, d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy,
+        s.activations, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
+        o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_assign, 11 + 3 * s.M + F_out);
+  } else {
+    preprocess_bwd_kernel<F, false><<<nb, PB_THREADS, bucket_lds, st>>>(
+        OLSR_PB_ARGS, o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii,
+        o.bucket_assign, s.activations, s.opacities, F_out, o.bucket_row_mask, nullptr, nullptr, nullptr);
+  }
+#undef OLSR_PB_ARGS
   if (o.dL_dtau_sum)
-    tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, nb, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
+    tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, n_partials, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
   else if (o.status_dev || o.sticky_error)
     tau_final_kernel<<<1, 64, 0, st>>>(tau_partials, 0, nullptr, g.counters, o.status_dev, o.sticky_error);
 }
