@@ -228,3 +228,36 @@ def test_usable_cpus_respects_affinity_and_quota(monkeypatch, tmp_path):
     monkeypatch.setattr(builtins, "open", fake_open)
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
     assert oracle_C.usable_cpus() == 3
+
+
+def test_sparse_exchange_entries_validate_their_arguments(L):
+    """The three local steps of the capacity-bound sparse exchange (include/olsr.h): argument errors come back before any
+    launch, P == 0 is a no-op, and the scratch size is one int per 1024 rows."""
+    from online_lang_splatting_amd import _abi
+    assert L.olsr_sparse_exchange_scratch_ints(0) == 0 and L.olsr_sparse_exchange_scratch_ints(1) == 1
+    assert L.olsr_sparse_exchange_scratch_ints(1024) == 1 and L.olsr_sparse_exchange_scratch_ints(500000) == 489
+    assert L.olsr_sparse_exchange_mask(0, 29, None, None, None, None, None) == _abi.OLSR_OK
+    assert L.olsr_sparse_exchange_mask(10, 0, None, None, None, None, None) == _abi.OLSR_ERR_ARG
+    assert L.olsr_sparse_exchange_mask(10, 29, None, None, None, None, None) == _abi.OLSR_ERR_ARG
+    assert b"must not be NULL" in L.olsr_last_error()
+    assert L.olsr_sparse_exchange_pack(10, 29, 0, *([None] * 10)) == _abi.OLSR_ERR_ARG
+    assert L.olsr_sparse_exchange_pack(10, 29, 4, *([None] * 10)) == _abi.OLSR_ERR_ARG
+    assert L.olsr_sparse_exchange_pack(0, 29, 4, *([None] * 10)) == _abi.OLSR_OK
+    assert L.olsr_sparse_exchange_unpack(10, 29, 4, None, None, None, None, None) == _abi.OLSR_ERR_ARG
+    assert L.olsr_sparse_exchange_unpack(-1, 29, 4, None, None, None, None, None) == _abi.OLSR_ERR_ARG
+
+
+def test_weak_scaling_poses_are_side_by_side_and_centred():
+    """shard_cameras: what rank r of N renders in bench.py's weak-scaling mode - N poses 1.5 cm apart, no rotation, centred on
+    the identity pose (N = 1: the identity pose itself), so that every rank's view costs what the N = 1 view costs."""
+    import torch
+    from online_lang_splatting_amd.scene import default_camera, shard_cameras
+    ident = default_camera(1200, 680)
+    one = shard_cameras(1200, 680, n=1)
+    assert len(one) == 1 and torch.equal(one[0].world_view_transform, ident.world_view_transform)
+    for n in (2, 4, 8):
+        cams = shard_cameras(1200, 680, n=n)
+        tx = torch.tensor([float(c.T[0]) for c in cams])
+        assert len(cams) == n and all(torch.equal(c.R, ident.R) for c in cams)
+        assert abs(float(tx.sum())) < 1e-6 and torch.allclose(tx[1:] - tx[:-1], torch.full((n - 1,), 0.015), atol=1e-6)
+        assert float(tx.abs().max()) <= 0.015 * 3.5 + 1e-6
