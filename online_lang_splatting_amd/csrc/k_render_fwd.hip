@@ -34,6 +34,9 @@
 namespace olsr {
 
 constexpr int FWD_BATCH = 128;
+#ifndef OLSR_FWD_WAVES
+#define OLSR_FWD_WAVES 7  // waves per SIMD the default accumulation is compiled for at F <= 16 (8: spills, measured slower)
+#endif
 #ifndef OLSR_FWD_ACC2_WAVES
 #define OLSR_FWD_ACC2_WAVES 7  // waves per SIMD the weight-accumulation variant is compiled for
 #endif
@@ -63,7 +66,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // CUT:  the per-tile depth cut-off bookkeeping (include/olsr.h) — its own instantiation: carried as a run-time test it cost the
 //       plain kernel 4 % (0.1588 -> 0.1647 ms at config 3, two more live scalars across the entry loop).
 template <int TILE, int F, int ACC, int LOSS, bool CUT>
-__global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FWD_ACC2_WAVES : 7)) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
+__global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FWD_ACC2_WAVES : OLSR_FWD_WAVES)) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
