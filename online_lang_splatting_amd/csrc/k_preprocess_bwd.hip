@@ -236,42 +236,54 @@ __device__ __forceinline__ f3 sh_backward(int idx, int deg, int M, const f3& pos
   return dnormvdv(dir_orig, dL_ddir);
 }
 
-// Sigma = Rq diag(s)^2 Rq^T, backward (what computeCov3D's backward computes, CR/backward.cu:350-413), in matrix form.
-// Forward (cov3d_from_scale_rot): with Rq the rotation matrix of the quaternion q = (r, x, y, z) and s = mod * scale,
-//   N = diag(s) Rq^T,  Sigma = N^T N.
-// Backward, D = dL/dSigma as a symmetric matrix (the packed off-diagonals carry both entries, hence the halves):
-//   dL/dN = 2 N D,   dL/ds_i = sum_k dL/dN(i, k) Rq(k, i),   dL/dRq(k, i) = s_i dL/dN(i, k),
-//   dL/dq = sum_{kj} dL/dRq(k, j) dRq(k, j)/dq  with the derivative of the (unnormalised-quaternion) rotation formula —
-//   the reference does not differentiate a normalisation either (its dnormvdv call is commented out, :412).
+// Sigma = Rq diag(s)^2 Rq^T, backward: what computeCov3D's backward computes (CR/backward.cu:350-413), in ITS operation
+// order (rounds 1-4 had the matrix form dL/dN = 2 N D, dL/ds_i = sum_k dL/dN(i, k) Rq(k, i), ...: same algebra, other rounding).
+// The reference differentiates the unnormalised-quaternion rotation formula and no normalisation (its dnormvdv call is
+// commented out, :412).
 __device__ __forceinline__ void cov3d_backward(const float* scale, float mod, const float* rot, const float* d,
                                                float* ds, float* dq) {
+  // operation for operation what the reference's glm expressions evaluate (CR/backward.cu:350-413; m3 is glm's
+  // column-major layout and mul() its accumulation order, olsr_device.h): M = S R, dL/dM = (2 M) dL/dSigma, the scale
+  // gradient from the rows of R^T and dL/dM^T, then dL/dM^T scaled by s and contracted with the quaternion derivative
   const float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
-  const float Rq[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
-                          {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
-                          {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-  const float sv[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
-  const float D[3][3] = {{d[0], 0.5f * d[1], 0.5f * d[2]}, {0.5f * d[1], d[3], 0.5f * d[4]}, {0.5f * d[2], 0.5f * d[4], d[5]}};
-  float dR[3][3];  // dL/dRq
+  const m3 R = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                 {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                 {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
+  m3 S = {{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}};
+  const f3 sv = {mod * scale[0], mod * scale[1], mod * scale[2]};
+  S.c[0][0] = sv.x;
+  S.c[1][1] = sv.y;
+  S.c[2][2] = sv.z;
+  const m3 Mm = mul(S, R);
+  const m3 dL_dSigma = {{{d[0], 0.5f * d[1], 0.5f * d[2]}, {0.5f * d[1], d[3], 0.5f * d[4]}, {0.5f * d[2], 0.5f * d[4], d[5]}}};
+  m3 M2;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    // row i of N is s_i times column i of Rq; row i of dL/dN = 2 N D
-    float dN[3];
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      dN[k] = 2.0f * sv[i] * (Rq[0][i] * D[0][k] + Rq[1][i] * D[1][k] + Rq[2][i] * D[2][k]);
-    // (gradient with respect to s_i = mod * scale_i: like the reference, :393-396, the factor `mod` of the chain to
-    //  the raw scale is NOT applied — visible only to callers that render with scale_modifier != 1, i.e. the GUI)
-    ds[i] = dN[0] * Rq[0][i] + dN[1] * Rq[1][i] + dN[2] * Rq[2][i];
+    for (int rr = 0; rr < 3; ++rr) M2.c[c][rr] = Mm.c[c][rr] * 2.0f;
+  const m3 dL_dM = mul(M2, dL_dSigma);
+  const m3 Rt = transpose(R);
+  m3 dL_dMt = transpose(dL_dM);
+  ds[0] = Rt.c[0][0] * dL_dMt.c[0][0] + Rt.c[0][1] * dL_dMt.c[0][1] + Rt.c[0][2] * dL_dMt.c[0][2];
+  ds[1] = Rt.c[1][0] * dL_dMt.c[1][0] + Rt.c[1][1] * dL_dMt.c[1][1] + Rt.c[1][2] * dL_dMt.c[1][2];
+  ds[2] = Rt.c[2][0] * dL_dMt.c[2][0] + Rt.c[2][1] * dL_dMt.c[2][1] + Rt.c[2][2] * dL_dMt.c[2][2];
+  // (gradient with respect to s_i = mod * scale_i: like the reference, :393-396, the factor `mod` of the chain to
+  //  the raw scale is NOT applied — visible only to callers that render with scale_modifier != 1, i.e. the GUI)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dR[k][i] = sv[i] * dN[k];
+  for (int k = 0; k < 3; ++k) {
+    dL_dMt.c[0][k] *= sv.x;
+    dL_dMt.c[1][k] *= sv.y;
+    dL_dMt.c[2][k] *= sv.z;
   }
-  dq[0] = 2.f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
-  dq[1] = 2.f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) -
-          4.f * x * (dR[1][1] + dR[2][2]);
-  dq[2] = 2.f * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) -
-          4.f * y * (dR[0][0] + dR[2][2]);
-  dq[3] = 2.f * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) -
-          4.f * z * (dR[0][0] + dR[1][1]);
+#define OLSR_MT(c_, r_) dL_dMt.c[c_][r_]
+  dq[0] = 2 * z * (OLSR_MT(0, 1) - OLSR_MT(1, 0)) + 2 * y * (OLSR_MT(2, 0) - OLSR_MT(0, 2)) + 2 * x * (OLSR_MT(1, 2) - OLSR_MT(2, 1));
+  dq[1] = 2 * y * (OLSR_MT(1, 0) + OLSR_MT(0, 1)) + 2 * z * (OLSR_MT(2, 0) + OLSR_MT(0, 2)) + 2 * r * (OLSR_MT(1, 2) - OLSR_MT(2, 1)) -
+          4 * x * (OLSR_MT(2, 2) + OLSR_MT(1, 1));
+  dq[2] = 2 * x * (OLSR_MT(1, 0) + OLSR_MT(0, 1)) + 2 * r * (OLSR_MT(2, 0) - OLSR_MT(0, 2)) + 2 * z * (OLSR_MT(1, 2) + OLSR_MT(2, 1)) -
+          4 * y * (OLSR_MT(2, 2) + OLSR_MT(0, 0));
+  dq[3] = 2 * r * (OLSR_MT(0, 1) - OLSR_MT(1, 0)) + 2 * x * (OLSR_MT(2, 0) + OLSR_MT(0, 2)) + 2 * y * (OLSR_MT(1, 2) + OLSR_MT(2, 1)) -
+          4 * z * (OLSR_MT(1, 1) + OLSR_MT(0, 0));
+#undef OLSR_MT
 }
 
 // The analytic chain of ONE Gaussian from its composite-level gradient sums acc[0..9] = {mean2D.x, mean2D.y, conic.x, conic.y,
@@ -291,123 +303,146 @@ __device__ __forceinline__ void pb_chain(u32 idx, const float (&acc)[N], int D, 
                                          float (&dmean)[3], float (&dcov)[6], float (&dscale)[3], float (&drot)[4],
                                          float (&tau)[6], bool& sh_written) {
   static_assert(N >= 10, "acc holds the ten composite-level sums");
-    const f3 mean = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
-    // ---- EWA splat, backward (what computeCov2DCUDA computes, CR/backward.cu:150-346), in matrix form.
-    // Forward (cov2d_common):  t = R m + T (x, y clamped to the guard frustum),  J = d(pixel)/dt (2x3),
-    //   M = J R (2x3),  Sigma' = M V M^T + 0.3 I = [[a, b], [b, c]],  conic K = Sigma'^-1 = adj / det.
-    // Backward, with G = [[g_x, g_y], [g_y, g_w]] the gradient of the loss with respect to the entries of K (the
-    // composite accumulates the off-diagonal one per entry, CR/backward.cu:1150-1153):
-    //   S    = dL/dSigma' = -K G K = -adj G adj / det^2            (the reference regularises 1 / (det^2 + 1e-7))
-    //   dL/dV = M^T S M        (off-diagonals of the packed symmetric V count twice)
-    //   dL/dM = 2 S M V,   dL/dJ = dL/dM R^T,   dL/dR = J^T dL/dM
-    //   dL/dt from the four non-constant entries of J;  dL/dm += R^T dL/dt
-    //   pose (left perturbation, tau = [rho | theta]):  rho += dL/dt,  theta += t x dL/dt + sum_c R_c x (dL/dR)_c
-    {
-      float cov3D[6];
+  // Since late round 4 every expression below is written in the association of the reference's source (which the oracle
+  // restates line by line): this translation unit is built without contraction, so on identical inputs the chain's outputs
+  // are the oracle's bits.  Rounds 1-4 derived the chain in matrix form (M = J R, S = -adj G adj / det^2, dL/dV = M^T S M,
+  // dL/dM = 2 S M V, theta as cross products): the same algebra, 30 % fewer operations — and wherever two large terms cancel
+  // (dL/dM for a strongly anisotropic covariance, the entries of -adj G adj) a different association is a different rounding,
+  // which a 1e-4 comparison notices (scripts/probe/one_stress_scene.py 2585 90000 base: six elements 3e-4 off on identical
+  // inputs).  The kernel is bound by its loads and stores, not by this arithmetic.
+  const f3 mean = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+  // ---- computeCov2DCUDA, backward (CR/backward.cu:150-346) --------------------------------------------------------------
+  {
+    float cov3D[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) cov3D[i] = cov3Ds[6 * (size_t)idx + i];
-      Cov2D ci;
-      cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, ci);
-      const f3 t = ci.t;
-      const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-      const float keep_x = (ci.txtz < -limx || ci.txtz > limx) ? 0.f : 1.f;  // a clamped coordinate passes no gradient
-      const float keep_y = (ci.tytz < -limy || ci.tytz > limy) ? 0.f : 1.f;
-      // M(i, k) = (J R)(i, k) is what the forward keeps as T.c[i][k]; R(j, k) = view[4 k + j]
-      float Mx[3] = {ci.T.c[0][0], ci.T.c[0][1], ci.T.c[0][2]}, My[3] = {ci.T.c[1][0], ci.T.c[1][1], ci.T.c[1][2]};
-      const float V[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}};
-      const float a = ci.cov.c[0][0] + 0.3f, b = ci.cov.c[0][1], c = ci.cov.c[1][1] + 0.3f;
-      const float det = a * c - b * b;
-      const float inv_det2 = 1.0f / ((det * det) + 0.0000001f);
-      const float gx = acc[2], gy = acc[3], gw = acc[4];
-      // The three entries of -adj G adj, adj = [[c, -b], [-b, a]].  For a large splat a c and b^2 agree to two digits
-      // and each entry is what is left after three terms of order 1e8 cancel: ANY association differs from any other by
-      // that amplified rounding (1e-5 .. 1e-4 relative, found by scripts/oracle_stress.py), so these three — and only
-      // these — keep the association of the reference's source (CR/backward.cu:220-228), with det - a c standing for
-      // -b^2 and S01 being half of its dL_db.
-      float S00 = inv_det2 * (-c * c * gx + 2 * b * c * gy + (det - a * c) * gw);
-      float S11 = inv_det2 * (-a * a * gw + 2 * a * b * gy + (det - a * c) * gx);
-      float S01 = inv_det2 * (b * c * gx - (det + 2 * b * b) * gy + a * b * gw);
-      if (inv_det2 == 0.f) S00 = S01 = S11 = 0.f;  // (det^2 overflowed: the reference leaves these gradients zero)
-      // dL/dV = M^T S M
-      float SMx[3], SMy[3];  // rows of S M (2x3)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        SMx[k] = S00 * Mx[k] + S01 * My[k];
-        SMy[k] = S01 * Mx[k] + S11 * My[k];
-      }
-      if (inv_det2 != 0.f) {
-        dcov[0] = Mx[0] * SMx[0] + My[0] * SMy[0];
-        dcov[3] = Mx[1] * SMx[1] + My[1] * SMy[1];
-        dcov[5] = Mx[2] * SMx[2] + My[2] * SMy[2];
-        dcov[1] = 2.f * (Mx[0] * SMx[1] + My[0] * SMy[1]);
-        dcov[2] = 2.f * (Mx[0] * SMx[2] + My[0] * SMy[2]);
-        dcov[4] = 2.f * (Mx[1] * SMx[2] + My[1] * SMy[2]);
-      }
-      // dL/dM = 2 (S M) V
-      float dMx[3], dMy[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        dMx[k] = 2.f * (SMx[0] * V[0][k] + SMx[1] * V[1][k] + SMx[2] * V[2][k]);
-        dMy[k] = 2.f * (SMy[0] * V[0][k] + SMy[1] * V[1][k] + SMy[2] * V[2][k]);
-      }
-      // the entries of J that depend on t: J00 = fx / tz, J02 = -fx tx / tz^2, J11 = fy / tz, J12 = -fy ty / tz^2
-      // dL/dJ(i, j) = sum_k dL/dM(i, k) R(j, k)
-      const float dJ00 = dMx[0] * view[0] + dMx[1] * view[4] + dMx[2] * view[8];
-      const float dJ02 = dMx[0] * view[2] + dMx[1] * view[6] + dMx[2] * view[10];
-      const float dJ11 = dMy[0] * view[1] + dMy[1] * view[5] + dMy[2] * view[9];
-      const float dJ12 = dMy[0] * view[2] + dMy[1] * view[6] + dMy[2] * view[10];
-      const float rz = 1.f / t.z, rz2 = rz * rz, rz3 = rz2 * rz;
-      const f3 dt = {keep_x * (-h_x * rz2) * dJ02, keep_y * (-h_y * rz2) * dJ12,
-                     -h_x * rz2 * dJ00 - h_y * rz2 * dJ11 + (2.f * h_x * t.x) * rz3 * dJ02 + (2.f * h_y * t.y) * rz3 * dJ12};
-      // dL/dR(j, k) = sum_i J(i, j) dL/dM(i, k): column c of it, crossed with column c of R
-      const float J00 = ci.J.c[0][0], J02 = ci.J.c[0][2], J11 = ci.J.c[1][1], J12 = ci.J.c[1][2];
-      f3 theta = cross3(t, dt);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const f3 Rk = {view[4 * k], view[4 * k + 1], view[4 * k + 2]};
-        const f3 dRk = {J00 * dMx[k], J11 * dMy[k], J02 * dMx[k] + J12 * dMy[k]};
-        const f3 x = cross3(Rk, dRk);
-        theta.x += x.x;
-        theta.y += x.y;
-        theta.z += x.z;
-      }
-      tau[0] += dt.x;
-      tau[1] += dt.y;
-      tau[2] += dt.z;
-      tau[3] += theta.x;
-      tau[4] += theta.y;
-      tau[5] += theta.z;
-      const f3 dm = transformVec4x3Transpose(dt, view);  // R^T dL/dt (assigned: the reference's first writer, :292-297)
-      dmean[0] = dm.x;
-      dmean[1] = dm.y;
-      dmean[2] = dm.z;
+    for (int i = 0; i < 6; ++i) cov3D[i] = cov3Ds[6 * (size_t)idx + i];
+    Cov2D ci;
+    cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, ci);
+    const f3 t = ci.t;
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    const float x_grad_mul = (ci.txtz < -limx || ci.txtz > limx) ? 0.f : 1.f;  // a clamped coordinate passes no gradient
+    const float y_grad_mul = (ci.tytz < -limy || ci.tytz > limy) ? 0.f : 1.f;
+    const m3& J = ci.J;
+    const m3& Wm = ci.Wm;
+    const m3& T = ci.T;
+    const m3& Vrk = ci.Vrk;
+    const float a = ci.cov.c[0][0] + 0.3f, b = ci.cov.c[0][1], c = ci.cov.c[1][1] + 0.3f;
+    const float denom = a * c - b * b;
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    const float gx = acc[2], gy = acc[3], gw = acc[4];  // dL_dconic .x .y .w
+    if (denom2inv != 0.f) {  // (det^2 overflowed otherwise: the reference leaves these gradients zero)
+      dL_da = denom2inv * (-c * c * gx + 2 * b * c * gy + (denom - a * c) * gw);
+      dL_dc = denom2inv * (-a * a * gw + 2 * a * b * gy + (denom - a * c) * gx);
+      dL_db = denom2inv * 2 * (b * c * gx - (denom + 2 * b * b) * gy + a * b * gw);
+      dcov[0] = (T.c[0][0] * T.c[0][0] * dL_da + T.c[0][0] * T.c[1][0] * dL_db + T.c[1][0] * T.c[1][0] * dL_dc);
+      dcov[3] = (T.c[0][1] * T.c[0][1] * dL_da + T.c[0][1] * T.c[1][1] * dL_db + T.c[1][1] * T.c[1][1] * dL_dc);
+      dcov[5] = (T.c[0][2] * T.c[0][2] * dL_da + T.c[0][2] * T.c[1][2] * dL_db + T.c[1][2] * T.c[1][2] * dL_dc);
+      dcov[1] = 2 * T.c[0][0] * T.c[0][1] * dL_da + (T.c[0][0] * T.c[1][1] + T.c[0][1] * T.c[1][0]) * dL_db +
+                2 * T.c[1][0] * T.c[1][1] * dL_dc;
+      dcov[2] = 2 * T.c[0][0] * T.c[0][2] * dL_da + (T.c[0][0] * T.c[1][2] + T.c[0][2] * T.c[1][0]) * dL_db +
+                2 * T.c[1][0] * T.c[1][2] * dL_dc;
+      dcov[4] = 2 * T.c[0][2] * T.c[0][1] * dL_da + (T.c[0][1] * T.c[1][2] + T.c[0][2] * T.c[1][1]) * dL_db +
+                2 * T.c[1][1] * T.c[1][2] * dL_dc;
     }
-    // ---- projected mean and depth, backward (preprocessCUDA / language_preprocessCUDA, CR/backward.cu:569-656).
-    // pixel = ndc2Pix(P m / (w + eps)): the 0.5 W / 0.5 H of ndc2Pix are already folded into dL_dmean2D by the
-    // composite.  With hom = P m, r = 1 / (hom.w + eps):  d(hom.x r)/dm = r P_row0 - hom.x r^2 P_row3 (same for y).
-    // The pose sees the mean through p_C = R m + T with the pinhole part of P only (P_raw[0] = 2 fx / W,
-    // P_raw[5] = 2 fy / H, P_raw[11] = 1): q = dL/dp_C, then rho += q, theta += p_C x q.  Depth adds dL/dz to q.z.
+    // gradients with respect to the upper 2x3 part of T (:246-257)
+    const float dL_dT00 = 2 * (T.c[0][0] * Vrk.c[0][0] + T.c[0][1] * Vrk.c[0][1] + T.c[0][2] * Vrk.c[0][2]) * dL_da +
+                          (T.c[1][0] * Vrk.c[0][0] + T.c[1][1] * Vrk.c[0][1] + T.c[1][2] * Vrk.c[0][2]) * dL_db;
+    const float dL_dT01 = 2 * (T.c[0][0] * Vrk.c[1][0] + T.c[0][1] * Vrk.c[1][1] + T.c[0][2] * Vrk.c[1][2]) * dL_da +
+                          (T.c[1][0] * Vrk.c[1][0] + T.c[1][1] * Vrk.c[1][1] + T.c[1][2] * Vrk.c[1][2]) * dL_db;
+    const float dL_dT02 = 2 * (T.c[0][0] * Vrk.c[2][0] + T.c[0][1] * Vrk.c[2][1] + T.c[0][2] * Vrk.c[2][2]) * dL_da +
+                          (T.c[1][0] * Vrk.c[2][0] + T.c[1][1] * Vrk.c[2][1] + T.c[1][2] * Vrk.c[2][2]) * dL_db;
+    const float dL_dT10 = 2 * (T.c[1][0] * Vrk.c[0][0] + T.c[1][1] * Vrk.c[0][1] + T.c[1][2] * Vrk.c[0][2]) * dL_dc +
+                          (T.c[0][0] * Vrk.c[0][0] + T.c[0][1] * Vrk.c[0][1] + T.c[0][2] * Vrk.c[0][2]) * dL_db;
+    const float dL_dT11 = 2 * (T.c[1][0] * Vrk.c[1][0] + T.c[1][1] * Vrk.c[1][1] + T.c[1][2] * Vrk.c[1][2]) * dL_dc +
+                          (T.c[0][0] * Vrk.c[1][0] + T.c[0][1] * Vrk.c[1][1] + T.c[0][2] * Vrk.c[1][2]) * dL_db;
+    const float dL_dT12 = 2 * (T.c[1][0] * Vrk.c[2][0] + T.c[1][1] * Vrk.c[2][1] + T.c[1][2] * Vrk.c[2][2]) * dL_dc +
+                          (T.c[0][0] * Vrk.c[2][0] + T.c[0][1] * Vrk.c[2][1] + T.c[0][2] * Vrk.c[2][2]) * dL_db;
+    const float dL_dJ00 = Wm.c[0][0] * dL_dT00 + Wm.c[0][1] * dL_dT01 + Wm.c[0][2] * dL_dT02;
+    const float dL_dJ02 = Wm.c[2][0] * dL_dT00 + Wm.c[2][1] * dL_dT01 + Wm.c[2][2] * dL_dT02;
+    const float dL_dJ11 = Wm.c[1][0] * dL_dT10 + Wm.c[1][1] * dL_dT11 + Wm.c[1][2] * dL_dT12;
+    const float dL_dJ12 = Wm.c[2][0] * dL_dT10 + Wm.c[2][1] * dL_dT11 + Wm.c[2][2] * dL_dT12;
+    const float tz = 1.f / t.z;
+    const float tz2 = tz * tz;
+    const float tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 +
+                         (2 * h_y * t.y) * tz3 * dL_dJ12;
+    // pose, part 1 (:273-288): dp_C/drho = I, dp_C/dtheta = -skew(t)
     {
-      const f3 m = mean;
-      const f4 hom = transformPoint4x4(m, proj);
-      const float r = 1.0f / (hom.w + 0.0000001f);
-      const float g2x = acc[0], g2y = acc[1], gz = acc[9];
-      const float sx = g2x * r, sy = g2y * r;                              // gradient of (hom.x, hom.y) ...
-      const float sw = -((hom.x * r) * sx + (hom.y * r) * sy);             // ... and of hom.w
+      const f3 rho_cols[3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+      const f3 th_cols[3] = {nskew_col(t, 0), nskew_col(t, 1), nskew_col(t, 2)};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) dmean[k] += proj[4 * k] * sx + proj[4 * k + 1] * sy + proj[4 * k + 3] * sw;
-      const f3 p_C = transformPoint4x3(m, view);
-      const f3 q = {proj_raw[0] * sx, proj_raw[5] * sy, proj_raw[11] * sw + gz};
-      const f3 th = cross3(p_C, q);
-      tau[0] += q.x;
-      tau[1] += q.y;
-      tau[2] += q.z;
-      tau[3] += th.x;
-      tau[4] += th.y;
-      tau[5] += th.z;
-      dmean[0] += gz * view[2];
-      dmean[1] += gz * view[6];
-      dmean[2] += gz * view[10];
+      for (int i = 0; i < 3; ++i) {
+        tau[i] += dL_dtx * rho_cols[i].x + dL_dty * rho_cols[i].y + dL_dtz * rho_cols[i].z;
+        tau[i + 3] += dL_dtx * th_cols[i].x + dL_dty * th_cols[i].y + dL_dtz * th_cols[i].z;
+      }
+    }
+    const f3 dm = transformVec4x3Transpose({dL_dtx, dL_dty, dL_dtz}, view);  // (assigned: the reference's first writer, :292-297)
+    dmean[0] = dm.x;
+    dmean[1] = dm.y;
+    dmean[2] = dm.z;
+    // pose, part 2 (:299-345): dL/dW = J^T dL/dT, contracted with the columns of -skew of the columns of R
+    const float dL_dW00 = J.c[0][0] * dL_dT00;
+    const float dL_dW01 = J.c[0][0] * dL_dT01;
+    const float dL_dW02 = J.c[0][0] * dL_dT02;
+    const float dL_dW10 = J.c[1][1] * dL_dT10;
+    const float dL_dW11 = J.c[1][1] * dL_dT11;
+    const float dL_dW12 = J.c[1][1] * dL_dT12;
+    const float dL_dW20 = J.c[0][2] * dL_dT00 + J.c[1][2] * dL_dT10;
+    const float dL_dW21 = J.c[0][2] * dL_dT01 + J.c[1][2] * dL_dT11;
+    const float dL_dW22 = J.c[0][2] * dL_dT02 + J.c[1][2] * dL_dT12;
+    const f3 c1 = {view[0], view[1], view[2]}, c2 = {view[4], view[5], view[6]}, c3 = {view[8], view[9], view[10]};
+    const f3 dW1 = {dL_dW00, dL_dW10, dL_dW20}, dW2 = {dL_dW01, dL_dW11, dL_dW21}, dW3 = {dL_dW02, dL_dW12, dL_dW22};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      tau[3 + i] += dot3(dW1, nskew_col(c1, i)) + dot3(dW2, nskew_col(c2, i)) + dot3(dW3, nskew_col(c3, i));
+  }
+  // ---- preprocessCUDA / language_preprocessCUDA, backward (CR/backward.cu:418-682): the projected mean and the depth ----
+  {
+    const f3 m = mean;
+    const f4 m_hom = transformPoint4x4(m, proj);
+    const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+    const float g2x = acc[0], g2y = acc[1];
+    const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+    dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+    dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+    dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    const float alpha = 1.0f * m_w;
+    const float beta = -m_hom.x * m_w * m_w;
+    const float gamma = -m_hom.y * m_w * m_w;
+    const float pa = proj_raw[0], pb = proj_raw[5], pe = proj_raw[11];
+    // p_C = R m + t through the reference's SE3 (CR/math.h:322-324): the rotation first, then the translation
+    const f3 c0 = {view[0], view[1], view[2]}, c1 = {view[4], view[5], view[6]}, c2 = {view[8], view[9], view[10]};
+    const f3 tt = {view[12], view[13], view[14]};
+    const f3 Rm = {c0.x * m.x + c1.x * m.y + c2.x * m.z, c0.y * m.x + c1.y * m.y + c2.y * m.z,
+                   c0.z * m.x + c1.z * m.y + c2.z * m.z};
+    const f3 p_C = {Rm.x + tt.x, Rm.y + tt.y, Rm.z + tt.z};
+    const f3 th_cols[3] = {nskew_col(p_C, 0), nskew_col(p_C, 1), nskew_col(p_C, 2)};
+    const f3 I_cols[3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+    const f3 d1 = {alpha * pa, 0.f, beta * pe};
+    const f3 d2 = {0.f, alpha * pb, gamma * pe};
+    float dmx[6], dmy[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dmx[i] = dot3(I_cols[i], d1);
+      dmy[i] = dot3(I_cols[i], d2);
+      dmx[i + 3] = dot3(th_cols[i], d1);
+      dmy[i + 3] = dot3(th_cols[i], d2);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tau[i] += g2x * dmx[i] + g2y * dmy[i];
+    const float dL_dpCz = acc[9];
+    dmean[0] += dL_dpCz * view[2];
+    dmean[1] += dL_dpCz * view[6];
+    dmean[2] += dL_dpCz * view[10];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      tau[i] += dL_dpCz * I_cols[i].z;
+      tau[i + 3] += dL_dpCz * th_cols[i].z;
+    }
       if (shs) {
         const float dcol[3] = {acc[6], acc[7], acc[8]};
         // one evaluation: into the caller's dL_dsh row if there is one (copied to the bucket below),

@@ -46,7 +46,8 @@ COMPOSITE_KEYS = COMPOSITE_GRADS
 
 
 def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise=False, worst_bound=1e-2, log=None,
-           chain=True, chain_worst_bound=1e-3, chain_min_fraction=ELEM_MIN_FRACTION, composite_worst_bound=2e-4, **kw):
+           chain=True, chain_worst_bound=1e-3, chain_min_fraction=ELEM_MIN_FRACTION, composite_worst_bound=2e-4,
+           chain_exact=True, **kw):
     """Oracle vs the HIP library in both binning modes.
     RECT: images, counters AND the instance lists equal the reference's bit for bit.
     ELLIPSE (the product's default): identical images / radii / n_touched / final_T, gradients to RTOL,
@@ -61,7 +62,10 @@ def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise
     north-star one per element (two elements may leave the band in tensors too small for 99.99 % to allow any), worst
     element within chain_worst_bound = 1e-3 (the 2 800 random scenes of round 3's campaigns: every element of every
     tensor within 1e-4 except ONE element — 6.5e-5 in a tensor whose largest is 1.3e-2 — at 8.5e-4; the suite's own
-    scenes: one element of 9 308 at 1.5e-4)."""
+    scenes: one element of 9 308 at 1.5e-4).
+    chain_exact (late round 4, on by default): the product's chain is written in the association of the reference's source,
+    like the oracle, and neither is built with contraction - on identical inputs every element of dL_dmeans3D, dL_dcov3D,
+    dL_dsh, dL_dscales, dL_drotations and dL_dtau must EQUAL the oracle's replay (the sign of a zero aside)."""
     fo, go = run_backend(oracle, sc, None, seed, tile, mode, **kw)
     assert grad_keys is None or all(k in go for k in grad_keys), [k for k in grad_keys if k not in go]
     fr, gr = run_backend(hip, sc, torch.device(DEV), seed, tile, mode, binning=_abi.BINNING_RECT, **kw)
@@ -105,6 +109,12 @@ def _check(hip, oracle, sc, seed=0, tile=15, mode=0, grad_keys=None, elementwise
                 if gc[k].numel():
                     assert_elementwise(g_[k], gc[k], f"{name}:chain:{k}", chain_worst_bound, log, allow_outliers=2,
                                        min_fraction=chain_min_fraction)
+                    if chain_exact:
+                        a_, b_ = g_[k].detach().cpu().float(), gc[k].detach().cpu().float()
+                        same = (a_ == b_) | (a_.isnan() & b_.isnan())
+                        assert bool(same.all()), (f"{name}:chain:{k}: {int((~same).sum())} of {a_.numel()} elements differ from "
+                                                  f"the oracle's replay on identical inputs (largest difference "
+                                                  f"{float((a_ - b_).abs().nan_to_num(0).max()):.3e})")
         if P and grad_keys is None:
             tau_sum = go["dL_dtau"].double().sum(0).float()
             # six sums over all P Gaussians (millions of cancelling terms at the full configs): held to 1e-4 of the
