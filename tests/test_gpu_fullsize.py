@@ -7,7 +7,9 @@ paths — thousands of radix blocks, multi-block scans — with the oracle), exa
 sub-list that keeps every blending instance, and EVERY gradient (composite level, per-Gaussian chain, dL_dtau per
 Gaussian and summed) under the element-wise north-star criterion: >= 99.99 % of the elements within 1e-4 relative
 (+ 1e-6 of the tensor's largest magnitude), the worst element bounded (WORST_BOUND), both printed and written to
-gpurun_out/parity_fullsize.json.
+gpurun_out/parity_fullsize.json.  Since late round 4 the per-Gaussian chain on identical inputs (the oracle replaying the
+reference's chain on the product's composite-level gradients) must EQUAL the product's outputs element for element
+(`_check(chain_exact=True)`): its `:chain:` rows in the record have worst = 0.
 
 The oracle needs ~2 s (config 2/3) to ~10 s (config 5) per frame on the GPU box's host cores.
 """
