@@ -49,6 +49,25 @@ def _bits(mask, P):
     (5000, 29, 300, "exact"), (5000, 29, 300, "none"), (64 * 16 * 3 + 17, 91, 777, "superset"), (1024, 14, 5, "ones"),
     (100003, 29, 2500, "exact"), (63, 11, 10, "exact"), (2048, 29, 0, "exact")])
 def test_two_ranks_on_one_gpu_equal_the_dense_exchange(hip, P, width, rows, mask_kind):
+    _two_ranks(P, width, rows, mask_kind)
+
+
+def test_random_shapes_around_the_block_boundaries(hip):
+    """Seeded random sizes: P around the multiples of 64 and 1024 the kernels are cut by, empty to nearly full unions,
+    every mask kind, widths from 11 (no SH, no language) to 91."""
+    g = torch.Generator().manual_seed(2024)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for _ in range(40):
+        base = (64, 1024, 2048, 4096, 1024 * 7)[ri(0, 4)]
+        P = max(1, base * ri(1, 3) + ri(-3, 3))
+        width = (11, 14, 29, 46, 91)[ri(0, 4)]
+        rows = min(P, (0, 1, 7, P // 50 + 1, P // 3 + 1, P - 1)[ri(0, 5)])
+        _two_ranks(P, width, rows, ("exact", "none", "superset", "ones")[ri(0, 3)])
+
+
+def _two_ranks(P, width, rows, mask_kind):
     from online_lang_splatting_amd._lib import check, lib
     L = lib()
     dev = torch.device(DEV)
