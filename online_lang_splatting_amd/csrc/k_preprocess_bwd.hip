@@ -948,7 +948,8 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
       d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy, o.dL_dmeans2D, o.dL_dconic, o.dL_dopacity, o.dL_dcolors,              \
       o.dL_dlanguage, o.dL_ddepths, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau
   int n_partials = nb;
-  if (OLSR_PB_SPLIT) {
+#if OLSR_PB_SPLIT
+  {
     // scratch: the depth sort's key / value buffers are dead once the forward's emission has run (olsr_state.h)
     u32 *act_list = g.key_a, *act_count = g.key_b, *compact = g.val_b;
     int32_t* total = &g.counters[10];
@@ -962,11 +963,12 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
         cov3D_ptr, s.viewmatrix, s.projmatrix, s.projmatrix_raw, s.cam_pos, d.focal_x, d.focal_y, s.tan_fovx, s.tan_fovy,
         s.activations, o.dL_dmeans3D, o.dL_dcov3D, o.dL_dsh, o.dL_dscales, o.dL_drotations, o.dL_dtau,
         o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_assign, 11 + 3 * s.M + F_out);
-  } else {
-    preprocess_bwd_kernel<F, false><<<nb, PB_THREADS, bucket_lds, st>>>(
-        OLSR_PB_ARGS, o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii,
-        o.bucket_assign, s.activations, s.opacities, F_out, o.bucket_row_mask, nullptr, nullptr, nullptr);
   }
+#else
+  preprocess_bwd_kernel<F, false><<<nb, PB_THREADS, bucket_lds, st>>>(
+      OLSR_PB_ARGS, o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii,
+      o.bucket_assign, s.activations, s.opacities, F_out, o.bucket_row_mask, nullptr, nullptr, nullptr);
+#endif
 #undef OLSR_PB_ARGS
   if (o.dL_dtau_sum)
     tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, n_partials, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
