@@ -109,6 +109,10 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float*
     const int nxt = item + nwaves;
     const uint4 next = item_at(nxt < count ? nxt : item);
     const u32 idx = cur.x, first = rowbase[cur.y], nrows = rowbase[cur.y + cur.z] - first;
+    if (nrows == 0) {  // (wave-uniform) behind the saturation depth of every tile it covers: most listed Gaussians.  Nothing to
+      cur = next;      // sum and nothing to store: preprocess_bwd_kernel looks the count up itself and reads gacc only with rows
+      continue;
+    }
     float acc[NP];
 #pragma unroll
     for (int v = 0; v < NP; ++v) acc[v] = 0.f;
@@ -533,13 +537,15 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
         const u32 u0 = inst_start[idx];
         has_rows = rowbase[u0 + ntiles_g] != rowbase[u0];
         const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
+        if (has_rows) {  // (row_reduce_big_kernel writes no row for a Gaussian without any)
 #pragma unroll
-        for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
-          const float4 x = row[v4];
-          if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] = x.x;
-          if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] = x.y;
-          if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] = x.z;
-          if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
+          for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
+            const float4 x = row[v4];
+            if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] = x.x;
+            if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] = x.y;
+            if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] = x.z;
+            if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
+          }
         }
       }
     } else if (ntiles_g > 0 && !frame_unusable(counters)) {
