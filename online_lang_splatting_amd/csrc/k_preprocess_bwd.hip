@@ -62,6 +62,7 @@ __device__ __forceinline__ void wave_reduce_rec(float (&v)[N], int lane) {
 }
 
 constexpr int RR_THREADS = 256;
+
 #ifndef OLSR_RR_BLOCKS
 #define OLSR_RR_BLOCKS 8192  // (65 k listed Gaussians at config 3: 1024 / 2048 / 4096 / 8192 blocks: 30 / 29 / 24 / 23 us)
 #endif
@@ -104,24 +105,37 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float*
   const int nbig = counters[5], count = nbig + counters[4];  // front list, then the medium list from the back
   if (wave >= count || frame_unusable(counters)) return;
   auto item_at = [&](int i) { return big_list[i < nbig ? i : P - 1 - (i - nbig)]; };
+  // Most listed Gaussians lie behind the saturation depth of every tile they cover and have NO row (config 3: 65 k listed,
+  // a few thousand with rows): such an item ends after its look-up — no butterfly, no gacc row (preprocess_bwd_kernel looks
+  // the count up itself and discards what it reads there).  The look-ups are pipelined two items deep by hand: an iteration
+  // issues the descriptor load of the item after next and the two rowbase loads of the next one, whose descriptor arrived an
+  // iteration ago, and works on an item whose everything has arrived — one dependent trip per item.  (Measured in round 4,
+  // profiles/r4_experiments.json: the same early exit WITHOUT the explicit pipeline won 4 us at config 3 and lost 60 us at
+  // config 5, where a wave walks twelve items and the compiler had sunk the prefetch behind the exit; 64 look-ups per wave
+  // at once with the items that have rows then served in series lost 100 us: those cluster at the front of the list.)
   uint4 cur = item_at(wave);
+  const int i1_ = wave + nwaves;
+  uint4 nx = item_at(i1_ < count ? i1_ : wave);
+  u32 cur_first = rowbase[cur.y], cur_end = rowbase[cur.y + cur.z];
   for (int item = wave; item < count; item += nwaves) {
-    const int nxt = item + nwaves;
-    const uint4 next = item_at(nxt < count ? nxt : item);
-    const u32 idx = cur.x, first = rowbase[cur.y], nrows = rowbase[cur.y + cur.z] - first;
-    if (nrows == 0) {  // (wave-uniform) behind the saturation depth of every tile it covers: most listed Gaussians.  Nothing to
-      cur = next;      // sum and nothing to store: preprocess_bwd_kernel looks the count up itself and reads gacc only with rows
-      continue;
-    }
-    float acc[NP];
+    const int i2_ = item + 2 * nwaves;
+    const uint4 nn = item_at(i2_ < count ? i2_ : item);                          // descriptor of the item after next
+    const u32 nx_first = rowbase[nx.y], nx_end = rowbase[nx.y + nx.z];          // the next item's run of rows
+    const u32 idx = cur.x, first = cur_first, nrows = cur_end - cur_first;
+    if (nrows != 0u) {  // (wave-uniform)
+      float acc[NP];
 #pragma unroll
-    for (int v = 0; v < NP; ++v) acc[v] = 0.f;
-    for (u32 t = (u32)lane; t < nrows; t += 64) add_row<F, NP>(rows, first + t, acc);
-    wave_reduce_rec<NP / 2, 32, NP>(acc, lane);
-    float v = __shfl(acc[0], (lane * G_LANES) & 63);
-    if (lane >= NVAL) v = 0.f;
-    if (lane < ROW) gacc[(size_t)idx * ROW + lane] = v;
-    cur = next;
+      for (int v = 0; v < NP; ++v) acc[v] = 0.f;
+      for (u32 t = (u32)lane; t < nrows; t += 64) add_row<F, NP>(rows, first + t, acc);
+      wave_reduce_rec<NP / 2, 32, NP>(acc, lane);
+      float v = __shfl(acc[0], (lane * G_LANES) & 63);
+      if (lane >= NVAL) v = 0.f;
+      if (lane < ROW) gacc[(size_t)idx * ROW + lane] = v;
+    }
+    cur = nx;
+    cur_first = nx_first;
+    cur_end = nx_end;
+    nx = nn;
   }
 }
 
@@ -537,15 +551,15 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
         const u32 u0 = inst_start[idx];
         has_rows = rowbase[u0 + ntiles_g] != rowbase[u0];
         const float4* row = reinterpret_cast<const float4*>(gacc + (size_t)idx * ROW);
-        if (has_rows) {  // (row_reduce_big_kernel writes no row for a Gaussian without any)
+        // row_reduce_big_kernel writes no row for a Gaussian without any: the row is read regardless — its loads go out
+        // beside the look-up's instead of behind it (a fourth dependent trip cost config 5 60 us) — and discarded then
 #pragma unroll
-          for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
-            const float4 x = row[v4];
-            if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] = x.x;
-            if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] = x.y;
-            if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] = x.z;
-            if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = x.w;
-          }
+        for (int v4 = 0; v4 < (NVAL + 3) / 4; ++v4) {
+          const float4 x = row[v4];
+          if (4 * v4 + 0 < NVAL) acc[4 * v4 + 0] = has_rows ? x.x : 0.f;
+          if (4 * v4 + 1 < NVAL) acc[4 * v4 + 1] = has_rows ? x.y : 0.f;
+          if (4 * v4 + 2 < NVAL) acc[4 * v4 + 2] = has_rows ? x.z : 0.f;
+          if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = has_rows ? x.w : 0.f;
         }
       }
     } else if (ntiles_g > 0 && !frame_unusable(counters)) {
