@@ -285,13 +285,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
     int ellipse, int act, u32* __restrict__ rect_partials, u32* __restrict__ count_partials,
-    uint4* __restrict__ sync_words, int sync_quads, const float* __restrict__ depth_cut) {
+    uint4* __restrict__ sync_words, int sync_quads, const float* __restrict__ depth_cut, uint8_t* __restrict__ blended) {
   __shared__ u32 s_area[4], s_cnt[4];
   __shared__ PreWaveLds s_rows[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   // the words the frame's fused kernels synchronise through (tickets, digit histograms, published block counts):
   // zeroed here, at the head of the frame, by as many threads as there are 16-byte pieces
   if (idx < sync_quads) sync_words[idx] = make_uint4(0u, 0u, 0u, 0u);
+  if (idx < P) blended[idx] = 0;  // set by the forward composite for a Gaussian that blends anywhere (olsr_state.h)
   u32 area = 0, count = 0;
   PendingRows pend;
   pend.nrows = 0;
@@ -332,7 +333,7 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
       g.emit_rec, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
       s.activations | (s.flags << 16), g.part_rect, g.part_count, reinterpret_cast<uint4*>(g.sync_words), sync_quads,      \
-      ((s.binning == OLSR_BINNING_ELLIPSE) ? s.tile_depth_cut : nullptr)
+      ((s.binning == OLSR_BINNING_ELLIPSE) ? s.tile_depth_cut : nullptr), g.blended
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float* __restrict__ dL_dtau, float* __restrict__ tau_partials, float* __restrict__ bucket_flat,
     float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign, int act,
     const float* __restrict__ opacities_raw, int F_out, u64* __restrict__ bucket_row_mask, float* gacc_park,
-    u32* __restrict__ act_list, u32* __restrict__ act_count) {
+    u32* __restrict__ act_list, u32* __restrict__ act_count, const uint8_t* __restrict__ blended) {
   // F: language channels of the partial-gradient rows; F_out: the scene's (width of dL_dlanguage and of the bucket's
   // language columns).  F == 0 < F_out: the backward ran without a language cotangent, those gradients are zero.
   constexpr int ROW = grad_row(F);
@@ -544,7 +544,9 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float acc[NVAL];
 #pragma unroll
     for (int v = 0; v < NVAL; ++v) acc[v] = 0.f;
-    const u32 ntiles_g = vis ? tiles_touched[idx] : 0u;  // (a Gaussian listed in no tile has no rows: all zeros)
+    // (a Gaussian listed in no tile, or one no pixel blended — 98 % of the visible ones behind the saturation depth —, has no
+    //  rows: all zeros, and the dependent look-ups below — emission index, two ends of its run of rows — are not made for it)
+    const u32 ntiles_g = (vis && blended[idx] != 0) ? tiles_touched[idx] : 0u;
     if (ntiles_g > OLSR_MID_FOOTPRINT) {
       if (!frame_unusable(counters)) {  // summed by row_reduce_big_kernel
         // (looked up since the chain below is skipped without rows: a large footprint behind the saturation depth has none)
@@ -975,7 +977,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
     int32_t* total = &g.counters[10];
     preprocess_bwd_kernel<F, true><<<nb, PB_THREADS, bucket_lds, st>>>(
         OLSR_PB_ARGS, nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign, s.activations,
-        s.opacities, F_out, o.bucket_row_mask, g.gacc, act_list, act_count);
+        s.opacities, F_out, o.bucket_row_mask, g.gacc, act_list, act_count, g.blended);
     pb_compact_kernel<<<1, PC_THREADS, 0, st>>>(nb, act_count, act_list, compact, total);
     n_partials = std::min(nb, 256);
     pb_chain_kernel<<<n_partials, CH_THREADS, 0, st>>>(
@@ -987,7 +989,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
 #else
   preprocess_bwd_kernel<F, false><<<nb, PB_THREADS, bucket_lds, st>>>(
       OLSR_PB_ARGS, o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii,
-      o.bucket_assign, s.activations, s.opacities, F_out, o.bucket_row_mask, nullptr, nullptr, nullptr);
+      o.bucket_assign, s.activations, s.opacities, F_out, o.bucket_row_mask, nullptr, nullptr, nullptr, g.blended);
 #endif
 #undef OLSR_PB_ARGS
   if (o.dL_dtau_sum)

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     float* __restrict__ out_opacity, int32_t* __restrict__ n_touched, uint8_t* __restrict__ flags,
     u32* __restrict__ tile_work, const u32* __restrict__ order_hint, const int32_t* __restrict__ counters,
     const u32* __restrict__ hint_slot, float* __restrict__ depth_cut, int32_t* __restrict__ cut_miss,
-    const FusedLossArgs fl) {
+    uint8_t* __restrict__ blended, const FusedLossArgs fl) {
   // a radix pass of this frame lost a predecessor's counts (olsr_state.h, counters[8]): the lists are garbage and must not be
   // used as indices — render nothing; the tile-order kernel behind this one reports OLSR_STATUS_SYNC_ERROR
   if (counters[8] != 0) return;
@@ -330,7 +330,10 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
         // bits 0-3: forward slots that blended it; bits 4-5: backward waves of the reference-mode survivors
         fl = ((hit.x >> 15) & 1u) | ((hit.x >> 30) & 2u) | ((hit.y >> 13) & 4u) | ((hit.y >> 28) & 8u);
         cl2 = ((hit.x >> 8) | (hit.x >> 24) | (hit.y >> 8) | (hit.y >> 24)) & 3u;
-        if (fl) flags[s_src[tid]] = (uint8_t)(fl | (cl2 << 4));
+        if (fl) {
+          flags[s_src[tid]] = (uint8_t)(fl | (cl2 << 4));
+          blended[s_id[tid]] = 1;  // (every writer stores the same byte: the per-Gaussian backward looks rows up only for these)
+        }
         const u32 tc = (hit.x & 0x7Fu) + ((hit.x >> 16) & 0x7Fu) + (hit.y & 0x7Fu) + ((hit.y >> 16) & 0x7Fu);
         if (tc) atomicAdd(&n_touched[s_id[tid]], (int)tc);
       }
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
   im.ranges, im.ranges, b.inst_gid, b.src, d.W, d.H, d.gx, d.ntiles, g.means2D, g.conic_opacity, g.depths, colors,     \
       s.language_precomp, s.background, im.final_T, im.n_contrib, out_color, out_language, out_depth, out_opacity,     \
       n_touched, b.flags, im.tile_work, order_inout, g.counters, hint_slot,                                             \
-      (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), &g.counters[9]
+      (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), &g.counters[9], g.blended
 
 #if OLSR_FWD_TU_LOSS == 0
 template <int TILE, int F>

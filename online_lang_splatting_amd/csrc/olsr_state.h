@@ -121,6 +121,8 @@ struct GeometryState {
   float* cov3D;           // [P][6]
   float* rgb;             // [P][3]
   uint8_t* clamped;       // [P][3]
+  uint8_t* blended;       // [P] 1 = some pixel blended some instance of the Gaussian in this frame's forward (zeroed by
+                          //     preprocess, set by the forward composite's flush): only those can have gradient rows
   uint32_t* tiles_touched;  // [P] instances the Gaussian emits (rect area, or the exact tile count)
   float4* emit_rec;       // [P][2] everything the emission needs about a Gaussian in ONE 32-byte gather (it runs in
                           //     depth order): {mean x, mean y, conic a, conic b}, {conic c, cull t2, radius, #instances}
@@ -163,6 +165,7 @@ struct GeometryState {
     g.cov3D = c.take<float>(6 * P);
     g.rgb = c.take<float>(3 * P);
     g.clamped = c.take<uint8_t>(3 * P);
+    g.blended = c.take<uint8_t>(P);
     g.tiles_touched = c.take<uint32_t>(P);
     g.emit_rec = c.take<float4>(2 * P);
     g.key_a = c.take<uint32_t>(P);
