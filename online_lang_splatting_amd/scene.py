@@ -190,3 +190,201 @@ def make_config_scene(cfg, seed=None, P=None):
         c["P"] = P
     return make_scene(c["P"], c["W"], c["H"], c["F"], seed=cfg if seed is None else seed,
                       max_sh_degree=c["max_sh_degree"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A surface-structured map: what BASELINE.json configs[3] (the Replica `slam.py` loop) renders, as far as it can be built
+# without Replica data.  The generator of SURVEY 8(d) above fills a VOLUME with i.i.d. Gaussians: saturation ends 87 % of
+# every tile list and 98 % of the Gaussians receive no gradient.  A SLAM map is one surface layer deep.  make_room_scene
+# builds such a map the way the reference's back end does (gaussian_splatting/scene/gaussian_model.py:180-281):
+#   for every keyframe: the depth image is back-projected with the keyframe's pose (create_from_rgbd_image + extrinsic),
+#   randomly down-sampled by pcd_downsample_init = 32 (first keyframe) / pcd_downsample = 64
+#   (configs/rgbd/replicav2/base_config.yaml:11-12); colours -> RGB2SH into f_dc, f_rest = 0; scale = sqrt(distCUDA2(points
+#   of THIS keyframe) clamped at 1e-7, times point_size) with point_size = min(0.05, 0.05 * median depth)
+#   (adaptive_pointsize, :199-203, :252-263), the same value on the three axes (isotropic = False -> repeat(1, 3));
+#   rotation = identity quaternion; opacity = 0.5 (:268-275).
+# The depth images are ray-cast from a closed box room of Replica scale with a few pieces of box furniture; the keyframes
+# stand on a loop inside the room, looking outwards, close enough together for ten neighbours to overlap (the window of
+# BackEnd.map, utils/slam_backend.py:499-670).  Language codes are unit-norm (the auto-encoder's codes are,
+# language/autoencoder/model.py:52-56): one code per surface, a little noise per Gaussian.
+C0_SH = 0.28209479177387814  # RGB2SH, gaussian_splatting/utils/sh_utils.py:114-118
+
+ROOM_HALF = (3.5, 1.4, 2.5)  # half extents in metres, x right / y down / z forward: a 7.0 x 2.8 x 5.0 m room
+# furniture: axis-aligned boxes (lo, hi) standing on the floor (y = +1.4) or hanging on a wall
+ROOM_BOXES = (((-3.3, 0.55, 1.2), (-1.9, 1.4, 2.3)),     # sofa
+              ((-0.8, 0.65, -0.5), (0.9, 0.72, 0.6)),      # table top
+              ((-0.75, 0.72, -0.45), (-0.65, 1.4, -0.35)),  # table legs
+              ((0.75, 0.72, -0.45), (0.85, 1.4, -0.35)),
+              ((-0.75, 0.72, 0.45), (-0.65, 1.4, 0.55)),
+              ((0.75, 0.72, 0.45), (0.85, 1.4, 0.55)),
+              ((2.6, -0.6, -2.4), (3.4, 1.4, -1.2)),       # cabinet
+              ((1.2, 0.9, 1.6), (2.0, 1.4, 2.4)),          # stool
+              ((-1.0, -0.9, 2.42), (1.0, 0.3, 2.5)))       # picture on the far wall
+
+
+def _raycast_room(cam: "Camera", W: int, H: int):
+    """z-depth [H, W], hit point in the world [H, W, 3] and surface id [H, W] (0..5 the room's faces, 6 + 6 b + face for box
+    b) seen by `cam` at resolution W x H (the intrinsics are scaled from the camera's own resolution)."""
+    f64 = torch.float64
+    sx, sy = W / cam.width, H / cam.height
+    fx, fy = cam.fx * sx, cam.fy * sy
+    cx, cy = (cam.cx + 0.5) * sx - 0.5, (cam.cy + 0.5) * sy - 0.5
+    R, T = cam.R.to(f64), cam.T.to(f64)
+    c = -(R.t() @ T)                                       # camera centre in the world
+    v, u = torch.meshgrid(torch.arange(H, dtype=f64), torch.arange(W, dtype=f64), indexing="ij")
+    d_cam = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], dim=-1)
+    d = d_cam @ R                                          # R^T d_cam, row-vector form: z-depth = ray parameter
+    eps = 1e-12
+    d = torch.where(d.abs() < eps, torch.full_like(d, eps), d)
+    half = torch.tensor(ROOM_HALF, dtype=f64)
+    # the room, from the inside: the nearest of the three walls the ray points at
+    t_ax = (torch.where(d > 0, half, -half) - c) / d
+    t, ax = t_ax.min(dim=-1)
+    sid = 2 * ax + (torch.gather(d, -1, ax.unsqueeze(-1)).squeeze(-1) > 0).long()
+    for b, (lo, hi) in enumerate(ROOM_BOXES):              # boxes, from the outside: slab test
+        lo_, hi_ = torch.tensor(lo, dtype=f64), torch.tensor(hi, dtype=f64)
+        t1, t2 = (lo_ - c) / d, (hi_ - c) / d
+        tn, tf = torch.minimum(t1, t2), torch.maximum(t1, t2)
+        t_in, ax_in = tn.max(dim=-1)
+        t_out = tf.min(dim=-1).values
+        hit = (t_out >= t_in) & (t_in > 1e-6) & (t_in < t)
+        t = torch.where(hit, t_in, t)
+        sid = torch.where(hit, 6 + 6 * b + 2 * ax_in + (torch.gather(d, -1, ax_in.unsqueeze(-1)).squeeze(-1) > 0).long(), sid)
+    hitp = c + t.unsqueeze(-1) * d
+    return t.to(torch.float32), hitp.to(torch.float32), sid
+
+
+def _room_colour(hitp, sid):
+    """A procedural texture in [0, 1]: one base colour per surface, modulated by a 0.5 m checker and a fine sinusoid."""
+    n_s = 6 + 6 * len(ROOM_BOXES)
+    g = torch.Generator().manual_seed(77)
+    base = 0.25 + 0.6 * torch.rand(n_s, 3, generator=g)
+    p = hitp.to(torch.float64)
+    checker = ((torch.floor(p[..., 0] * 2) + torch.floor(p[..., 1] * 2) + torch.floor(p[..., 2] * 2)) % 2)
+    fine = 0.5 + 0.5 * torch.sin(23.0 * p[..., 0] + 17.0 * p[..., 1] + 29.0 * p[..., 2])
+    rgb = base[sid] * (0.75 + 0.2 * checker.unsqueeze(-1).to(torch.float32)) + 0.08 * (fine.unsqueeze(-1).to(torch.float32) - 0.5)
+    return rgb.clamp(0.0, 1.0)
+
+
+def _surface_codes(F, seed=78):
+    n_s = 6 + 6 * len(ROOM_BOXES)
+    g = torch.Generator().manual_seed(seed)
+    c = torch.randn(n_s, F, generator=g)
+    return c / c.norm(dim=1, keepdim=True)
+
+
+def knn_mean_dist2_host(points: torch.Tensor) -> torch.Tensor:
+    """distCUDA2 (submodules/simple-knn/simple_knn.cu:185-221) for the scene GENERATOR on a host without a GPU: an exact k-d
+    tree finds the neighbours, the distances use the library kernel's pinned expression d = fma(dz, dz, fma(dy, dy, dx dx)),
+    mean = ((d0 + d1) + d2) / 3 — the same bits olsr_knn_mean_dist2 returns (tests/test_gpu_knn.py).  Workload plumbing, not a
+    product path: the product's distCUDA2 is GPU only."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    x = points.detach().cpu().to(torch.float32).numpy()
+    n = x.shape[0]
+    if n < 4:
+        raise ValueError("knn_mean_dist2_host needs at least four points")
+    k = min(n, 8)  # self + 7: margin for ties at fp32 resolution
+    _, idx = cKDTree(x.astype(np.float64)).query(x.astype(np.float64), k=k)
+    d = x[idx[:, 1:]] - x[:, None, :]
+    d2 = np.float32(d[..., 0] * d[..., 0])
+    d2 = np.float32(np.float64(d[..., 1]) * np.float64(d[..., 1]) + np.float64(d2))
+    d2 = np.float32(np.float64(d[..., 2]) * np.float64(d[..., 2]) + np.float64(d2))
+    d2.sort(axis=1)
+    return torch.from_numpy((((d2[:, 0] + d2[:, 1]) + d2[:, 2]) / np.float32(3.0)).astype(np.float32))
+
+
+def room_keyframe_cameras(W, H, n, radius=0.9, height=0.1):
+    """n keyframe poses on a loop of `radius` metres around the room's centre, `height` metres below it, each looking
+    outwards along its radius (yaw = 360 k / n degrees); fx = fy = W / 2 as in default_camera (Replica: 600 at W = 1200)."""
+    cams = []
+    for k in range(n):
+        a = 2.0 * math.pi * k / n
+        # camera z axis (forward) in the world: (sin a, 0, cos a); W2C rotation about y by -a ... written out
+        R = torch.tensor([[math.cos(a), 0.0, -math.sin(a)], [0.0, 1.0, 0.0], [math.sin(a), 0.0, math.cos(a)]])
+        c = torch.tensor([radius * math.sin(a) * ROOM_HALF[0] / 3.5, height, radius * math.cos(a) * ROOM_HALF[2] / 3.5])
+        cams.append(Camera(W, H, W / 2.0, W / 2.0, (W - 1) / 2.0, (H - 1) / 2.0, R, -(R @ c)))
+    return cams
+
+
+@dataclass
+class RoomScene:
+    """make_room_scene's result: the map (`scene`, whose camera is the window's first view), the window's cameras, and per
+    view the ray-cast targets a mapping iteration fits (gt_image [3,H,W], gt_depth [H,W], gt_language [F,192,192] or None)."""
+    scene: Scene
+    cameras: list
+    targets: list
+    keyframes: int
+    points_per_keyframe: list
+
+    def view(self, v) -> Scene:
+        s = self.scene
+        return Scene(self.cameras[v], s.means3D, s.opacities, s.scales, s.rotations, s.shs, s.language, s.sh_degree, s.bg, s.F)
+
+
+def make_room_scene(P=500_000, W=1200, H=680, F=15, views=10, seed=0, max_sh_degree=0, knn=None, lang_size=192,
+                    window_start=0):
+    """About P Gaussians (exactly P when the keyframes supply enough) built keyframe by keyframe as the reference's back end
+    builds its map, and `views` consecutive keyframe poses to render it from.  `knn`: points [n,3] (CPU float32) -> mean
+    squared distance to the three nearest neighbours [n]; default: the library's olsr_knn_mean_dist2 when a GPU is present,
+    else knn_mean_dist2_host (bit-identical, tests/test_gpu_room_scene.py)."""
+    if knn is None:
+        if torch.cuda.is_available():
+            from .simple_knn import distCUDA2
+
+            def knn(p):
+                return distCUDA2(p.cuda()).cpu()
+        else:
+            knn = knn_mean_dist2_host
+    g = torch.Generator().manual_seed(seed)
+    N = W * H
+    n_first, n_next = N // 32, N // 64                     # pcd_downsample_init / pcd_downsample
+    K = 1 if P <= n_first else 1 + -(-(P - n_first) // max(n_next, 1))
+    K = max(K, views)
+    kcams = room_keyframe_cameras(W, H, K)
+    codes = _surface_codes(F) if F > 0 else None
+    xyz, rgb, scl, lang, per_kf = [], [], [], [], []
+    left = P
+    for k, cam in enumerate(kcams):
+        if left <= 0:
+            break
+        depth, hitp, sid = _raycast_room(cam, W, H)
+        col = _room_colour(hitp, sid)
+        # create_from_rgbd_image(..., extrinsic = W2C): x = (u - cx) z / fx, y = (v - cy) z / fy, then C2W
+        v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        pc = torch.stack([(u - cam.cx) * depth / cam.fx, (v - cam.cy) * depth / cam.fy, depth], dim=-1).reshape(-1, 3)
+        pw = (pc - cam.T) @ cam.R                          # R^T (p - T)
+        n_take = min(n_first if k == 0 else n_next, left)  # random_down_sample(1 / factor)
+        pick = torch.randperm(N, generator=g)[:n_take]
+        pts = pw[pick].contiguous()
+        point_size = min(0.05, 0.05 * float(depth.median()))
+        d2 = torch.clamp_min(knn(pts), 1e-7) * point_size
+        xyz.append(pts)
+        rgb.append(col.reshape(-1, 3)[pick])
+        scl.append(torch.sqrt(d2))
+        if F > 0:
+            l = codes[sid.reshape(-1)[pick]] + 0.1 * torch.randn(n_take, F, generator=g)
+            lang.append(l / l.norm(dim=1, keepdim=True))
+        per_kf.append(n_take)
+        left -= n_take
+    means3D = torch.cat(xyz).contiguous()
+    n = means3D.shape[0]
+    M = (max_sh_degree + 1) ** 2
+    shs = torch.zeros(n, M, 3)
+    shs[:, 0, :] = (torch.cat(rgb) - 0.5) / C0_SH          # RGB2SH
+    scales = torch.cat(scl).unsqueeze(1).repeat(1, 3).contiguous()
+    rotations = torch.zeros(n, 4)
+    rotations[:, 0] = 1.0
+    opacities = torch.full((n, 1), 0.5)
+    language = torch.cat(lang).contiguous() if F > 0 else None
+    window = [kcams[(window_start + i) % K] for i in range(views)]
+    targets = []
+    for cam in window:
+        depth, hitp, sid = _raycast_room(cam, W, H)
+        gt_lang = None
+        if F > 0:
+            _, _, sid_l = _raycast_room(cam, lang_size, lang_size)
+            gt_lang = codes[sid_l].permute(2, 0, 1).contiguous()
+        targets.append((_room_colour(hitp, sid).permute(2, 0, 1).contiguous(), depth.contiguous(), gt_lang))
+    sc = Scene(window[0], means3D, opacities, scales, rotations, shs.contiguous(), language, 0, torch.zeros(3), F)
+    return RoomScene(sc, window, targets, len(per_kf), per_kf)
