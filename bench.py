@@ -21,7 +21,8 @@ one frame overlaps the compute of the next.  The timed region still issues exact
 RCCL; fewer GPUs than ranks is an error, OLSR_BENCH_BACKEND=gloo shares devices for functional checks).  `--exchange
 {sparse,all_reduce,reduce_scatter}` picks how the shared-Gaussian gradients travel; sparse (default) exchanges only the rows
 that are non-zero on some rank, capacity-bound and without a host synchronisation.  The contract's K-step region is run
-`--repeats` (5) times back to back: `value` is the median run, `value_runs` lists all of them.
+`--repeats` times back to back (default: until the timed regions total `--min-timed-s` = 2 s): `value` is the median run,
+`config.value_runs` lists all of them.  `--scene room` runs the same legs on the surface-structured map of scene.make_room_scene.
 
 Rank 0 prints ONE JSON line.  `non_coherent`: the camera changes every step.  `isolated` repeats the measurement with ONE frame in flight: there the
 intervals between the library's HIP events (recorded on the launch stream) ARE the kernel durations, whereas
@@ -212,6 +213,211 @@ def cpu_baseline(sc, seed, gpu=None, budget_s=12.0, max_frames=16, single_thread
         res["single_thread"] = {"value": round(1.0 / d1, 5), "unit": "frames/s", "cores": 1,
                                 "sample": f"1 full frame of the same workload, {d1:.2f} s wall"}
     return res
+
+
+def workload_stats(ws, sc_P, W, H, F, tile=15):
+    """What the frame on workspace `ws` (already rendered, synchronised here) looked like to the rasterizer: the reference's
+    instance count R (bounding squares), the instances the exact binning kept, visible Gaussians, Gaussians some pixel blended,
+    and how far the tile lists were READ: sum over tiles of the deepest list position any pixel of the tile blended
+    (max n_contrib) / sum of the list lengths — saturation ends a list early, a surface map reads it to the end."""
+    from online_lang_splatting_amd import _C
+    torch.cuda.synchronize(ws.device)
+    Rb, _ = ws.rendered()
+    cnt = _C.state_field("geometry", ws.geom, "counters", P=sc_P, F=F, dtype=torch.int32, count=8).cpu()
+    nc = _C.state_field("image", ws.img, "n_contrib", W=W, H=H, dtype=torch.int32, count=W * H).view(H, W)
+    tx, ty = (W + tile - 1) // tile, (H + tile - 1) // tile
+    pad = torch.zeros(ty * tile, tx * tile, dtype=torch.int32, device=nc.device)
+    pad[:H, :W] = nc
+    deepest = pad.view(ty, tile, tx, tile).amax(dim=(1, 3)).to(torch.int64)
+    rg = _C.state_field("image", ws.img, "ranges", W=W, H=H, dtype=torch.int32, count=2 * tx * ty).view(-1, 2).to(torch.int64)
+    lens = rg[:, 1] - rg[:, 0]
+    bl = _C.state_field("geometry", ws.geom, "blended", P=sc_P, F=F, dtype=torch.uint8, count=sc_P)
+    vis = int((ws.out["radii"] > 0).sum())
+    return {"R": int(cnt[3]), "R_over_P": round(int(cnt[3]) / max(sc_P, 1), 3), "R_binned": int(Rb),
+            "R_binned_over_R": round(int(Rb) / max(int(cnt[3]), 1), 4), "visible_gaussians": vis,
+            "visible_fraction": round(vis / max(sc_P, 1), 4), "blended_gaussians": int((bl != 0).sum()),
+            "blended_of_visible": round(int((bl != 0).sum()) / max(vis, 1), 4),
+            "mean_list_length": round(float(lens.double().mean()), 1),
+            "list_fraction_read_before_saturation": round(float(deepest.sum()) / max(float(lens.sum()), 1.0), 4),
+            "pixels_saturated_fraction": round(float((ws.out["opacity"] > 1.0 - 1e-4).float().mean()), 4)
+            if ws.out["opacity"].numel() else None}
+
+
+def choose_exchange(union_rows, P, width):
+    """The step's exchange, from the data: the capacity-bound sparse exchange moves 8 P bytes of
+    flags and radii, 8 P bytes of densification statistics and 1.25 x the union's rows; the dense two-phase exchange moves
+    the bucket (P x width floats + the statistics + the radii).  Sparse only when it is the smaller payload."""
+    cap = min(P, int(1.25 * union_rows) + 4096)
+    sparse_bytes = 8 * P + (cap * width + 2 * P) * 4
+    dense_bytes = (P * width + 2 * P) * 4 + 4 * P
+    return ("sparse" if sparse_bytes < dense_bytes else "reduce_scatter"), cap, sparse_bytes, dense_bytes
+
+
+def room_scene_leg(dev, dims, steps, seed=3):
+    """config4_substitute.room_scene: BASELINE configs[3] is blocked in this image, and every other
+    number of this line is measured on SURVEY 8(d)'s i.i.d. VOLUME of Gaussians, where saturation ends 87 % of every tile list
+    and 98 % of the Gaussians receive no gradient.  A SLAM map is one surface layer deep.  scene.make_room_scene builds one the
+    way the reference's back end does (gaussian_splatting/scene/gaussian_model.py:180-281) from ray-cast keyframes of a closed
+    box room, ~P Gaussians; this leg renders the 10-keyframe window + 2 random keyframes of BackEnd.map against it and reports
+    the same quantities as the headline: workload shape, stage times, frames/s (one and four frames in flight, coherent and
+    cycling through the views), the tracking and the mapping iteration, and what the round-3/4 optimisations are worth here."""
+    from online_lang_splatting_amd.frame_shard import FrameLanes, GradientBucket, GradLayout, RasterWorkspace
+    from online_lang_splatting_amd.scene import make_room_scene
+    from online_lang_splatting_amd.slam_iterations import MappingStep, PoseState, TrackingLoop
+    P, W, H, F, M = dims
+    t_build = time.perf_counter()
+    rs = make_room_scene(P, W, H, F, views=10, random_views=2, seed=seed)
+    t_build = time.perf_counter() - t_build
+    sc = rs.scene
+    g_dev, _ = device_inputs(sc, rs.cameras[0], dev)
+    camd = [device_inputs(sc, c_, dev)[1] for c_ in rs.cameras]
+    dc, dl, dd = [None if t is None else t.to(dev) for t in sc.cotangents(seed)]
+    cfg0 = (15, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE)
+    R0 = max(_sized_capacity(F, g_dev, c_, H, W, 0, dev, cfg0) for c_ in camd)
+    cap = int(1.5 * R0) + (1 << 16)
+    out = {"what": f"{sc.P} Gaussians of {rs.keyframes} ray-cast keyframes of a 7.0 x 2.8 x 5.0 m box room with furniture, built by "
+                   "the reference's recipe (depth back-projection, pcd_downsample 32 / 64, scale = sqrt(distCUDA2 x point_size) "
+                   "through olsr_knn_mean_dist2, identity rotations, opacity 0.5, unit-norm language codes), rendered from the "
+                   "10-keyframe window + 2 random keyframes",
+           "P": sc.P, "keyframes": rs.keyframes, "width": W, "height": H, "F": F, "views": len(camd),
+           "scene_build_s": round(t_build, 2)}
+    lanes = FrameLanes(4, sc.P, W, H, F, M, cap, dev)
+
+    def step(lane, cam_):
+        ws_, bucket_, stream_ = lane
+        with torch.cuda.stream(stream_):
+            ws_.set_scene(sh_degree=0, **cam_, **g_dev)
+            ws_.forward()
+            ws_.backward(dc, dl, dd, bucket=bucket_, first=True, bucket_only=True)
+
+    def rate(n, pick_lane, pick_cam, warm=8):
+        for i in range(warm):
+            step(pick_lane(), pick_cam(i))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(pick_lane(), pick_cam(i))
+        torch.cuda.synchronize(dev)
+        return n / (time.perf_counter() - t0)
+    lane0 = lanes.lanes[0]
+    n = max(steps, 20)
+    out["isolated"] = {"value": round(rate(n, lambda: lane0, lambda i: camd[0]), 1), "unit": "frames/s", "frames_in_flight": 1}
+    out["four_in_flight"] = {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[0], warm=40), 1), "unit": "frames/s",
+                             "same_view_every_step": True}
+    out["four_in_flight_cycling_12_views"] = {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[i % len(camd)], warm=48), 1),
+                                              "unit": "frames/s", "same_view_every_step": False}
+    out["isolated_cycling_12_views"] = {"value": round(rate(n, lambda: lane0, lambda i: camd[i % len(camd)], warm=24), 1),
+                                        "unit": "frames/s"}
+    # stage times, one frame in flight (events between the stages)
+    for _ in range(3):
+        step(lane0, camd[0])
+    torch.cuda.synchronize(dev)
+    _lib.set_profiling(True)
+    for _ in range(10):
+        step(lane0, camd[0])
+    per = {}
+    for name, ms in _lib.stage_times():
+        per.setdefault(name, []).append(ms)
+    _lib.set_profiling(False)
+    out["stage_ms"] = {k: round(sum(v) / len(v), 4) for k, v in per.items()}
+    out["stage_ms_sum"] = round(sum(out["stage_ms"].values()), 4)
+    ws0, b0 = lane0[0], lane0[1]
+    st = workload_stats(ws0, sc.P, W, H, F)
+    live = int((b0.flat != 0).any(dim=1).sum())
+    L_rows, row_ovf = ws0.backward_status()
+    st.update({"live_gradient_rows_gaussians": live, "live_rows_of_P": round(live / sc.P, 4),
+               "live_rows_of_visible": round(live / max(st["visible_gaussians"], 1), 4), "gradient_rows_L": L_rows,
+               "capacity_overflow": bool(ws0.rendered()[1] or row_ovf)})
+    out["workload"] = st
+    model = algorithmic_bytes(sc.P, st["R_binned"], W * H, 3, F, M)
+    out["frame_model"] = {"algorithmic_bytes": int(model["frame"]),
+                          "frac_of_8TBs_four_in_flight": round(model["frame"] * out["four_in_flight"]["value"] / 1e9 / HBM_PEAK_GBS, 4),
+                          "frac_of_8TBs_isolated": round(model["frame"] * out["isolated"]["value"] / 1e9 / HBM_PEAK_GBS, 4)}
+    # the union of the gradient rows over the 12 views of a mapping iteration, and what the run-time rule makes of it
+    union = torch.zeros(sc.P, dtype=torch.bool, device=dev)
+    for c_ in camd:
+        step(lane0, c_)
+        union |= (b0.flat != 0).any(dim=1)
+    torch.cuda.synchronize(dev)
+    width = 11 + 3 * M + F
+    choice, cap_rows, sp_b, de_b = choose_exchange(int(union.sum()), sc.P, width)
+    out["exchange"] = {"union_rows_over_12_views": int(union.sum()), "union_of_P": round(int(union.sum()) / sc.P, 4),
+                       "rows_one_view": live, "sparse_payload_bytes": sp_b, "dense_payload_bytes": de_b, "chosen": choice,
+                       "rule": "sparse iff 8 P + (1.25 x union rows x width + 2 P) x 4 bytes < the dense bucket + statistics + radii"}
+    # what the round-3/4 optimisations are worth on a surface: A/B, one frame in flight
+    ab = {}
+    for name, kw, track in (("default", {}, True), ("no_row_mask", {}, False),
+                            ("rect_binning", {"binning": _abi.BINNING_RECT}, True)):
+        capn = cap if not kw else int(1.5 * max(_sized_capacity(F, g_dev, camd[0], H, W, 0, dev, (15, _abi.BWD_REFERENCE, _abi.BINNING_RECT)), R0)) + (1 << 16)
+        ws_ = RasterWorkspace(sc.P, W, H, F, M, capn, dev, **kw)
+        bk_ = GradientBucket(sc.P, GradLayout(M, F), dev, track_rows=track)
+        lane_ = (ws_, bk_, torch.cuda.current_stream(dev))
+        ab[name] = round(rate(n, lambda: lane_, lambda i: camd[0]), 1)
+        del ws_, bk_, lane_
+    out["ab_isolated_fps"] = dict(ab, note="no_row_mask: the bucket overwrite stores all P rows (round-4 row mask off); rect_binning: "
+                                           "the reference's bounding-square lists instead of the exact ellipse lists; the `blended` "
+                                           "byte cannot be switched off at run time - its effect is bounded by blended_of_visible")
+    # tracking iteration against the ray-cast frame of view 0, from a pose a few cm off (as in config4_substitute.tracking)
+    cam0 = rs.cameras[0]
+    T_gt = torch.eye(4)
+    T_gt[:3, :3], T_gt[:3, 3] = cam0.R, cam0.T
+    T_gt = T_gt.to(dev)
+    pose = PoseState(T_gt, cam0.projection_matrix.to(dev), cam0.tanfovx, cam0.tanfovy)
+    tau0 = torch.tensor([0.02, -0.015, 0.01, 0.004, -0.006, 0.003])
+    th = tau0[3:]
+    Wm = torch.tensor([[0.0, -th[2], th[1]], [th[2], 0.0, -th[0]], [-th[1], th[0], 0.0]])
+    dT = torch.eye(4)
+    dT[:3, :3] = torch.eye(3) + Wm + 0.5 * Wm @ Wm
+    dT[:3, 3] = tau0[:3]
+    T0 = (dT.to(dev) @ T_gt).contiguous()
+    gt_image, gt_depth = rs.targets[0][0].to(dev), rs.targets[0][1].to(dev)
+    trk = {}
+    for fused in (True, False):
+        pose.reset(T0)
+        loop = TrackingLoop(ws0, g_dev, 0, pose, gt_image, gt_depth, language_cotangent="null", fused_loss=fused)
+        for _ in range(5):
+            loop.iteration()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(60):
+            loop.iteration()
+        torch.cuda.synchronize(dev)
+        trk["fused_loss" if fused else "two_kernel_loss"] = round(1e3 * (time.perf_counter() - t0) / 60, 4)
+    out["tracking"] = {"ms_per_iteration": trk, "iterations": 60,
+                       "pose_error_start": round(float((T0 - T_gt).abs().max()), 6),
+                       "pose_error_after": round(float((pose.T_w2c - T_gt).abs().max()), 6)}
+    # mapping iteration: the 12 views against their ray-cast targets, raw parameters, four views in flight
+    params = dict(means3D=g_dev["means3D"].clone(), shs=g_dev["shs"].clone(),
+                  opacities=torch.logit(g_dev["opacities"].clamp(1e-4, 1 - 1e-4)).contiguous(),
+                  scales=torch.log(g_dev["scales"]).contiguous(), rotations=g_dev["rotations"].clone(),
+                  language=None if F == 0 else g_dev["language"].clone())
+    start = {k: (None if v is None else v.clone()) for k, v in params.items()}
+    lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
+    mp = {}
+    for fused in (True, False):
+        for k, v in params.items():
+            if v is not None:
+                v.copy_(start[k])
+        stp = MappingStep(lanes, params, g_dev["bg"], 0, camd, rs.targets, lrs, exposure=torch.zeros(2, device=dev),
+                          fused_loss=fused)
+        stp.iteration()
+        first = float(stp.last_loss[0])
+        stp.iteration()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            stp.iteration()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        mp["fused_loss" if fused else "two_kernel_loss"] = {
+            "ms_per_iteration": round(1e3 * el / 6, 3), "views_per_s": round(len(camd) * 6 / el, 1),
+            "loss_last_view_first_iteration": round(first, 6), "loss_last_view_final_iteration": round(float(stp.last_loss[0]), 6),
+            "capacity_overflow": bool(any(w_.rendered()[1] or w_.backward_status()[1] for w_, _, _ in lanes.lanes))}
+        del stp
+    out["mapping"] = dict(mp, views=len(camd), views_in_flight=len(lanes))
+    del lanes
+    torch.cuda.empty_cache()
+    return out
 
 
 def dropin_leg(sc, dev, steps, warmup):
@@ -685,8 +891,17 @@ def main():
     ap.add_argument("--rank-view", default="", help="K,N[,arc]: with one rank, render what rank K of an N-GPU run renders instead of "
                                                     "the identity pose (the per-rank cost of a weak-scaling point); ',arc': "
                                                     "pose K of the N-pose arc of the mapping mode")
-    ap.add_argument("--repeats", type=int, default=5,
-                    help="how many times the contract's K-step region is run; the value is the median run (all in value_runs)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how many times the contract's K-step region is run; the value is the median run (all in "
+                         "config.value_runs).  0 (default): as many as it takes for the timed regions to total --min-timed-s "
+                         "seconds (at least 5)")
+    ap.add_argument("--min-timed-s", type=float, default=2.0,
+                    help="with --repeats 0: repeat the K-step region until the timed regions total this many seconds, so that "
+                         "the GPU is visibly busy to an outside sampler (the K = 20 region alone lasts 9 ms)")
+    ap.add_argument("--scene", default="volume", choices=["volume", "room"],
+                    help="volume (default): SURVEY 8(d)'s i.i.d. Gaussians, the BASELINE workload; room: the surface-structured "
+                         "map of scene.make_room_scene (a SLAM map by the reference's recipe) at the config's size, rank r "
+                         "rendering keyframe r of the mapping window")
     ap.add_argument("--setup-steps", type=int, default=40, help="untimed frames before the W warm-up steps (steady state)")
     ap.add_argument("--isolated-steps", type=int, default=30, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
@@ -740,7 +955,15 @@ def main():
 
     cfg = CONFIGS[a.config]
     P, W, H, F = cfg["P"], cfg["W"], cfg["H"], cfg["F"]
-    sc = make_scene(P, W, H, F, seed=a.config, max_sh_degree=cfg["max_sh_degree"])
+    room = None
+    if a.scene == "room":
+        from online_lang_splatting_amd.scene import make_room_scene
+        room = make_room_scene(P, W, H, F, views=max(world, 10), random_views=2, seed=a.config,
+                               max_sh_degree=cfg["max_sh_degree"])
+        sc = room.scene
+    else:
+        sc = make_scene(P, W, H, F, seed=a.config, max_sh_degree=cfg["max_sh_degree"])
+    P = sc.P
     M = sc.shs.shape[1]
     if a.views > 0:
         views_mode(a, sc, dev, rank, world, dist)
@@ -750,7 +973,7 @@ def main():
         return
     # weak scaling = the same work per GPU whatever N: rank r renders pose r of N poses 3 cm apart without rotation, whose
     # cost equals the identity pose's (n == 1 -> the identity pose of config 3); the arc's rotated poses cost up to 12 % more
-    cams = shard_cameras(W, H, n=max(world, 1))
+    cams = shard_cameras(W, H, n=max(world, 1)) if room is None else room.cameras[:max(world, 1)]
     if a.rank_view and world == 1:
         k_, n_ = (int(x) for x in a.rank_view.split(",")[:2])
         cams = [(arc_cameras if a.rank_view.endswith("arc") else shard_cameras)(W, H, n=n_)[k_]]
@@ -899,7 +1122,15 @@ def main():
     # The contract's region (W warm-up steps, then exactly K timed steps between barriers) is run `--repeats` times back to
     # back; the line's value is the MEDIAN run, all runs are listed (with K = 20 the region is
     # 10 ms long and a single run swings by several per cent).
-    runs = [timed(a.steps, a.warmup if i == 0 else 0, lanes.next_lane, events=False) for i in range(max(1, a.repeats))]
+    runs = []
+    while True:
+        runs.append(timed(a.steps, a.warmup if not runs else 0, lanes.next_lane, events=False))
+        if a.repeats > 0:
+            if len(runs) >= a.repeats:
+                break
+        elif len(runs) >= 5 and (sum(r_[0] for r_ in runs) >= a.min_timed_s or len(runs) >= 2000):
+            # (identical on every rank: the elapsed times are the MAX over the ranks)
+            break
     order_ = sorted(range(len(runs)), key=lambda i: runs[i][0])
     elapsed, avg, lat = runs[order_[len(runs) // 2]]
     run_fps = [world * a.steps / r_[0] for r_ in runs]
@@ -910,7 +1141,7 @@ def main():
         if world == 1 and not a.no_extra_legs:
             # non-coherent frames: the camera changes EVERY step (eight arc views, yaw -14 .. +14 degrees), so a lane's
             # tile-order hint comes from another view and nothing of the previous frame can be reused
-            view_cycle[0] = [device_inputs(sc, c_, dev)[1] for c_ in arc_cameras(W, H, n=8)]
+            view_cycle[0] = [device_inputs(sc, c_, dev)[1] for c_ in (arc_cameras(W, H, n=8) if room is None else room.cameras)]
             step_no[0] = 0
             nc4 = timed(a.steps, a.warmup, lanes.next_lane, events=False)
             nc1 = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
@@ -979,6 +1210,7 @@ def main():
     # the reference's num_rendered (bounding-square instances) of this view: the R of the byte model
     R_ref = int(_C.state_field("geometry", ws0.geom, "counters", P=P, F=F, dtype=torch.int32, count=8)[3])
     L_rows, row_overflow = ws0.backward_status()
+    wstats = workload_stats(ws0, P, W, H, F) if rank == 0 else None
 
     if rank == 0:
         frames = world * a.steps
@@ -1035,14 +1267,28 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "value_runs": {"fps": [round(x, 1) for x in run_fps], "median": round(sorted(run_fps)[len(run_fps) // 2], 3),
-                           "min": round(min(run_fps), 3), "max": round(max(run_fps), 3), "steps_per_run": a.steps,
-                           "note": "the contract's K-step region repeated back to back; value = the median run"},
-            "config": {"workload": f"BASELINE.json configs[{a.config - 1}]: {P} Gaussians, {W}x{H}, RGB+depth+{F} "
+            # what `value` is a rate OF: this many frames in flight per GPU, the same camera every step (the headline's
+            # tile-order hints therefore belong to the view rendered; `non_coherent` and `isolated` are the other cases)
+            "frames_in_flight": len(lanes), "same_view_every_step": True,
+            "config": {"workload": (f"BASELINE.json configs[{a.config - 1}]: {P} Gaussians, {W}x{H}, RGB+depth+{F} "
+                                    if room is None else
+                                    f"room map (scene.make_room_scene) at the size of BASELINE.json configs[{a.config - 1}]: "
+                                    f"{sc.P} Gaussians of {room.keyframes} keyframes, {W}x{H}, RGB+depth+{F} ") +
                                    f"language channels, forward+backward, tile 15, backward mode {a.mode}; "
                                    f"{a.setup_steps} untimed set-up frames precede the warm-up (allocations, tile-order "
                                    "hints, clocks)",
-                       "P": P, "width": W, "height": H, "F": F, "R": R_ref, "R_over_P": round(R_ref / max(P, 1), 3),
+                       "scene": a.scene,
+                       "value_runs": {"runs": len(run_fps), "steps_per_run": a.steps,
+                                      "timed_seconds_total": round(sum(r_[0] for r_ in runs), 3),
+                                      "median": round(sorted(run_fps)[len(run_fps) // 2], 3),
+                                      "min": round(min(run_fps), 3), "max": round(max(run_fps), 3),
+                                      "p10": round(sorted(run_fps)[int(0.1 * (len(run_fps) - 1))], 3),
+                                      "p90": round(sorted(run_fps)[int(0.9 * (len(run_fps) - 1) + 0.5)], 3),
+                                      "fps": [int(round(x)) for x in run_fps],
+                                      "note": "the contract's K-step region (barrier, K steps, barrier) repeated back to back "
+                                              "until the timed regions total --min-timed-s; value = the median run"},
+                       "frames_in_flight": len(lanes), "same_view_every_step": True,
+                       "P": sc.P, "width": W, "height": H, "F": F, "R": R_ref, "R_over_P": round(R_ref / max(sc.P, 1), 3),
                        "binning": a.binning, "R_binned": Rr, "forward_accumulation": a.fwd_accum,
                        "views_per_step": world, "parallelism": f"frame-shard x{world}",
                        "rccl_ranks": world if backend == "nccl" else 0, "backend": backend,
@@ -1053,6 +1299,7 @@ def main():
                        "exchange_detail": exch_detail,
                        "frames_in_flight_per_gpu": len(lanes), "untimed_setup_steps": a.setup_steps,
                        "live_gradient_rows": L_rows,
+                       "workload_stats": wstats,
                        "capacity_overflow": bool(overflow or row_overflow)},
             "roofline": roof,
             "frame_model": frame,
@@ -1073,8 +1320,9 @@ def main():
         if world == 1 and a.isolated_steps > 0 and not a.no_extra_legs:
             dims = (P, W, H, F, M)
             out["bracket"] = bracket_legs(sc, g_dev, c0, (dc, dl, dd), dev, max(10, a.isolated_steps), dims)
-            if a.config == 3:
+            if a.config == 3 and room is None:
                 out["config4_substitute"] = config4_substitute(sc, g_dev, dev, dims)
+                out["config4_substitute"]["room_scene"] = room_scene_leg(dev, dims, a.isolated_steps)
         if world == 1 and not a.no_cpu_baseline:
             lane0 = lanes.lanes[0]
             sl = lane0[1].layout.slices()

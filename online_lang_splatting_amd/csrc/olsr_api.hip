@@ -926,6 +926,7 @@ const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t 
   if (!std::strcmp(name, "counters")) return g.counters;
   if (!std::strcmp(name, "emit_totals")) return g.emit_status;
   if (!std::strcmp(name, "inst_start")) return g.inst_start;
+  if (!std::strcmp(name, "blended")) return g.blended;  // u8[P]: some pixel blended the Gaussian in this frame's forward
   return nullptr;
 }
 

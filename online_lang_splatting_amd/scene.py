@@ -222,16 +222,20 @@ ROOM_BOXES = (((-3.3, 0.55, 1.2), (-1.9, 1.4, 2.3)),     # sofa
               ((-1.0, -0.9, 2.42), (1.0, 0.3, 2.5)))       # picture on the far wall
 
 
-def _raycast_room(cam: "Camera", W: int, H: int):
+def _raycast_room(cam: "Camera", W: int, H: int, pix=None):
     """z-depth [H, W], hit point in the world [H, W, 3] and surface id [H, W] (0..5 the room's faces, 6 + 6 b + face for box
-    b) seen by `cam` at resolution W x H (the intrinsics are scaled from the camera's own resolution)."""
+    b) seen by `cam` at resolution W x H (the intrinsics are scaled from the camera's own resolution).  `pix` (flat pixel
+    indices v * W + u, int64 [n]): cast only those rays; the results are then [n], [n, 3], [n]."""
     f64 = torch.float64
     sx, sy = W / cam.width, H / cam.height
     fx, fy = cam.fx * sx, cam.fy * sy
     cx, cy = (cam.cx + 0.5) * sx - 0.5, (cam.cy + 0.5) * sy - 0.5
     R, T = cam.R.to(f64), cam.T.to(f64)
     c = -(R.t() @ T)                                       # camera centre in the world
-    v, u = torch.meshgrid(torch.arange(H, dtype=f64), torch.arange(W, dtype=f64), indexing="ij")
+    if pix is None:
+        v, u = torch.meshgrid(torch.arange(H, dtype=f64), torch.arange(W, dtype=f64), indexing="ij")
+    else:
+        v, u = torch.div(pix, W, rounding_mode="floor").to(f64), (pix % W).to(f64)
     d_cam = torch.stack([(u - cx) / fx, (v - cy) / fy, torch.ones_like(u)], dim=-1)
     d = d_cam @ R                                          # R^T d_cam, row-vector form: z-depth = ray parameter
     eps = 1e-12
@@ -323,9 +327,10 @@ class RoomScene:
 
 
 def make_room_scene(P=500_000, W=1200, H=680, F=15, views=10, seed=0, max_sh_degree=0, knn=None, lang_size=192,
-                    window_start=0):
+                    window_start=0, random_views=0):
     """About P Gaussians (exactly P when the keyframes supply enough) built keyframe by keyframe as the reference's back end
-    builds its map, and `views` consecutive keyframe poses to render it from.  `knn`: points [n,3] (CPU float32) -> mean
+    builds its map, and `views` consecutive keyframe poses to render it from, followed by `random_views` keyframes drawn from
+    the rest of the loop (BackEnd.map renders its window plus two random earlier keyframes, utils/slam_backend.py:510-530).  `knn`: points [n,3] (CPU float32) -> mean
     squared distance to the three nearest neighbours [n]; default: the library's olsr_knn_mean_dist2 when a GPU is present,
     else knn_mean_dist2_host (bit-identical, tests/test_gpu_room_scene.py)."""
     if knn is None:
@@ -348,22 +353,24 @@ def make_room_scene(P=500_000, W=1200, H=680, F=15, views=10, seed=0, max_sh_deg
     for k, cam in enumerate(kcams):
         if left <= 0:
             break
-        depth, hitp, sid = _raycast_room(cam, W, H)
+        # random_down_sample(1 / factor) of the back-projected image: the kept pixels are drawn first and only their rays are
+        # cast (the depth image of a keyframe is never needed whole; the median depth of adaptive_pointsize is taken over the
+        # kept pixels — in this room it is above 1 m from every pose, so point_size = 0.05 either way)
+        n_take = min(n_first if k == 0 else n_next, left)
+        pick = torch.randperm(N, generator=g)[:n_take]
+        depth, hitp, sid = _raycast_room(cam, W, H, pick)
         col = _room_colour(hitp, sid)
         # create_from_rgbd_image(..., extrinsic = W2C): x = (u - cx) z / fx, y = (v - cy) z / fy, then C2W
-        v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-        pc = torch.stack([(u - cam.cx) * depth / cam.fx, (v - cam.cy) * depth / cam.fy, depth], dim=-1).reshape(-1, 3)
-        pw = (pc - cam.T) @ cam.R                          # R^T (p - T)
-        n_take = min(n_first if k == 0 else n_next, left)  # random_down_sample(1 / factor)
-        pick = torch.randperm(N, generator=g)[:n_take]
-        pts = pw[pick].contiguous()
+        u, v = (pick % W).to(torch.float32), torch.div(pick, W, rounding_mode="floor").to(torch.float32)
+        pc = torch.stack([(u - cam.cx) * depth / cam.fx, (v - cam.cy) * depth / cam.fy, depth], dim=-1)
+        pts = ((pc - cam.T) @ cam.R).contiguous()          # R^T (p - T)
         point_size = min(0.05, 0.05 * float(depth.median()))
         d2 = torch.clamp_min(knn(pts), 1e-7) * point_size
         xyz.append(pts)
-        rgb.append(col.reshape(-1, 3)[pick])
+        rgb.append(col)
         scl.append(torch.sqrt(d2))
         if F > 0:
-            l = codes[sid.reshape(-1)[pick]] + 0.1 * torch.randn(n_take, F, generator=g)
+            l = codes[sid] + 0.1 * torch.randn(n_take, F, generator=g)
             lang.append(l / l.norm(dim=1, keepdim=True))
         per_kf.append(n_take)
         left -= n_take
@@ -378,6 +385,10 @@ def make_room_scene(P=500_000, W=1200, H=680, F=15, views=10, seed=0, max_sh_deg
     opacities = torch.full((n, 1), 0.5)
     language = torch.cat(lang).contiguous() if F > 0 else None
     window = [kcams[(window_start + i) % K] for i in range(views)]
+    rest = [k for k in range(K) if (k - window_start) % K >= views]
+    if random_views > 0 and rest:
+        for j in torch.randperm(len(rest), generator=g)[:random_views].tolist():
+            window.append(kcams[rest[j]])
     targets = []
     for cam in window:
         depth, hitp, sid = _raycast_room(cam, W, H)

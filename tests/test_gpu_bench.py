@@ -77,8 +77,21 @@ def test_config3_line_carries_the_config4_substitute():
     assert prof2["stage_ms_per_view"]["loss"] > 0 and prof["stage_ms_per_view"]["render_backward"] > 0
     assert set(d["bracket"]) == {"exact_mode", "tile16", "rect_binning", "fwd_accum_weight"}
     assert d["bracket"]["fwd_accum_weight"]["forward_accumulation"] == "weight"
-    runs = d["value_runs"]   # the K-step region repeated; the value is the median run
-    assert len(runs["fps"]) == 5 and runs["min"] <= runs["median"] <= runs["max"] and abs(runs["median"] - d["value"]) < 0.01
+    runs = d["config"]["value_runs"]   # the K-step region repeated until the timed regions total 2 s; the value is the median run
+    assert len(runs["fps"]) == runs["runs"] >= 5 and runs["timed_seconds_total"] >= 2.0
+    assert runs["min"] <= runs["p10"] <= runs["median"] <= runs["p90"] <= runs["max"] and abs(runs["median"] - d["value"]) < 0.01
+    assert d["frames_in_flight"] == 4 and d["same_view_every_step"] is True and d["config"]["scene"] == "volume"
+    ws_ = d["config"]["workload_stats"]   # the i.i.d. volume: saturation ends the lists early, few Gaussians blend
+    assert ws_["list_fraction_read_before_saturation"] < 0.5 and ws_["blended_of_visible"] < 0.2
+    room = c4["room_scene"]               # the surface-structured map: nothing saturates, nearly every visible Gaussian is live
+    rw = room["workload"]
+    assert rw["list_fraction_read_before_saturation"] > 0.8 and rw["live_rows_of_visible"] > 0.9 and not rw["capacity_overflow"]
+    assert room["isolated"]["value"] > 0 and room["four_in_flight"]["value"] > room["isolated"]["value"]
+    assert room["exchange"]["chosen"] in ("sparse", "reduce_scatter") and room["exchange"]["union_rows_over_12_views"] >= rw["live_gradient_rows_gaussians"]
+    assert room["tracking"]["pose_error_after"] < room["tracking"]["pose_error_start"]
+    for k_ in ("fused_loss", "two_kernel_loss"):
+        m_ = room["mapping"][k_]
+        assert not m_["capacity_overflow"] and m_["loss_last_view_final_iteration"] < m_["loss_last_view_first_iteration"]
     assert "untimed set-up frames" in d["config"]["workload"]
     assert d["dropin"]["alternating_4_views"]["value"] > 0.8 * d["dropin"]["value"]   # per-view orders inside the library
     nc = d["non_coherent"]   # the camera changes every step: no reusable tile-order hint
