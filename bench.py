@@ -247,10 +247,12 @@ def choose_exchange(union_rows, P, width):
     """The step's exchange, from the data: the capacity-bound sparse exchange moves 8 P bytes of
     flags and radii, 8 P bytes of densification statistics and 1.25 x the union's rows; the dense two-phase exchange moves
     the bucket (P x width floats + the statistics + the radii).  Sparse only when it is the smaller payload."""
+    from online_lang_splatting_amd.frame_shard import GradientBucket
     cap = min(P, int(1.25 * union_rows) + 4096)
     sparse_bytes = 8 * P + (cap * width + 2 * P) * 4
     dense_bytes = (P * width + 2 * P) * 4 + 4 * P
-    return ("sparse" if sparse_bytes < dense_bytes else "reduce_scatter"), cap, sparse_bytes, dense_bytes
+    pays = sparse_bytes < GradientBucket.SPARSE_MARGIN * dense_bytes   # (GradientBucket.sparse_pays: the same rule)
+    return ("sparse" if pays else "reduce_scatter"), cap, sparse_bytes, dense_bytes
 
 
 def room_scene_leg(dev, dims, steps, seed=3):
@@ -343,7 +345,7 @@ def room_scene_leg(dev, dims, steps, seed=3):
     choice, cap_rows, sp_b, de_b = choose_exchange(int(union.sum()), sc.P, width)
     out["exchange"] = {"union_rows_over_12_views": int(union.sum()), "union_of_P": round(int(union.sum()) / sc.P, 4),
                        "rows_one_view": live, "sparse_payload_bytes": sp_b, "dense_payload_bytes": de_b, "chosen": choice,
-                       "rule": "sparse iff 8 P + (1.25 x union rows x width + 2 P) x 4 bytes < the dense bucket + statistics + radii"}
+                       "rule": "sparse iff 8 P + (1.25 x union rows x width + 2 P) x 4 bytes < 0.75 x (the dense bucket + statistics + radii)"}
     # what the round-3/4 optimisations are worth on a surface: A/B, one frame in flight
     ab = {}
     for name, kw, track in (("default", {}, True), ("no_row_mask", {}, False),
@@ -834,6 +836,7 @@ def views_mode(a, sc, dev, rank, world, dist):
                        "views_in_flight_per_gpu": len(lanes),
                        "views_of_rank0": len(views_of_rank(a.views, 0, world)), "parallelism": f"frame-shard x{world}",
                        "exchange": a.exchange, "bucket_bytes": P * width * 4,
+                       "exchange_chosen": (step.wire or {}).get("chosen", a.exchange) if a.exchange == "auto" else a.exchange,
                        "wire": step.wire}}), file=JSON_OUT, flush=True)
 
 
@@ -880,11 +883,15 @@ def main():
                     help="mapping-iteration mode: every step renders this many viewpoints in total, view v on rank v mod N "
                          "(BackEnd.map renders 12, utils/slam_backend.py:510-670), then ONE exchange of the bucket; "
                          "0 (default): one view per rank per step, weak scaling")
-    ap.add_argument("--exchange", default="sparse", choices=["all_reduce", "reduce_scatter", "sparse"],
-                    help="how the shared-Gaussian gradients travel when N > 1.  sparse (default): only the rows that are "
-                         "non-zero on some rank (2 %% of the rows of a config-3 view) - capacity-bound and sync-free in the "
-                         "default weak-scaling mode, exact in --views mode; all_reduce: the whole bucket; reduce_scatter: "
-                         "two direct phases over all xGMI links (with --views: owner-applies Adam in between)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "all_reduce", "reduce_scatter", "sparse"],
+                    help="how the shared-Gaussian gradients travel when N > 1.  auto (default): chosen from the data - the "
+                         "union of the ranks' non-zero gradient rows is measured (at set-up in the weak-scaling mode, every "
+                         "step with --views) and the rows travel packed (sparse) only when that is the smaller payload by a "
+                         "quarter, else the bucket goes densely in two direct phases (reduce_scatter); sparse: only the rows "
+                         "that are non-zero on some rank (2 %% of the rows of a config-3 view, 20 %% of a room-map view) - "
+                         "capacity-bound and sync-free in the default weak-scaling mode, exact in --views mode; all_reduce: "
+                         "the whole bucket; reduce_scatter: two direct phases over all xGMI links (with --views: "
+                         "owner-applies Adam in between)")
     ap.add_argument("--self-launch", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (N > 1 does so by itself when "
                          "WORLD_SIZE is not set)")
@@ -1008,13 +1015,43 @@ def main():
     step_done = []  # one event per step of the current timed region, recorded on the step's stream
     sparse_cap = [0]  # rows of the capacity-bound sparse exchange (sized below, from the measured row sparsity)
 
+    chosen = [a.exchange]  # "auto" is resolved below, from the measured union of the ranks' gradient rows
+
+    # OLSR_BENCH_EXCHANGE_STREAM=1 (an experiment of round 5, OFF by default): the exchange on ONE side stream shared by the
+    # lanes, so that a lane's stream goes on to its next forward while the exchange's launches and the hops to RCCL's own
+    # stream and back happen beside it (the lane's next backward waits for the completion event).  Measured on one rank over
+    # RCCL it is WORSE than the exchange in the lane's own stream — room map 3 274 against 3 764 fps (sparse), volume 1 999
+    # against 2 217: a sixth stream takes a hardware queue from the lanes.
+    class _Waitable:
+        def __init__(self, ev, stream):
+            self.ev, self.stream = ev, stream
+
+        def wait(self):
+            torch.cuda.current_stream(dev).wait_event(self.ev)
+    side = [None]
+    use_side = os.environ.get("OLSR_BENCH_EXCHANGE_STREAM", "0") == "1"
+
     def exchange(bucket):
-        """The step's one exchange of the shared-Gaussian gradients, enqueued on the lane's stream (no host sync)."""
+        """The step's one exchange of the shared-Gaussian gradients (no host sync)."""
         if dist is None:
             return
-        if a.exchange == "all_reduce":
+        if use_side and chosen[0] != "all_reduce":
+            if side[0] is None:
+                side[0] = torch.cuda.Stream(dev)
+            lane_stream = torch.cuda.current_stream(dev)
+            side[0].wait_stream(lane_stream)
+            with torch.cuda.stream(side[0]):
+                if chosen[0] == "sparse":
+                    bucket.sparse_all_reduce_capped(sparse_cap[0])
+                else:
+                    bucket.reduce_scatter_all_gather(rank, world)
+                ev = torch.cuda.Event()
+                ev.record(side[0])
+            pending[id(bucket)] = [_Waitable(ev, side[0])]
+            return
+        if chosen[0] == "all_reduce":
             pending[id(bucket)] = bucket.all_reduce(async_op=True)
-        elif a.exchange == "sparse":
+        elif chosen[0] == "sparse":
             bucket.sparse_all_reduce_capped(sparse_cap[0])
         else:
             bucket.reduce_scatter_all_gather(rank, world)
@@ -1105,12 +1142,19 @@ def main():
         dist.all_reduce(nz, op=dist.ReduceOp.MAX)
         active_rows = int(nz.item())
         sparse_cap[0] = min(P, int(1.25 * world * active_rows) + 4096)
-        if a.exchange == "sparse":
+        union_rows = None
+        if a.exchange in ("sparse", "auto"):
             # ... and the union itself: neighbouring views share most of their front layer (the overlapping keyframes of a
             # mapping window do too), so the union is far smaller than world x rows.  One exchange at the safe capacity,
             # its row count read back (set-up: the one host synchronisation of this path), 25 % head-room on that.
             union_rows = int(bucket_.sparse_all_reduce_capped(sparse_cap[0])[0].item())  # identical on every rank
             sparse_cap[0] = min(P, int(1.25 * union_rows) + 4096)
+        if a.exchange == "auto":
+            # the exchange is chosen from the data (identical on every rank: the union is): packed rows only when the
+            # capacity-bound payload is the smaller one by a quarter (GradientBucket.sparse_pays), else the dense bucket in
+            # two direct phases
+            pays_, sp_b_, de_b_ = bucket_.sparse_pays(union_rows, capacity=sparse_cap[0])
+            chosen[0] = "sparse" if pays_ else "reduce_scatter"
     for _ in range(a.setup_steps):
         one_step(lanes.next_lane())
     for lane_ in lanes.lanes:
@@ -1131,9 +1175,9 @@ def main():
         elif len(runs) >= 5 and (sum(r_[0] for r_ in runs) >= a.min_timed_s or len(runs) >= 2000):
             # (identical on every rank: the elapsed times are the MAX over the ranks)
             break
-    order_ = sorted(range(len(runs)), key=lambda i: runs[i][0])
-    elapsed, avg, lat = runs[order_[len(runs) // 2]]
     run_fps = [world * a.steps / r_[0] for r_ in runs]
+    order_ = sorted(range(len(runs)), key=lambda i: run_fps[i])
+    elapsed, avg, lat = runs[order_[len(runs) // 2]]   # the median run (the upper one of an even count), as value_runs.median
     iso = prof = nonco = None
     if a.isolated_steps > 0:
         iso = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
@@ -1160,8 +1204,15 @@ def main():
     if dist is not None:
         b0 = lanes.lanes[0][1]
         exch_detail = {"bucket_bytes": b0.sum_storage.numel() * 4 + P * 4, "gradient_rows": P,
-                       "rows_nonzero_per_view_max_over_ranks": active_rows}
-        if a.exchange == "sparse":
+                       "rows_nonzero_per_view_max_over_ranks": active_rows,
+                       "live_row_fraction_per_view": round(active_rows / max(P, 1), 4),
+                       "requested": a.exchange, "chosen": chosen[0]}
+        if union_rows is not None:
+            pays_, sp_b_, de_b_ = b0.sparse_pays(union_rows, capacity=sparse_cap[0])
+            exch_detail.update({"rows_in_union_at_setup": union_rows, "union_fraction": round(union_rows / max(P, 1), 4),
+                                "sparse_payload_bytes": sp_b_, "dense_payload_bytes": de_b_, "sparse_pays": bool(pays_),
+                                "rule": "sparse iff 8 P + (capacity x width + 2 P) x 4 < 0.75 x dense payload"})
+        if chosen[0] == "sparse":
             stt = torch.stack([lane_[1]._capped["status"] for lane_ in lanes.lanes if getattr(lane_[1], "_capped", None)])
             exch_detail.update({"packed_capacity_rows": sparse_cap[0], "rows_in_union_last_step": int(stt[:, 0].max()),
                                 "overflow": bool(int(stt[:, 1].max()))})
@@ -1292,10 +1343,11 @@ def main():
                        "binning": a.binning, "R_binned": Rr, "forward_accumulation": a.fwd_accum,
                        "views_per_step": world, "parallelism": f"frame-shard x{world}",
                        "rccl_ranks": world if backend == "nccl" else 0, "backend": backend,
-                       "exchange": a.exchange if dist is not None else None,
+                       "exchange": chosen[0] if dist is not None else None,
+                       "exchange_requested": a.exchange if dist is not None else None,
                        "exchange_forced_single_rank": forced,
                        "exchange_bytes_per_step": None if dist is None else
-                       lanes.lanes[0][1].exchange_bytes(a.exchange, sparse_cap[0]),
+                       lanes.lanes[0][1].exchange_bytes(chosen[0], sparse_cap[0]),
                        "exchange_detail": exch_detail,
                        "frames_in_flight_per_gpu": len(lanes), "untimed_setup_steps": a.setup_steps,
                        "live_gradient_rows": L_rows,

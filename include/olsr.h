@@ -343,6 +343,26 @@ int olsr_adam_step_sum(int32_t P, int32_t M, int32_t F, const olsr_adam_params *
                        const float *const *flats, float *means3D, float *shs, float *opacities, float *scales,
                        float *rotations, float *language, float *exp_avg, float *exp_avg_sq, void *hip_stream);
 
+/* The same step for buckets that carry a row mask (olsr_grad_bucket.row_mask; round 5): row_masks[b] (host array of device
+ * pointers, an entry or the array itself may be NULL = "every row may be non-zero") names the rows of flats[b] that may hold
+ * a gradient; a row whose bit is clear is NOT READ — its gradient is the +0.0 the row holds by the mask's invariant.  The
+ * update stays dense (every parameter and both moments of every row are read and written): parameters and moments equal
+ * olsr_adam_step_sum's — torch.optim.Adam's — bit for bit.  What goes is the read of known-zero gradient rows: on a surface
+ * map a view leaves 20 % of the rows live, on the i.i.d. volume of SURVEY 8(d) 2 %.  P must start at a multiple of 64 rows
+ * of the masks (a block of the kernel owns one mask word). */
+int olsr_adam_step_masked(int32_t P, int32_t M, int32_t F, const olsr_adam_params *params, int32_t n_flats,
+                          const float *const *flats, const uint64_t *const *row_masks, float *means3D, float *shs,
+                          float *opacities, float *scales, float *rotations, float *language, float *exp_avg,
+                          float *exp_avg_sq, void *hip_stream);
+
+/* dst bucket += src bucket — the sum of the per-stream buckets of a step before its exchange (what autograd's `.grad +=`
+ * over the views of BackEnd.map does, utils/slam_backend.py:510-670) — reading and writing only the gradient rows that
+ * src_row_mask says may be non-zero (NULL: all of them); dst_row_mask (may be NULL) |= src_row_mask.  densify (SUM) and
+ * max_radii (MAX) are combined for every Gaussian.  Same bits as a dense dst += src (a row left alone is dst + 0.0). */
+int olsr_bucket_add(int32_t P, int32_t width, float *dst_flat, float *dst_densify, int32_t *dst_max_radii,
+                    uint64_t *dst_row_mask, const float *src_flat, const float *src_densify, const int32_t *src_max_radii,
+                    const uint64_t *src_row_mask, void *hip_stream);
+
 /* ---- the reference's other native dependency ----------------------------
  * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest neighbours (FLT_MAX counts
  * for a missing neighbour when P < 4).  Replaces simple_knn._C.distCUDA2 -> SimpleKNN::knn

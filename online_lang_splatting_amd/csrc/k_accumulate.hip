@@ -77,6 +77,50 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
                                                  dmeans2D, radii, flat, densify, max_radii);
 }
 
+// ---- dst bucket += src bucket, reading only the rows src's row mask says may be non-zero ------------------------------
+// The sum of the lane buckets of a step (frame_shard.FrameLanes: one bucket per HIP stream) before an exchange.  torch's
+// dst.add_(src) reads and writes P x width floats whatever they hold; with row masks (olsr_grad_bucket.row_mask) a block
+// of 64 Gaussians whose src word is zero touches neither bucket, and inside a block only the flagged rows move:
+// dst[g] + 0.0 == dst[g] for the rows left alone.  dst_mask |= src_mask.  The densification statistics and radii are dense
+// (every visible Gaussian has them): densify += , max_radii = max.
+__global__ __launch_bounds__(256) void bucket_add_kernel(int P, int width, float* __restrict__ dst,
+                                                         const float* __restrict__ src,
+                                                         unsigned long long* __restrict__ dst_mask,
+                                                         const unsigned long long* __restrict__ src_mask,
+                                                         float* __restrict__ dst_densify,
+                                                         const float* __restrict__ src_densify,
+                                                         int32_t* __restrict__ dst_radii,
+                                                         const int32_t* __restrict__ src_radii) {
+  static_assert(ACC_G == 64, "one row-mask word per block");
+  const int g0 = blockIdx.x * ACC_G;
+  const int ng = min(ACC_G, P - g0);
+  if (threadIdx.x < ng) {
+    const int g = g0 + threadIdx.x;
+    float2* dz = reinterpret_cast<float2*>(dst_densify) + g;
+    const float2 a = *dz, b = reinterpret_cast<const float2*>(src_densify)[g];
+    *dz = make_float2(a.x + b.x, a.y + b.y);
+    dst_radii[g] = max(dst_radii[g], src_radii[g]);
+  }
+  const unsigned long long w = src_mask ? src_mask[blockIdx.x] : ~0ull;
+  if (w == 0ull) return;
+  if (threadIdx.x == 0 && dst_mask) dst_mask[blockIdx.x] |= w;
+  const int count = ng * width;
+  const float inv_w = 1.0f / (float)width;
+  const size_t base = (size_t)g0 * width;
+  for (int e = threadIdx.x; e < count; e += 256) {
+    const int gl = (int)(((float)e + 0.5f) * inv_w);
+    if ((w >> gl) & 1ull) dst[base + e] = dst[base + e] + src[base + e];
+  }
+}
+
+void launch_bucket_add(int P, int width, float* dst, const float* src, unsigned long long* dst_mask,
+                       const unsigned long long* src_mask, float* dst_densify, const float* src_densify,
+                       int32_t* dst_radii, const int32_t* src_radii, hipStream_t st) {
+  if (P <= 0) return;
+  bucket_add_kernel<<<(unsigned)((P + ACC_G - 1) / ACC_G), 256, 0, st>>>(P, width, dst, src, dst_mask, src_mask, dst_densify,
+                                                                        src_densify, dst_radii, src_radii);
+}
+
 
 // ---- the capacity-bound sparse exchange of the bucket (frame_shard.py: sparse_all_reduce_capped) ----
 // Saturation leaves ~2 % of a view's Gaussians with a gradient row, so a frame-sharded step exchanges the UNION of the
@@ -141,8 +185,7 @@ __global__ __launch_bounds__(256) void exchange_pack_kernel(int P, int width, in
                                                             int32_t* __restrict__ status) {
   __shared__ int s_red[2][4];
   __shared__ int s_pop[16];
-  __shared__ int s_g[EX_ROWS], s_slot[EX_ROWS];
-  __shared__ int s_nsel;
+  __shared__ int s_g[EX_ROWS];  // the block's selected rows in slot order: local rank -> row
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, b = blockIdx.x;
   // rows of the union in front of this block, and in total
   int before = 0, total = 0;
@@ -160,7 +203,6 @@ __global__ __launch_bounds__(256) void exchange_pack_kernel(int P, int width, in
     s_red[0][w] = before;
     s_red[1][w] = total;
   }
-  if (tid == 0) s_nsel = 0;
   u64 m[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -180,18 +222,28 @@ __global__ __launch_bounds__(256) void exchange_pack_kernel(int P, int width, in
       if (slot < cap) {
         const int g = b * EX_ROWS + k * 256 + tid;
         idx[slot] = g;
-        const int i = atomicAdd(&s_nsel, 1);
-        s_g[i] = g;
-        s_slot[i] = slot;
+        s_g[slot - before] = g;  // (the block's slots are consecutive: before, before + 1, ...)
       }
     }
   }
   __syncthreads();
-  const int nsel = s_nsel;
-  for (int i = w; i < nsel; i += 4) {  // a wave per selected row
-    const float* src = flat + (size_t)s_g[i] * width;
-    float* dst = packed + (size_t)s_slot[i] * width;
-    for (int c = lane; c < width; c += 64) dst[c] = src[c];
+  // the block's rows land in consecutive slots: packed[before * width ...) is ONE contiguous run of nsel * width floats.
+  // One element per thread and step — independent loads, perfectly coalesced stores.  (Round 4 gave every selected row a
+  // wave: with 20 % of the rows live — a surface map — a wave copied ~50 rows one after the other, each a dependent
+  // load -> store: 75 us for 11 MB.)
+  int in_block = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) in_block += s_pop[i];
+  const int nsel = max(0, min(in_block, cap - before));
+  {
+    const float inv_w = 1.0f / (float)width;
+    float* dst = packed + (size_t)before * width;
+    const int count = nsel * width;
+    for (int e = tid; e < count; e += 256) {
+      const int i = (int)(((float)e + 0.5f) * inv_w);  // (exact below 2^22 elements: nsel <= 1024, width <= 107)
+      const int c = e - i * width;
+      dst[e] = flat[(size_t)s_g[i] * width + c];
+    }
   }
   // the slots behind the union: zeros, so that the SUM leaves zeros and the scatter skips them
   const int used = min(total, cap);
@@ -209,16 +261,15 @@ __global__ __launch_bounds__(256) void exchange_pack_kernel(int P, int width, in
 __global__ __launch_bounds__(256) void exchange_unpack_kernel(int P, int width, int cap, const int32_t* __restrict__ idx,
                                                               const float* __restrict__ packed, const float* __restrict__ tail,
                                                               float* __restrict__ flat, float* __restrict__ densify) {
-  const int lane = threadIdx.x & 63;
-  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * 256) >> 6;
-  for (size_t s = wave; s < (size_t)cap; s += nwaves) {
-    const int g = idx[s];
-    if ((unsigned)g >= (unsigned)P) continue;
-    const float* src = packed + s * width;
-    float* dst = flat + (size_t)g * width;
-    for (int c = lane; c < width; c += 64) dst[c] = src[c];
-  }
+  // one element per thread and step: the packed rows are read as one contiguous stream (round 4 walked them a wave per
+  // row, eight dependent idx -> row -> store trips per wave)
   const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+  const size_t total = (size_t)cap * width;
+  for (size_t e = gtid; e < total; e += gsz) {
+    const size_t s = e / (size_t)width;
+    const int g = idx[s];
+    if ((unsigned)g < (unsigned)P) flat[(size_t)g * width + (e - s * width)] = packed[e];
+  }
   for (size_t e = gtid; e < 2 * (size_t)P; e += gsz) densify[e] = tail[e];
 }
 
@@ -262,7 +313,7 @@ void launch_exchange_pack(int P, int width, int cap, const float* flat, const in
 void launch_exchange_unpack(int P, int width, int cap, const int32_t* idx, const float* fsum, float* flat, float* densify,
                             hipStream_t st) {
   if (P <= 0) return;
-  const size_t work = std::max((size_t)cap * 64, (size_t)2 * P);
+  const size_t work = std::max((size_t)cap * width, (size_t)2 * P);
   const unsigned nb = (unsigned)std::min<size_t>((work + 255) / 256, 4096);
   exchange_unpack_kernel<<<nb, 256, 0, st>>>(P, width, cap, idx, fsum, fsum + (size_t)cap * width, flat, densify);
 }

@@ -32,6 +32,11 @@ struct AdamScalars {
 struct AdamBuckets {
   const float* more[OLSR_ADAM_MAX_BUCKETS - 1];
   int n_more;
+  // row masks (olsr_grad_bucket.row_mask: bit g clear = row g of that bucket is zero), or null = every row is read.
+  // A block covers ADAM_G = 64 Gaussians = one mask word: rows a mask proves zero are not read at all (their gradient is the
+  // +0.0 the row holds), the update itself stays dense — parameters and moments are those of torch.optim.Adam bit for bit.
+  const unsigned long long* mask0;
+  const unsigned long long* mask_more[OLSR_ADAM_MAX_BUCKETS - 1];
 };
 
 __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int width, const float* __restrict__ flat,
@@ -47,6 +52,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int
   const int sh_w = 3 * M;
   const float inv_w = 1.0f / (float)width;
   const size_t base = (size_t)g0 * width;
+  static_assert(ADAM_G == 64, "one row-mask word per block");
+  const unsigned long long w0 = extra.mask0 ? extra.mask0[blockIdx.x] : ~0ull;
+  unsigned long long wm[OLSR_ADAM_MAX_BUCKETS - 1];
+#pragma unroll
+  for (int b = 0; b < OLSR_ADAM_MAX_BUCKETS - 1; ++b)
+    wm[b] = (b < extra.n_more) ? (extra.mask_more[b] ? extra.mask_more[b][blockIdx.x] : ~0ull) : 0ull;
   for (int e = threadIdx.x; e < count; e += 256) {
     const int gl = (int)(((float)e + 0.5f) * inv_w);
     const int c = e - gl * width;
@@ -59,8 +70,10 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int
     else if (c < 7 + sh_w) { p = scales + 3 * g + (c - 4 - sh_w); neg_step = hp.neg_step_scale; }
     else if (c < 11 + sh_w) { p = rotations + 4 * g + (c - 7 - sh_w); neg_step = hp.neg_step_rotation; }
     else { p = language + g * F + (c - 11 - sh_w); neg_step = hp.neg_step_language; }
-    float grad = flat[base + e];
-    for (int b = 0; b < extra.n_more; ++b) grad += extra.more[b][base + e];
+    float grad = ((w0 >> gl) & 1ull) ? flat[base + e] : 0.0f;
+#pragma unroll
+    for (int b = 0; b < OLSR_ADAM_MAX_BUCKETS - 1; ++b)
+      if ((wm[b] >> gl) & 1ull) grad += extra.more[b][base + e];
     float m = exp_avg[base + e], v = exp_avg_sq[base + e];
     m = m + (grad - m) * hp.one_minus_beta1;              // exp_avg.lerp_(grad, 1 - beta1)
     v = v * hp.beta2 + hp.one_minus_beta2 * grad * grad;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
@@ -71,14 +84,18 @@ __global__ __launch_bounds__(256) void adam_step_kernel(int P, int M, int F, int
   }
 }
 
-void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* const* flats, int n_flats,
-                      float* means3D, float* shs, float* opacities, float* scales, float* rotations, float* language,
+void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* const* flats,
+                      const unsigned long long* const* masks, int n_flats, float* means3D, float* shs, float* opacities, float* scales, float* rotations, float* language,
                       float* exp_avg, float* exp_avg_sq, hipStream_t st) {
   if (P <= 0) return;
   const float* flat = flats[0];
   AdamBuckets extra{};
   extra.n_more = n_flats - 1;
-  for (int b = 1; b < n_flats; ++b) extra.more[b - 1] = flats[b];
+  extra.mask0 = masks ? masks[0] : nullptr;
+  for (int b = 1; b < n_flats; ++b) {
+    extra.more[b - 1] = flats[b];
+    extra.mask_more[b - 1] = masks ? masks[b] : nullptr;
+  }
   const int width = 11 + 3 * M + F;
   // torch/optim/adam.py, _single_tensor_adam: Python-float (double) arithmetic for every scalar
   const double bc1 = 1.0 - pow(hp.beta1, (double)hp.step);

@@ -752,7 +752,7 @@ int olsr_adam_step(int32_t P, int32_t M, int32_t F, const olsr_adam_params* para
       (F > 0 && !language))
     return fail(OLSR_ERR_ARG, "the bucket, every parameter array and both moment buffers are required");
   const float* one[1] = {flat};
-  launch_adam_step(P, M, F, *params, one, 1, means3D, shs, opacities, scales, rotations, language, exp_avg, exp_avg_sq,
+  launch_adam_step(P, M, F, *params, one, nullptr, 1, means3D, shs, opacities, scales, rotations, language, exp_avg, exp_avg_sq,
                    (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("adam_step launch: ") + hipGetErrorString(e));
@@ -762,6 +762,14 @@ int olsr_adam_step(int32_t P, int32_t M, int32_t F, const olsr_adam_params* para
 int olsr_adam_step_sum(int32_t P, int32_t M, int32_t F, const olsr_adam_params* params, int32_t n_flats,
                        const float* const* flats, float* means3D, float* shs, float* opacities, float* scales,
                        float* rotations, float* language, float* exp_avg, float* exp_avg_sq, void* hip_stream) {
+  return olsr_adam_step_masked(P, M, F, params, n_flats, flats, nullptr, means3D, shs, opacities, scales, rotations, language,
+                               exp_avg, exp_avg_sq, hip_stream);
+}
+
+int olsr_adam_step_masked(int32_t P, int32_t M, int32_t F, const olsr_adam_params* params, int32_t n_flats,
+                          const float* const* flats, const uint64_t* const* row_masks, float* means3D, float* shs,
+                          float* opacities, float* scales, float* rotations, float* language, float* exp_avg,
+                          float* exp_avg_sq, void* hip_stream) {
   if (P < 0 || M < 0 || !supported_F(F)) return fail(OLSR_ERR_ARG, "P, M must be >= 0 and F one of 0, 3, 15, 16, 32");
   if (!params || params->step < 1) return fail(OLSR_ERR_ARG, "adam params are required and step must be >= 1");
   if (n_flats < 1 || n_flats > OLSR_ADAM_MAX_BUCKETS || !flats)
@@ -772,8 +780,8 @@ int olsr_adam_step_sum(int32_t P, int32_t M, int32_t F, const olsr_adam_params* 
   if (!means3D || !opacities || !scales || !rotations || !exp_avg || !exp_avg_sq || (M > 0 && !shs) ||
       (F > 0 && !language))
     return fail(OLSR_ERR_ARG, "every parameter array and both moment buffers are required");
-  launch_adam_step(P, M, F, *params, flats, n_flats, means3D, shs, opacities, scales, rotations, language, exp_avg,
-                   exp_avg_sq, (hipStream_t)hip_stream);
+  launch_adam_step(P, M, F, *params, flats, reinterpret_cast<const unsigned long long* const*>(row_masks), n_flats, means3D,
+                   shs, opacities, scales, rotations, language, exp_avg, exp_avg_sq, (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("adam_step_sum launch: ") + hipGetErrorString(e));
   return OLSR_OK;
@@ -869,6 +877,21 @@ int olsr_accumulate_gradients(int32_t P, int32_t M, int32_t F, int32_t assign, c
                     radii, flat, densify, max_radii, (hipStream_t)hip_stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("accumulate launch: ") + hipGetErrorString(e));
+  return OLSR_OK;
+}
+
+int olsr_bucket_add(int32_t P, int32_t width, float* dst_flat, float* dst_densify, int32_t* dst_max_radii,
+                    uint64_t* dst_row_mask, const float* src_flat, const float* src_densify, const int32_t* src_max_radii,
+                    const uint64_t* src_row_mask, void* hip_stream) {
+  if (P < 0 || width <= 0) return fail(OLSR_ERR_ARG, "P must be >= 0, width > 0");
+  if (P == 0) return OLSR_OK;
+  if (!dst_flat || !dst_densify || !dst_max_radii || !src_flat || !src_densify || !src_max_radii)
+    return fail(OLSR_ERR_ARG, "bucket_add: flat, densify and max_radii of both buckets are required");
+  launch_bucket_add(P, width, dst_flat, src_flat, reinterpret_cast<unsigned long long*>(dst_row_mask),
+                    reinterpret_cast<const unsigned long long*>(src_row_mask), dst_densify, src_densify, dst_max_radii,
+                    src_max_radii, (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("bucket_add launch: ") + hipGetErrorString(e));
   return OLSR_OK;
 }
 

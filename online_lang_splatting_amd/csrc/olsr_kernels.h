@@ -153,11 +153,14 @@ void launch_accumulate(int P, int M, int F, bool assign, const float* dmeans3D, 
                        const float* dopacity, const float* dscales, const float* drot, const float* dlang,
                        const float* dmeans2D, const int32_t* radii, float* flat, float* densify, int32_t* max_radii,
                        hipStream_t st);
+void launch_bucket_add(int P, int width, float* dst, const float* src, unsigned long long* dst_mask,
+                       const unsigned long long* src_mask, float* dst_densify, const float* src_densify,
+                       int32_t* dst_radii, const int32_t* src_radii, hipStream_t st);
 
 // k_adam.hip
 constexpr int OLSR_ADAM_MAX_BUCKETS = 8;
-void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* const* flats, int n_flats,
-                      float* means3D, float* shs, float* opacities, float* scales, float* rotations, float* language,
+void launch_adam_step(int P, int M, int F, const olsr_adam_params& hp, const float* const* flats,
+                      const unsigned long long* const* masks, int n_flats, float* means3D, float* shs, float* opacities, float* scales, float* rotations, float* language,
                       float* exp_avg, float* exp_avg_sq, hipStream_t st);
 
 // k_pose.hip

@@ -82,7 +82,8 @@ class GradientBucket:
         # (+ one small MAX all-reduce): [P x width gradients | P x 2 densification statistics]
         # (row P is a spare row that stays zero: the fill target of the capacity-bound sparse exchange)
         off = ((P + 1) * layout.width + 3) // 4 * 4  # keep the statistics 16-byte aligned
-        self.sum_storage = torch.zeros(off + 2 * P, dtype=torch.float32, device=device)
+        # (padded to a multiple of 64 floats: the two-phase dense exchange cuts the storage into `world` equal chunks in place)
+        self.sum_storage = torch.zeros((off + 2 * P + 63) // 64 * 64, dtype=torch.float32, device=device)
         self.flat = self.sum_storage[: P * layout.width].view(P, layout.width)
         self.flat_ext = self.sum_storage[: (P + 1) * layout.width].view(P + 1, layout.width)
         # xyz_gradient_accum, denom (gaussian_model.py:965-969): sum-reducible once the norm is taken per view
@@ -105,6 +106,25 @@ class GradientBucket:
                 self.row_mask.bitwise_or_(other.row_mask)
             else:
                 self.row_mask.fill_(-1)
+
+    def add_bucket(self, other):
+        """self += other (gradient rows and densification statistics SUM, max_radii MAX): the sum of the lane buckets of a
+        step.  On the GPU one launch of olsr_bucket_add that reads and writes only the rows `other`'s row mask flags
+        (FrameLanes' buckets keep one); on CPU tensors the torch formulation — the kernel's specification."""
+        if self.flat.is_cuda:
+            P, width = self.flat.shape
+            check(lib().olsr_bucket_add(
+                P, width, self.flat.data_ptr(), self.densify.data_ptr(), self.max_radii.data_ptr(),
+                self.row_mask.data_ptr() if self.row_mask is not None else None, other.flat.data_ptr(),
+                other.densify.data_ptr(), other.max_radii.data_ptr(),
+                other.row_mask.data_ptr() if other.row_mask is not None else None,
+                C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)))
+            if self.row_mask is not None and other.row_mask is None:
+                self.rows_unknown()
+            return
+        self.sum_storage.add_(other.sum_storage)
+        self.rows_merge(other)
+        torch.maximum(self.max_radii, other.max_radii, out=self.max_radii)
 
     def zero_(self):
         self.flat.zero_()
@@ -200,6 +220,20 @@ class GradientBucket:
         (With an optimiser the second phase carries the updated PARAMETER rows instead: FrameShardedStep.optimizer_step.)"""
         import torch.distributed as dist
         P, width = self.flat.shape
+        n = self.sum_storage.numel()
+        if self._multi(group) and dist.get_backend(group) == "nccl" and n % world == 0:
+            # Both phases IN PLACE on the one SUM storage [gradient rows | spare row | statistics | padding]: rank r reduces
+            # chunk r (ncclReduceScatter with recvbuff = sendbuff + r x chunk), then the chunks are gathered where they lie —
+            # three collectives (with the MAX of the radii) and no staging copy.  Round 4 went through row-aligned staging
+            # buffers (a 58 MB out-of-place receive, its copy back, a clone for the gather) and four collectives; every rank
+            # wants the whole sum here, so the chunks need not respect row ownership.
+            chunk = n // world
+            mine = self.sum_storage[rank * chunk:(rank + 1) * chunk]
+            dist.reduce_scatter_tensor(mine, self.sum_storage, op=dist.ReduceOp.SUM, group=group)
+            dist.all_gather_into_tensor(self.sum_storage, mine, group=group)
+            dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
+            self.rows_unknown()
+            return self.owned_rows(P, rank, world)
         r0, r1 = self.reduce_scatter(rank, world, group)
         if not self._multi(group) or dist.get_backend(group) != "nccl":
             return r0, r1  # (gloo: reduce_scatter() already all-reduced)
@@ -214,8 +248,26 @@ class GradientBucket:
             self.flat.copy_(full[:P])
         return r0, r1
 
+    # the sparse exchange is two collectives and three local passes (flags, pack, unpack) where the dense one is one
+    # collective: it has to save at least a quarter of the payload to be the faster one
+    SPARSE_MARGIN = 0.75
+
+    def sparse_pays(self, rows, capacity=None):
+        """Choosing the exchange from the data: does exchanging `rows` packed gradient rows (the union
+        of the ranks' non-zero rows; `capacity` rows travel in the capacity-bound form) move fewer bytes than the dense
+        bucket (by the margin above)?  Payloads per rank: sparse = 8 P (flags + radii, int32) + (rows x width + 2 P) x 4;
+        dense = the bucket, the statistics and the radii.  On the i.i.d. volume of SURVEY 8(d) a view leaves 2 % of the rows live and sparse wins by
+        an order of magnitude; on a surface map (scene.make_room_scene) one view leaves 20 % live and the union over a
+        12-view window two thirds — there the dense two-phase exchange is the smaller one.
+        Returns (pays, sparse_bytes, dense_bytes)."""
+        P, width = self.flat.shape
+        n = int(rows if capacity is None else capacity)
+        sparse_bytes = 8 * P + (n * width + 2 * P) * 4
+        dense_bytes = self.sum_storage.numel() * 4 + 4 * P
+        return sparse_bytes < self.SPARSE_MARGIN * dense_bytes, sparse_bytes, dense_bytes
+
     # ---- sparse exchange (SURVEY.md section 8(f) row 2, the parity-preserving half) ------------------------------
-    def sparse_all_reduce(self, group=None):
+    def sparse_all_reduce(self, group=None, auto=False):
         """Exchange only the gradient rows that are non-zero on at least one rank: every other row is zero everywhere, so
         its sum is the zero it already holds.  Saturation ends most tile lists early, so only the front layer of Gaussians
         receives gradients at all (config 3: 2 % of the visible ones per view) — far fewer rows than the ones a rank merely
@@ -225,7 +277,10 @@ class GradientBucket:
         of the per-rank bitmasks of non-zero rows (P / 8 bytes), all-reduce (SUM) of the packed [n_active, width] rows, and
         the small side buffers — the two densification statistics (SUM, [P, 2]) and max_radii (MAX, [P]) — dense.
         Same values as all_reduce().
-        Returns dict(active_rows, bytes_dense, bytes_sparse) — the bytes each rank contributes to the wire."""
+        auto: once the union's size is known (it is identical on every rank) the rows travel packed only if that is the
+        smaller payload (sparse_pays), else the bucket is all-reduced densely — the flags have told every rank the same thing,
+        so all ranks take the same branch; max_radii is already reduced by then and the row mask holds the exact union.
+        Returns dict(active_rows, bytes_dense, bytes_sparse, chosen) — the bytes each rank contributes to the wire."""
         import torch.distributed as dist
         P, width = self.flat.shape
         dense_bytes = self.sum_storage.numel() * 4 + self.max_radii.numel() * 4
@@ -247,8 +302,15 @@ class GradientBucket:
                                               mask_p, self.densify.data_ptr(), None, None, scratch.data_ptr(),
                                               status.data_ptr(), stream))                      # count only
             n = int(status[0].item())                                                           # identical on every rank
+            pays, sparse_b, dense_b = self.sparse_pays(n)
             if not multi:
-                return dict(active_rows=n, bytes_dense=dense_bytes, bytes_sparse=0)
+                return dict(active_rows=n, bytes_dense=dense_bytes, bytes_sparse=0,
+                            chosen=("sparse" if (pays or not auto) else "dense"))
+            if auto and not pays:
+                # the dense leg: gradient rows and statistics in one SUM all-reduce (the radii travelled with the flags; the
+                # row mask is the union the count-only pack left: exact for the summed bucket too)
+                dist.all_reduce(self.sum_storage, op=dist.ReduceOp.SUM, group=group)
+                return dict(active_rows=n, bytes_dense=dense_bytes, bytes_sparse=int(8 * P) + dense_b - 4 * P, chosen="dense")
             cap = max(n, 1)
             idx = torch.empty(cap, dtype=torch.int32, device=dev)
             fsum = torch.empty(cap * width + 2 * P, dtype=torch.float32, device=dev)
@@ -258,11 +320,13 @@ class GradientBucket:
             dist.all_reduce(fsum, op=dist.ReduceOp.SUM, group=group)
             check(L.olsr_sparse_exchange_unpack(P, width, cap, idx.data_ptr(), fsum.data_ptr(), self.flat.data_ptr(),
                                                 self.densify.data_ptr(), stream))
-            return dict(active_rows=n, bytes_dense=dense_bytes, bytes_sparse=int(8 * P + (n * width + 2 * P) * 4))
+            return dict(active_rows=n, bytes_dense=dense_bytes, bytes_sparse=int(8 * P + (n * width + 2 * P) * 4), chosen="sparse")
         # CPU tensors (the gloo tests): torch operations, four collectives - the specification of the path above
         nonzero = (self.flat != 0).any(dim=1)
         if not self._multi(group):
-            return dict(active_rows=int(nonzero.sum()), bytes_dense=dense_bytes, bytes_sparse=0)
+            n_ = int(nonzero.sum())
+            return dict(active_rows=n_, bytes_dense=dense_bytes, bytes_sparse=0,
+                        chosen=("sparse" if (self.sparse_pays(n_)[0] or not auto) else "dense"))
         world = dist.get_world_size(group)
         self.rows_unknown()
         nb = (P + 7) // 8
@@ -277,13 +341,17 @@ class GradientBucket:
             union |= every.view(world, nb)[r]
         anyrow = ((union.view(nb, 1).to(torch.int32) // weights) % 2).reshape(-1)[:P]
         idx = torch.nonzero(anyrow, as_tuple=False).reshape(-1)            # identical on every rank, ascending
+        if auto and not self.sparse_pays(int(idx.numel()))[0]:
+            dist.all_reduce(self.sum_storage, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
+            return dict(active_rows=int(idx.numel()), bytes_dense=dense_bytes, bytes_sparse=int(nb) + dense_bytes, chosen="dense")
         packed = self.flat.index_select(0, idx)
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         self.flat.index_copy_(0, idx, packed)
         dist.all_reduce(self.densify, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=group)
         return dict(active_rows=int(idx.numel()), bytes_dense=dense_bytes,
-                    bytes_sparse=int(nb + idx.numel() * width * 4 + P * 12))
+                    bytes_sparse=int(nb + idx.numel() * width * 4 + P * 12), chosen="sparse")
 
     def sparse_all_reduce_capped(self, capacity, group=None):
         """The sparse exchange WITHOUT a host synchronisation, for callers that keep several frames in flight
@@ -384,6 +452,7 @@ class FusedAdam:
         self.exp_avg = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(P, layout.width, dtype=torch.float32, device=device)
         self.step_count = 0
+        self.use_row_masks = True  # (False: read every gradient row, the A/B leg of tests and bench)
 
     def step(self, bucket, params: Dict[str, torch.Tensor], lrs: Dict[str, float], rows=None):
         """params: means3D [P,3], shs [P,M,3], opacities [P(,1)], scales [P,3], rotations [P,4], language [P,F]
@@ -412,12 +481,19 @@ class FusedAdam:
             t = params.get(name)
             return t.data_ptr() + 4 * r0 * per_row[name] if t is not None and t.numel() > 0 else None
         stream = C.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)
-        if len(buckets) > 1:
+        # rows a bucket's row mask proves zero are not read (olsr_adam_step_masked: the update stays dense, the bits are
+        # torch.optim.Adam's); a row range that does not start on a mask word (64 rows) takes the unmasked step
+        masked = self.use_row_masks and r0 % 64 == 0 and any(b.row_mask is not None for b in buckets)
+        if len(buckets) > 1 or masked:
             flats = (C.c_void_p * len(buckets))(*[b.flat.data_ptr() + 4 * r0 * W for b in buckets])
-            check(lib().olsr_adam_step_sum(r1 - r0, M, F, C.byref(hp), len(buckets), flats, p("means3D"), p("shs"),
-                                           p("opacities"), p("scales"), p("rotations"), p("language"),
-                                           self.exp_avg.data_ptr() + 4 * r0 * W, self.exp_avg_sq.data_ptr() + 4 * r0 * W,
-                                           stream))
+            masks = None
+            if masked:
+                masks = (C.c_void_p * len(buckets))(*[(b.row_mask.data_ptr() + 8 * (r0 // 64)) if b.row_mask is not None else None
+                                                      for b in buckets])
+            check(lib().olsr_adam_step_masked(r1 - r0, M, F, C.byref(hp), len(buckets), flats, masks, p("means3D"), p("shs"),
+                                              p("opacities"), p("scales"), p("rotations"), p("language"),
+                                              self.exp_avg.data_ptr() + 4 * r0 * W,
+                                              self.exp_avg_sq.data_ptr() + 4 * r0 * W, stream))
             return
         check(lib().olsr_adam_step(r1 - r0, M, F, C.byref(hp), bucket.flat.data_ptr() + 4 * r0 * W, p("means3D"),
                                    p("shs"), p("opacities"), p("scales"), p("rotations"), p("language"),
@@ -661,6 +737,10 @@ class FrameShardedStep:
                         all-gathered — 2 x (G-1)/G of the PARAMETER bytes + (G-1)/G of the gradient bytes per GPU,
                         all of it spread over the G-1 direct xGMI links;
       "sparse"          all-reduce of the gradient rows that are non-zero on some rank (GradientBucket.sparse_all_reduce).
+      "auto"            chosen per step from the data: the ranks learn the union of their non-zero rows (8 P bytes of flags
+                        and radii), and the rows travel packed only when that is the smaller payload — else the bucket is
+                        all-reduced densely (GradientBucket.sparse_pays; `wire["chosen"]` says which).  A view of the
+                        i.i.d. volume leaves 2 % of the rows live, a view of a surface map 20 %, a 12-view window of it 67 %.
     A capacity overflow on ANY rank (instances or gradient rows: that view contributed zeros) is surfaced: the
     per-rank flag travels with the MAX all-reduce and `run` raises OverflowError on every rank, with the capacity
     that would have sufficed, so the caller can regrow its workspace and repeat the step."""
@@ -669,7 +749,7 @@ class FrameShardedStep:
         """workspace: a RasterWorkspace (this rank's views are rendered one after the other) or a FrameLanes (they are
         rendered `len(lanes)` at a time on the lanes' streams, each lane accumulating into its own bucket; the lane
         buckets are summed — in lane order, a fixed order — before the exchange)."""
-        assert exchange in ("all_reduce", "reduce_scatter", "sparse")
+        assert exchange in ("all_reduce", "reduce_scatter", "sparse", "auto")
         if isinstance(workspace, FrameLanes):
             self.lanes = list(workspace.lanes)
         else:
@@ -751,15 +831,12 @@ class FrameShardedStep:
                 total.rows_unknown()
                 total.max_radii.copy_(self.lanes[used[0]][1].max_radii)
             for i in used[1:]:
-                b = self.lanes[i][1]
-                total.sum_storage.add_(b.sum_storage)
-                total.rows_merge(b)
-                torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
+                total.add_bucket(self.lanes[i][1])
         multi = GradientBucket._multi(self.group)
         if self.exchange == "reduce_scatter":
             self.owned = total.reduce_scatter(self.rank, self.world, self.group)
-        elif self.exchange == "sparse":
-            self.wire = total.sparse_all_reduce(self.group)
+        elif self.exchange in ("sparse", "auto"):
+            self.wire = total.sparse_all_reduce(self.group, auto=(self.exchange == "auto"))
         else:
             total.all_reduce(self.group)
         ovf = self._ovf[0].clone()

@@ -243,12 +243,11 @@ class MappingStep:
         multi = GradientBucket._multi()
         mark("lane_sum:begin", main)
         for b in used[1:]:
-            if multi:   # an exchange follows: it needs the total in one place
-                total.sum_storage.add_(b.sum_storage)
-                total.rows_merge(b)
+            if multi:   # an exchange follows: it needs the total in one place (only the rows b's row mask flags move)
+                total.add_bucket(b)
             else:       # one process: only the small densification statistics are summed, Adam adds the gradient rows itself
                 total.densify.add_(b.densify)
-            torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
+                torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
         mark("lane_sum:end", main)
         total.all_reduce()
         mark("adam:begin", main)

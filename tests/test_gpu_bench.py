@@ -183,17 +183,23 @@ def test_forced_single_rank_exchange_over_rccl_and_a_clean_stdout():
     """OLSR_BENCH_FORCE_EXCHANGE=1: a group of ONE rank over RCCL with every collective of the exchange issued - what a one-GPU
     box can run of the multi-GPU step.  RCCL prints a version banner to the process's stdout when its first communicator is
     created; the line must stay the ONLY thing on stdout (the driver parses it), whatever native code prints."""
-    for exchange in ("sparse", "all_reduce", "reduce_scatter"):
+    for exchange in ("auto", "sparse", "all_reduce", "reduce_scatter"):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OLSR_BENCH_BACKEND")}
         p = subprocess.run([sys.executable, "bench.py", "--config", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-                            "--no-extra-legs", "--isolated-steps", "0", "--exchange", exchange], cwd=ROOT,
+                            "--no-extra-legs", "--isolated-steps", "0", "--repeats", "2", "--exchange", exchange], cwd=ROOT,
                            env=dict(env, OLSR_BENCH_FORCE_EXCHANGE="1"), capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (exchange, p.stdout[-1500:], p.stderr[-1500:])
         lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, lines
         d = json.loads(lines[0])
         c = d["config"]
-        assert d["n_gpus"] == 1 and c["exchange"] == exchange and c["exchange_forced_single_rank"] and c["backend"] == "nccl"
+        assert d["n_gpus"] == 1 and c["exchange_requested"] == exchange and c["exchange_forced_single_rank"] and c["backend"] == "nccl"
+        if exchange == "auto":   # chosen from the measured union of the gradient rows, and the line says how
+            det = c["exchange_detail"]
+            assert c["exchange"] == det["chosen"] == ("sparse" if det["sparse_pays"] else "reduce_scatter")
+            assert 0 < det["rows_in_union_at_setup"] <= c["P"] and 0 < det["live_row_fraction_per_view"] <= 1
+        else:
+            assert c["exchange"] == exchange
         chk = c["exchange_detail"]["check"]
         assert chk["equals_dense"] and chk["radii_equal"] and chk["identical_on_every_rank"]
         assert chk["nonzero_gradient_rows_after"] > 0

@@ -203,7 +203,7 @@ def _rccl_worker(rank, world, port, ret):
         M = sc.shs.shape[1]
         ws = RasterWorkspace(P8, W, H, F, M, 400000, dev)
         out = {}
-        for exchange in ("all_reduce", "sparse", "reduce_scatter"):
+        for exchange in ("all_reduce", "sparse", "reduce_scatter", "auto"):
             st = FrameShardedStep(ws, 0, 1, exchange=exchange)
             params = {k: v.clone() for k, v in g.items() if k != "bg"}
             adam = FusedAdam(P8, GradLayout(M, F), dev)

@@ -110,3 +110,73 @@ def test_a_garbage_tile_order_hint_stays_in_bounds(hip):
         for k in ref:
             assert torch.equal(out[k], ref[k]), (fill, k)
         assert sorted(ws.tile_order.tolist()) == list(range(n))   # the order this frame measured: a permutation again
+
+
+@pytest.mark.parametrize("scene_kind,P,F,lanes_n", [("volume", 30000, 15, 3), ("room", 20000, 15, 4), ("volume", 64 * 9 + 5, 0, 2)])
+def test_masked_adam_and_masked_lane_sum_equal_the_dense_ones(hip, scene_kind, P, F, lanes_n):
+    """Round 5: FusedAdam does not read gradient rows a bucket's row mask proves zero
+    (olsr_adam_step_masked) and the sum of the lane buckets moves only flagged rows (olsr_bucket_add).  The optimiser stays
+    DENSE: parameters and both moments after several steps over changing views equal, bit for bit, those of the step that
+    reads every row (which tests/test_gpu_api.py holds to torch.optim.Adam); the summed bucket equals torch's add."""
+    from online_lang_splatting_amd.frame_shard import FrameLanes, FusedAdam, GradLayout, GradientBucket
+    from online_lang_splatting_amd.scene import make_room_scene
+    dev = torch.device(DEV)
+    W, H = 320, 180
+    if scene_kind == "room":
+        rs = make_room_scene(P, W, H, F, views=6, seed=3)
+        sc, cams = rs.scene, [_cam(c, dev) for c in rs.cameras]
+    else:
+        sc = make_scene(P, W, H, F, seed=21)
+        cams = [_cam(default_camera(W, H, y, t), dev) for y, t in ((0.0, 0.0), (5.0, 0.1), (-7.0, -0.2), (0.0, 300.0), (2.0, 0.0), (9.0, 0.3))]
+    M = sc.shs.shape[1]
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=None if F == 0 else sc.language.to(dev))
+    cot = [None if t is None else t.to(dev) for t in sc.cotangents(5)]
+    lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
+    lanes = FrameLanes(lanes_n, sc.P, W, H, F, M, 600_000, dev)   # buckets with row masks
+    results = {}
+    for masked in (True, False):
+        params = dict(means3D=g["means3D"].clone(), shs=g["shs"].clone(), opacities=g["opacities"].clone(),
+                      scales=g["scales"].clone(), rotations=g["rotations"].clone(),
+                      language=None if F == 0 else g["language"].clone())
+        adam = FusedAdam(sc.P, GradLayout(M, F), dev)
+        adam.use_row_masks = masked
+        for it in range(3):
+            used = []
+            for v in range(lanes_n + 1):                    # one lane gets two views: an overwrite and an add
+                ws, bucket, _ = lanes.lanes[v % lanes_n]
+                first = bucket not in used
+                if first:
+                    used.append(bucket)
+                ws.set_scene(sh_degree=sc.sh_degree, **cams[(it + v) % len(cams)], **g)
+                ws.forward()
+                ws.backward(*cot, bucket=bucket, first=first, bucket_only=True)
+            adam.step(used, params, lrs)
+            if it == 1:
+                adam.step(used[0], params, lrs)             # the single-bucket form takes the masked path too
+        torch.cuda.synchronize()
+        results[masked] = (params, adam.exp_avg.clone(), adam.exp_avg_sq.clone())
+    for k, t in results[True][0].items():
+        if t is not None:
+            assert torch.equal(t, results[False][0][k]), k
+    assert torch.equal(results[True][1], results[False][1]) and torch.equal(results[True][2], results[False][2])
+    assert float((results[True][0]["means3D"] - g["means3D"]).abs().max()) > 0
+    # the lane sum: olsr_bucket_add against torch's dense add, masks merged
+    total, others = lanes.lanes[0][1], [b for _, b, _ in lanes.lanes[1:]]
+    ref = total.sum_storage.clone()
+    ref_r = total.max_radii.clone()
+    for b in others:
+        ref.add_(b.sum_storage)
+        torch.maximum(ref_r, b.max_radii, out=ref_r)
+        total.add_bucket(b)
+    torch.cuda.synchronize()
+    assert torch.equal(total.sum_storage, ref) and torch.equal(total.max_radii, ref_r)
+    nz = (total.flat != 0).any(dim=1)
+    bits = ((total.row_mask.view(-1, 1) >> torch.arange(64, device=dev)) & 1).reshape(-1)[:sc.P].bool()
+    assert bool((bits | ~nz).all())
+    # a source without a mask is added densely and leaves the destination's mask "unknown"
+    plain = GradientBucket(sc.P, GradLayout(M, F), dev)
+    plain.flat.fill_(0.5)
+    before = total.flat.clone()
+    total.add_bucket(plain)
+    assert torch.equal(total.flat, before + 0.5) and int((total.row_mask != -1).sum()) == 0
