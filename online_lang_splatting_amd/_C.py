@@ -199,6 +199,21 @@ def rasterize_language_gaussians(bg, means3D, colors, language, opacity, scales,
                     image_width, sh, degree, campos, prefiltered, debug)
 
 
+# ctypes twin of the compiled binding's g_rows_per_instance / g_rows_redone: [unpacked ratio, packed ratio, backwards redone]
+_ROWS_PER_INSTANCE = [0.0, 0.0, 0]
+
+
+def debug_rows_ratio(packed, ratio=-1.0):
+    """(tests) Set (ratio >= 0) / read the rows-per-instance figure the next backward guesses its scratch size from, in
+    whichever binding serves the calls.  Returns (ratio in force, backwards that had to be redone exactly so far)."""
+    ext = compiled_binding()
+    if ext is not None:
+        return tuple(ext.debug_rows_ratio(bool(packed), float(ratio)))
+    if ratio >= 0:
+        _ROWS_PER_INSTANCE[1 if packed else 0] = float(ratio)
+    return (_ROWS_PER_INSTANCE[1 if packed else 0], _ROWS_PER_INSTANCE[2])
+
+
 _GRAD_NAMES = ("dL_dmeans2D", "dL_dcolors", "dL_dlanguage", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
                "dL_dscales", "dL_drotations", "dL_dtau", "dL_dtau_sum", "dL_dconic", "dL_ddepths")
 
@@ -253,18 +268,41 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
         # would cost more than 64 MB — the GPU is busy with the forward meanwhile.
         tile, bwd_mode, _binning = cfg if cfg is not None else current_config()
         packed = bwd_mode == _abi.BWD_REFERENCE and tile == 15
-        rows = lib().olsr_backward_rows(int(rows_token), 1 if packed else 0, int(R), int(F))
-        scratch = torch.empty(lib().olsr_backward_scratch_bytes(rows, F), dtype=torch.uint8, device=dev)
-        check(lib().olsr_backward(
-            C.byref(s), rad.data_ptr() if P else None, geomBuffer.data_ptr(), int(R), binningBuffer.data_ptr(),
-            imageBuffer.data_ptr(), _abi.ALLOC_FN(0), None, scratch.data_ptr(), rows,
-            dc.data_ptr() if dc is not None else None,
-            dl.data_ptr() if dl is not None else None, dd.data_ptr() if dd is not None else None,
-            p("dL_dmeans2D"), p("dL_dconic"), p("dL_dopacity"), p("dL_dcolors"), p("dL_dlanguage"), p("dL_ddepths"),
-            p("dL_dmeans3D"), p("dL_dcov3D"), p("dL_dsh"), p("dL_dscales"), p("dL_drotations"), p("dL_dtau"),
-            p("dL_dtau_sum"), None, None, _stream(dev)))
-        # the scratch tensor may be released now: later work on this stream is ordered after the kernels
-        # that read it, and the caching allocator reuses blocks stream-ordered
+        # the policy of the compiled binding (csrc/olsr_torch.cpp: backward): the posted count, else a guess from the last
+        # verified frame's rows per instance — launched at once, verified while the GPU works, redone exactly if too small
+        L = lib()
+        bound = max(int(R), 0) * (2 if packed else 4)
+        rows = int(L.olsr_live_rows(int(rows_token), 1 if packed else 0))
+        guessed = False
+        if rows < 0 or rows > bound:
+            ratio = _ROWS_PER_INSTANCE[1 if packed else 0]
+            if rows_token > 0 and ratio > 0 and R > 0 and L.olsr_backward_scratch_bytes(bound, F) > (64 << 20):
+                rows, guessed = min(bound, int(1.5 * ratio * R) + 65536), True
+            else:
+                rows = int(L.olsr_backward_rows(int(rows_token), 1 if packed else 0, int(R), int(F)))
+
+        def launch(nrows):
+            scratch = torch.empty(L.olsr_backward_scratch_bytes(nrows, F), dtype=torch.uint8, device=dev)
+            check(L.olsr_backward(
+                C.byref(s), rad.data_ptr() if P else None, geomBuffer.data_ptr(), int(R), binningBuffer.data_ptr(),
+                imageBuffer.data_ptr(), _abi.ALLOC_FN(0), None, scratch.data_ptr(), nrows,
+                dc.data_ptr() if dc is not None else None,
+                dl.data_ptr() if dl is not None else None, dd.data_ptr() if dd is not None else None,
+                p("dL_dmeans2D"), p("dL_dconic"), p("dL_dopacity"), p("dL_dcolors"), p("dL_dlanguage"), p("dL_ddepths"),
+                p("dL_dmeans3D"), p("dL_dcov3D"), p("dL_dsh"), p("dL_dscales"), p("dL_drotations"), p("dL_dtau"),
+                p("dL_dtau_sum"), None, None, _stream(dev)))
+            # the scratch tensor may be released now: later work on this stream is ordered after the kernels
+            # that read it, and the caching allocator reuses blocks stream-ordered
+        launch(rows)
+        exact = -1 if guessed else (rows if (rows < bound or bound == 0) else -1)
+        if guessed:
+            exact = int(L.olsr_live_rows_wait(int(rows_token), 1 if packed else 0, 20000))
+            if exact < 0 or exact > rows:
+                _ROWS_PER_INSTANCE[2] += 1
+                launch(bound if (exact < 0 or exact > bound) else exact)
+        if exact >= 0 and R > 0:  # a slowly decaying maximum (views of one window differ in rows per instance)
+            now, old = exact / float(R), _ROWS_PER_INSTANCE[1 if packed else 0]
+            _ROWS_PER_INSTANCE[1 if packed else 0] = max(now, 0.9 * old + 0.1 * now)
     return g
 
 

@@ -91,7 +91,48 @@ struct FrameHousekeeping {
   int32_t* host_mailbox;
   int32_t host_seq;
   u32* live_rows;  // [4] zeroed here, summed by the tile-order kernel
+  u32* hint_base;  // (may be null) per-view tile orders of the synchronising entry: wave 1 of block 0 picks this frame's slot
+  const float* view;
 };
+
+// One wave: compare the frame's view matrix with the HINT_SLOTS stored ones and name the nearest slot (within HINT_VIEW_TOL per
+// entry), else recycle the least recently used one (olsr_api.hip describes the buffer).  Round 4 ran this as a launch of its
+// own in front of the forward composite.
+__device__ __forceinline__ void hint_pick_wave(u32* base, const float* __restrict__ view, int lane) {
+  float d = __builtin_inff();
+  u32 age = 0xFFFFFFFFu;
+  if (lane < HINT_SLOTS) {
+    d = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const float sv = __uint_as_float(base[4 + HINT_SLOTS + 16 * lane + i]);
+      const float e = fabsf(view[i] - sv);
+      d = (e == e && d >= e) ? d : ((e == e) ? e : __builtin_inff());  // max; a NaN (empty slot) matches nothing
+    }
+    age = base[4 + lane];
+  }
+  // nearest slot, else the least recently used one (ties: the lower slot)
+  float dbest = d;
+  int ibest = lane;
+  u32 abest = age;
+  int iold = lane;
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float od = __shfl_xor(dbest, m);
+    const int oi = __shfl_xor(ibest, m);
+    if (od < dbest || (od == dbest && oi < ibest)) { dbest = od; ibest = oi; }
+    const u32 oa = (u32)__shfl_xor((int)abest, m);
+    const int oo = __shfl_xor(iold, m);
+    if (oa < abest || (oa == abest && oo < iold)) { abest = oa; iold = oo; }
+  }
+  const int pick = (dbest <= HINT_VIEW_TOL) ? ibest : iold;
+  const float mine = (lane < 16) ? view[lane] : 0.f;
+  if (lane < 16) base[4 + HINT_SLOTS + 16 * pick + lane] = __float_as_uint(mine);
+  if (lane == 0) {
+    const u32 c = base[1] + 1u;
+    base[0] = (u32)pick;
+    base[1] = c;
+    base[4 + pick] = c;
+  }
+}
 
 __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int passes, int db,
@@ -149,6 +190,8 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
     const int p = tid >> 8, d = tid & 255;
     if (p < passes && h[p][d] != 0) atomicAdd(&hist[p * 256 + d], h[p][d]);
   }
+  if (do_house && blockIdx.x == 0 && house.hint_base != nullptr && (tid >> 6) == 1)
+    hint_pick_wave(house.hint_base, house.view, tid & 63);  // (wave 1: wave 0's lane 0 finishes the counters below)
   if (do_house && blockIdx.x == 0) {
     // the frame's counters: R = sum of the per-Gaussian instance counts (preprocess' block partials), the reference's
     // num_rendered (rect binning), overflow against the caller's capacity; work-list and row counters reset;
@@ -567,6 +610,8 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
     h.host_mailbox = house->host_mailbox;
     h.host_seq = house->host_seq;
     h.live_rows = house->live_rows;
+    h.hint_base = house->hint_base;
+    h.view = house->view;
   }
   int64_t nb = (n_host + (int64_t)FS_T * 4 - 1) / ((int64_t)FS_T * 4);  // 4 keys (one 16-byte load) per thread ...
   if (nb < 1) nb = 1;

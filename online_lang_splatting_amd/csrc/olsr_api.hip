@@ -173,10 +173,8 @@ thread_local int32_t g_last_token = 0;  // token of the last olsr_forward of thi
 thread_local RowsMailbox g_rows_call;
 
 // (per-view tile orders of the synchronising entry: described at order_hint_of below)
-constexpr int HINT_SLOTS = 16;
-constexpr int HINT_HDR = 4 + HINT_SLOTS + 16 * HINT_SLOTS;  // words in front of the orders
-static_assert(HINT_HDR % 4 == 0, "the orders stay 16-byte aligned");
-constexpr float HINT_VIEW_TOL = 0.03f;
+using olsr::HINT_HDR;
+using olsr::HINT_SLOTS;
 __global__ void hint_init_kernel(uint32_t* base, int ntiles) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)HINT_HDR + (size_t)HINT_SLOTS * (size_t)ntiles;
@@ -185,41 +183,8 @@ __global__ void hint_init_kernel(uint32_t* base, int ntiles) {
   else if (i < HINT_HDR) base[i] = 0x7FC00000u;  // NaN: matches no view
   else base[i] = (uint32_t)((i - HINT_HDR) % (size_t)ntiles);
 }
-__global__ __launch_bounds__(64) void hint_pick_kernel(uint32_t* base, const float* __restrict__ view) {
-  const int lane = threadIdx.x;
-  float d = __builtin_inff();
-  uint32_t age = 0xFFFFFFFFu;
-  if (lane < HINT_SLOTS) {
-    d = 0.f;
-    for (int i = 0; i < 16; ++i) {
-      const float sv = __uint_as_float(base[4 + HINT_SLOTS + 16 * lane + i]);
-      const float e = fabsf(view[i] - sv);
-      d = (e == e && d >= e) ? d : ((e == e) ? e : __builtin_inff());  // max; a NaN (empty slot) matches nothing
-    }
-    age = base[4 + lane];
-  }
-  // nearest slot, else the least recently used one (ties: the lower slot)
-  float dbest = d;
-  int ibest = lane;
-  uint32_t abest = age;
-  int iold = lane;
-  for (int m = 32; m >= 1; m >>= 1) {
-    const float od = __shfl_xor(dbest, m);
-    const int oi = __shfl_xor(ibest, m);
-    if (od < dbest || (od == dbest && oi < ibest)) { dbest = od; ibest = oi; }
-    const uint32_t oa = (uint32_t)__shfl_xor((int)abest, m);
-    const int oo = __shfl_xor(iold, m);
-    if (oa < abest || (oa == abest && oo < iold)) { abest = oa; iold = oo; }
-  }
-  const int pick = (dbest <= HINT_VIEW_TOL) ? ibest : iold;
-  if (lane < 16) base[4 + HINT_SLOTS + 16 * pick + lane] = __float_as_uint(view[lane]);
-  if (lane == 0) {
-    const uint32_t c = base[1] + 1u;
-    base[0] = (uint32_t)pick;
-    base[1] = c;
-    base[4 + pick] = c;
-  }
-}
+// (the slot is picked by block 0 of the depth sort's histogram kernel — hint_pick_wave, k_sort.hip: a launch of its own, one
+//  wave, cost the synchronising entry 5 us per frame on its dependent chain)
 // A synchronisation error (olsr_state.h, counters[8]) is detected on the device after the call that caused it has returned.
 // The sync-free entries report it through their status words; for the reference-shaped, synchronising API the last kernel of
 // a forward / backward also raises a flag in mapped host memory, and the FIRST library call after the GPU got there fails
@@ -266,7 +231,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     // digit totals of the four depth passes in one read of the keys + the frame's counters (instances emitted,
     // the reference's num_rendered, overflow against the capacity), tile ranges reset to "empty"
     FusedHouse house{g.part_rect, g.part_count, (s.P + 255) / 256, sync_mode ? 0x7FFFFFFFLL : (long long)bp.capacity,
-                     g.counters, num_rendered_dev, im.ranges, 2 * d.ntiles, nullptr, 0, im.live_rows};
+                     g.counters, num_rendered_dev, im.ranges, 2 * d.ntiles, nullptr, 0, im.live_rows,
+                     view_hints, s.viewmatrix};  // (the synchronising entry: this frame's slot among the stream's per-view orders)
     if (sync_mode) {
       if (!g_pinned.p) {
         HIP_TRY(hipHostMalloc((void**)&g_pinned.p, 2 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -384,8 +350,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     g_rows_call.seq = tok;
     g_rows_call.sticky = g_rows.dp + 4 * ROWS_RING;
   }
-  if (view_hints != nullptr && s.P > 0) {  // (the synchronising entry) this frame's slot among the stream's per-view orders
-    hint_pick_kernel<<<1, 64, 0, st>>>(view_hints, s.viewmatrix);
+  if (view_hints != nullptr && s.P > 0) {  // (the synchronising entry; the slot was picked by the depth sort's histogram kernel)
     g_rows_call.hint_slot = view_hints;
     tile_order_inout = view_hints + HINT_HDR;
   }

@@ -87,7 +87,15 @@ struct FusedHouse {  // the frame's bookkeeping done by block 0 of the depth sor
   int32_t* host_mailbox;  // (may be null) device view of two host words: receives {R, host_seq}, in this order
   int32_t host_seq;
   uint32_t* live_rows;    // ImageState::live_rows (zeroed by the kernel)
+  uint32_t* hint_base;    // (may be null) the stream's per-view tile orders (olsr_api.hip: order_hint_of): the kernel picks this
+  const float* view;      //   frame's slot by its view matrix (hint_pick_wave)
 };
+// per-view tile orders of the synchronising entry (olsr_api.hip): [0] chosen slot, [1] use counter, [4, 4 + S) last use of every
+// slot, then S x 16 floats (view matrices, NaN = empty), then S x ntiles orders
+constexpr int HINT_SLOTS = 16;
+constexpr int HINT_HDR = 4 + HINT_SLOTS + 16 * HINT_SLOTS;  // words in front of the orders
+static_assert(HINT_HDR % 4 == 0, "the orders stay 16-byte aligned");
+constexpr float HINT_VIEW_TOL = 0.03f;
 bool fused_sort_applicable(int64_t n_host, int bits);
 int fused_sort_digit_bits(int bits, int* passes_out);
 // digit totals of all passes (hist[pass][256], zeroed beforehand); optionally the frame's bookkeeping

@@ -38,10 +38,21 @@ def _settings_args(rs):
     return (rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, rs.tanfovx, rs.tanfovy)
 
 
-def _split_tau(tau_sum):
-    """[6] -> (grad_theta[1,3], grad_rho[1,3]).  dL_dtau = [rho | theta] per Gaussian; the reference sums it over P with
-    torch.sum (:383-385), here the library's backward already left the sum behind (fixed order, one tiny kernel)."""
-    return tau_sum[3:].view(1, -1), tau_sum[:3].view(1, -1)
+def _split_tau(tau_sum, theta_shape=None, rho_shape=None):
+    """[6] -> (grad_theta, grad_rho).  dL_dtau = [rho | theta] per Gaussian; the reference sums it over P with
+    torch.sum (:383-385), here the library's backward already left the sum behind (fixed order, one tiny kernel).
+    The reference hands autograd [1, 3] views for parameters of shape [3] (cam_rot_delta / cam_trans_delta), which makes the
+    engine launch a sum-to-size reduction per parameter and per backward; views of the INPUT's shape carry the same three
+    numbers into .grad without those two kernels (round 5: 10 us of GPU time and their launch gaps per frame)."""
+    def shaped(t, shape):
+        if shape is not None:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            if n == 3:
+                return t.view(shape)
+        return t.view(1, -1)
+    return shaped(tau_sum[3:], theta_shape), shaped(tau_sum[:3], rho_shape)
 
 
 def _cotangent(g, shape, like):
@@ -68,6 +79,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.olsr_cfg = cfg
+        ctx.olsr_pose_shapes = (tuple(theta.shape), tuple(rho.shape))
         ctx.olsr_rows_token = _C.last_forward_token()  # the backward sizes its row scratch from this frame's exact count
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         ctx.mark_non_differentiable(radii, n_touched)
@@ -85,7 +97,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             *_settings_args(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
             binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True, rows_token=ctx.olsr_rows_token)
-        grad_theta, grad_rho = _split_tau(tau_sum)
+        grad_theta, grad_rho = _split_tau(tau_sum, *ctx.olsr_pose_shapes)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
 
@@ -106,6 +118,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.olsr_cfg = cfg
+        ctx.olsr_pose_shapes = (tuple(theta.shape), tuple(rho.shape))
         ctx.olsr_rows_token = _C.last_forward_token()  # the backward sizes its row scratch from this frame's exact count
         ctx.save_for_backward(colors_precomp, language_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geom, binning, img)
@@ -126,7 +139,7 @@ class _RasterizeLanguageGaussians(torch.autograd.Function):
             rs.bg, means3D, radii, colors_precomp, language_precomp, scales, rotations, rs.scale_modifier,
             cov3Ds_precomp, *_settings_args(rs), grad_out_color, grad_out_language, grad_out_depth, sh, rs.sh_degree,
             rs.campos, geom, ctx.num_rendered, binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True, rows_token=ctx.olsr_rows_token)
-        grad_theta, grad_rho = _split_tau(tau_sum)
+        grad_theta, grad_rho = _split_tau(tau_sum, *ctx.olsr_pose_shapes)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_language_precomp, grad_opacities,
                 grad_scales, grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)
 

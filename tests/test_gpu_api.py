@@ -54,6 +54,14 @@ def test_language_rasterizer_autograd_matches_c_level(hip, oracle):
     assert rel_err(rho.grad, tau[:3])[0] <= 1e-4 and rel_err(theta.grad, tau[3:])[0] <= 1e-4
     assert theta.grad.shape == (3,) and rho.grad.shape == (3,)
     oracle.release(fo["geom"])
+    # pose parameters of the reference's other shape ([1, 3] views are what its Function returns): same numbers, their shape
+    theta2 = torch.zeros(1, 3, device=dev, requires_grad=True)
+    rho2 = torch.zeros(1, 3, device=dev, requires_grad=True)
+    out = rast(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, language_precomp=lang, opacities=opac,
+               scales=scales, rotations=rots, cov3D_precomp=None, theta=theta2, rho=rho2)
+    ((out[0] * dc).sum() + (out[1] * dl).sum() + (out[3] * dd).sum()).backward()
+    assert theta2.grad.shape == (1, 3) and torch.equal(theta2.grad.reshape(3), theta.grad)
+    assert torch.equal(rho2.grad.reshape(3), rho.grad)
 
 
 @pytest.mark.parametrize("F", [0, 15])
@@ -797,6 +805,45 @@ def test_backward_scratch_is_exact_when_the_host_runs_ahead(hip):
     assert lib().olsr_backward_rows(tok, 1, R, 15) == lib().olsr_live_rows(tok, 1)
     assert lib().olsr_backward_rows(0, 1, R, 15) == 2 * R
     assert lib().olsr_live_rows_wait(tok + 7, 1, 1000) == -1  # never issued: times out
+
+
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+def test_a_guessed_backward_scratch_is_verified_and_redone_exactly(hip, binding, monkeypatch):
+    """Round 5: when the host reaches the backward before the forward has posted its row count, the bindings launch the
+    backward at once with a GUESSED scratch size (1.5 x the rows per instance of the last verified frame) and verify the
+    guess while the GPU works.  A guess that was too small — here forced by a ratio 100 x too low — makes that first backward
+    write zeros; the binding follows it with an exact second backward on the same stream.  The gradients are those of the
+    exactly sized call either way, bit for bit, and the redo is counted."""
+    from parity_common import fwd_args
+    monkeypatch.setenv("OLSR_BINDING", binding)
+    dev = torch.device(DEV)
+    sc = make_scene(150000, 800, 600, 15, seed=21)
+    a = fwd_args(sc, dev)
+    cots = [t.to(dev) for t in sc.cotangents(3)]
+
+    def pair():
+        R, color, lang, radii, geom, binb, img, depth, opac, nt = hip.rasterize_language_gaussians(*a)
+        tok = hip.last_forward_token()
+        args = [a[0], a[1], radii, a[2], a[3], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], *cots,
+                a[16], a[17], a[18], geom, R, binb, img, False]
+        return hip.backward_all(15, *args, rows_token=tok)      # no synchronisation in between
+
+    hip.debug_rows_ratio(True, 0.0)                             # (forget what earlier tests of this process left behind)
+    ref = pair()                                                # (establishes the ratio: exact count, waited for or posted)
+    torch.cuda.synchronize()
+    ratio, redone0 = hip.debug_rows_ratio(True)
+    assert 0.0 < ratio < 2.0
+    good = pair()                                               # a guess of 1.5 x that: large enough, no redo
+    torch.cuda.synchronize()
+    assert hip.debug_rows_ratio(True)[1] == redone0
+    hip.debug_rows_ratio(True, ratio / 100.0)
+    redo = pair()                                               # far too small: zeros first, then the exact backward
+    torch.cuda.synchronize()
+    ratio2, redone1 = hip.debug_rows_ratio(True)
+    assert redone1 == redone0 + 1 and abs(ratio2 - ratio) < 1e-4 * ratio   # (and the ratio is the verified one again)
+    for k in ref:
+        assert torch.equal(ref[k], good[k]) and torch.equal(ref[k], redo[k]), k
+    assert float(ref["dL_dmeans3D"].abs().max()) > 0
 
 
 def run_fwd_only(hip, sc, dev):
