@@ -416,6 +416,19 @@ def room_scene_leg(dev, dims, steps, seed=3):
             "loss_last_view_first_iteration": round(first, 6), "loss_last_view_final_iteration": round(float(stp.last_loss[0]), 6),
             "capacity_overflow": bool(any(w_.rendered()[1] or w_.backward_status()[1] for w_, _, _ in lanes.lanes))}
         del stp
+    for k, v in params.items():
+        if v is not None:
+            v.copy_(start[k])
+    stp = MappingStep(lanes, params, g_dev["bg"], 0, camd, rs.targets, lrs, exposure=torch.zeros(2, device=dev))
+    for _ in range(10):
+        stp.iteration()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(6):
+        stp.iteration()
+    torch.cuda.synchronize(dev)
+    mp["auto_loss"] = {"ms_per_iteration": round(1e3 * (time.perf_counter() - t0) / 6, 3), "calibration": stp.calibration}
+    del stp
     out["mapping"] = dict(mp, views=len(camd), views_in_flight=len(lanes))
     del lanes
     torch.cuda.empty_cache()
@@ -768,13 +781,30 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
 
     fused_leg = mapping_leg(True)
     two_leg = mapping_leg(False)
-    out["mapping_iteration_ms"] = fused_leg["ms_per_iteration"]
+    # MappingStep's default: the form is MEASURED by the object itself (iterations 3-6 alternate the two between HIP events)
+    for k, v in params.items():
+        if v is not None:
+            v.copy_(start[k])
+    st_auto = MappingStep(lanes, params, g_dev["bg"], sc.sh_degree, camd, targets, lrs, exposure=torch.zeros(2, device=dev))
+    for _ in range(9):
+        st_auto.iteration()
+    torch.cuda.synchronize(dev)
+    st_auto.iteration()
+    t0 = time.perf_counter()
+    for _ in range(mapping_iters):
+        st_auto.iteration()
+    torch.cuda.synchronize(dev)
+    auto_leg = {"ms_per_iteration": round(1e3 * (time.perf_counter() - t0) / mapping_iters, 3), "calibration": st_auto.calibration}
+    del st_auto
+    out["mapping_iteration_ms"] = auto_leg["ms_per_iteration"]
     out["mapping"] = {"views": views, "views_in_flight": len(lanes), "iterations": mapping_iters,
                       "what": f"{views} arc views x (render from raw parameters with the mapping loss incl. the 192x192 "
                               "language target in the composite's epilogue + backward into the gradient bucket) + sum of the "
                               "lane buckets + fused Adam step",
                       **fused_leg,
-                      "two_kernel_loss": dict(what="olsr_forward_async + olsr_mapping_loss instead (round 3)", **two_leg)}
+                      "two_kernel_loss": dict(what="olsr_forward_async + olsr_mapping_loss instead (round 3)", **two_leg),
+                      "auto_loss": dict(what="MappingStep's default (fused_loss='auto'): the object times both forms in its "
+                                             "iterations 3-6 and keeps the faster one", **auto_leg)}
     del lanes
     return out
 

@@ -479,8 +479,12 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
         const size_t plane = (size_t)fl.lh * fl.lw;
         float* s_win = s_feat;  // (idle: the last batch ended with a barrier, and tile_work's barrier is behind us)
         if (staged) {
+          // (quotients by reciprocal multiplication, exact for these ranges — i < B * FR, rem < wn: two integer divisions per
+          //  element cost ~80 vector instructions)
+          const float inv_wn = 1.0f / (float)wn, inv_ww = 1.0f / (float)ww;
           for (int i = tid; i < wn * F; i += 256) {
-            const int ch = i / wn, rem = i - ch * wn, yy = rem / ww, xx = rem - yy * ww;
+            const int ch = (int)(((float)i + 0.5f) * inv_wn), rem = i - ch * wn;
+            const int yy = (int)(((float)rem + 0.5f) * inv_ww), xx = rem - yy * ww;
             s_win[i] = fl.gt_lang[ch * plane + (size_t)(wy0 + yy) * fl.lw + (wx0 + xx)];
           }
           __syncthreads();

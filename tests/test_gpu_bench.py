@@ -89,6 +89,10 @@ def test_config3_line_carries_the_config4_substitute():
     assert room["isolated"]["value"] > 0 and room["four_in_flight"]["value"] > room["isolated"]["value"]
     assert room["exchange"]["chosen"] in ("sparse", "reduce_scatter") and room["exchange"]["union_rows_over_12_views"] >= rw["live_gradient_rows_gaussians"]
     assert room["tracking"]["pose_error_after"] < room["tracking"]["pose_error_start"]
+    for leg_ in (room["mapping"]["auto_loss"], c4["mapping"]["auto_loss"]):   # MappingStep's default measured both forms itself
+        cal_ = leg_["calibration"]
+        assert cal_["chosen"] in ("fused", "two_kernel") and len(cal_["fused_ms"]) >= 2 and len(cal_["two_kernel_ms"]) >= 2
+        assert (min(cal_["fused_ms"]) <= min(cal_["two_kernel_ms"])) == (cal_["chosen"] == "fused")
     for k_ in ("fused_loss", "two_kernel_loss"):
         m_ = room["mapping"][k_]
         assert not m_["capacity_overflow"] and m_["loss_last_view_final_iteration"] < m_["loss_last_view_first_iteration"]

@@ -92,3 +92,99 @@ def test_mapping_iterations_on_the_room_fit_the_raycast_targets(hip):
         last = float(st.last_loss[0])
         assert last < 0.9 * first, (fused, first, last)
         assert not any(ws.rendered()[1] or ws.backward_status()[1] for ws, _, _ in lanes.lanes)
+
+
+def test_mapping_step_measures_its_loss_form_and_keeps_per_view_hints_across_a_sliding_window(hip):
+    """MappingStep(fused_loss="auto") alternates the fused and the two-kernel loss in its iterations 3-6, keeps the faster and
+    says so; the parameters it reaches are those of either fixed form (the cotangents are bit-identical).  view_ids key the
+    tile-order hints: the keyframe window may grow, shrink and be reordered between iterations, and with more
+    than eight lanes in a single process the Adam step still sums every lane's bucket."""
+    from online_lang_splatting_amd.frame_shard import FrameLanes
+    from online_lang_splatting_amd.slam_iterations import MappingStep
+    W, H, F = 320, 180, 15
+    rs = make_room_scene(20_000, W, H, F, views=6, seed=9)
+    sc = rs.scene
+    dev = torch.device(DEV)
+    start = dict(means3D=sc.means3D.to(dev), shs=sc.shs.to(dev), opacities=torch.logit(sc.opacities).to(dev).contiguous(),
+                 scales=torch.log(sc.scales).to(dev).contiguous(), rotations=sc.rotations.to(dev), language=sc.language.to(dev))
+    camd = [dict(viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev),
+                 projmatrix_raw=c.projection_matrix.to(dev), campos=c.camera_center.to(dev), tanfovx=c.tanfovx,
+                 tanfovy=c.tanfovy) for c in rs.cameras]
+    lrs = dict(xyz=1.6e-4, sh_dc=2.5e-3, sh_rest=1.25e-4, opacity=0.05, scale=1e-3, rotation=1e-3, language=2.5e-3)
+    out = {}
+    for form in ("auto", True, False):
+        lanes = FrameLanes(3, sc.P, W, H, F, 1, 300_000, dev)
+        p = {k: v.clone() for k, v in start.items()}
+        st = MappingStep(lanes, p, sc.bg.to(dev), 0, camd, rs.targets, lrs, exposure=torch.zeros(2, device=dev), fused_loss=form)
+        for _ in range(12):
+            st.iteration()
+            torch.cuda.synchronize()   # (lets the calibration's events complete between iterations)
+        out[form] = ({k: v.clone() for k, v in p.items()}, st)
+    cal = out["auto"][1].calibration
+    assert cal is not None and cal["chosen"] in ("fused", "two_kernel") and out["auto"][1].auto is False
+    assert len(cal["fused_ms"]) >= 2 and len(cal["two_kernel_ms"]) >= 2
+    for k in start:   # the same parameters whichever form ran in which iteration
+        assert torch.equal(out["auto"][0][k], out[True][0][k]) and torch.equal(out[True][0][k], out[False][0][k]), k
+    # a sliding window: views keyed by id, reassigned / reordered / grown between iterations
+    st = out[True][1]
+    st.view_ids = [10, 11, 12, 13, 14, 15]
+    st.iteration()
+    st.cameras, st.targets, st.view_ids = camd[2:] + camd[:1], rs.targets[2:] + rs.targets[:1], [12, 13, 14, 15, 10]
+    st.iteration()
+    st.cameras, st.targets, st.view_ids = camd + camd[:2], rs.targets + rs.targets[:2], [10, 11, 12, 13, 14, 15, 16, 17]
+    st.iteration()
+    assert set(st.view_hints) >= {10, 11, 12, 13, 14, 15, 16, 17}
+    total = st.summed_gradients()
+    assert total.shape == (sc.P, 11 + 3 + F) and float(total.abs().max()) > 0
+    # more lanes than the Adam kernel sums at once: same parameters as with three lanes
+    lanes9 = FrameLanes(9, sc.P, W, H, F, 1, 300_000, dev)
+    views9 = camd + camd[:3]
+    tg9 = rs.targets + rs.targets[:3]
+    res = {}
+    for nl, lanes_ in ((9, lanes9), (3, FrameLanes(3, sc.P, W, H, F, 1, 300_000, dev))):
+        p = {k: v.clone() for k, v in start.items()}
+        st = MappingStep(lanes_, p, sc.bg.to(dev), 0, views9, tg9, lrs, exposure=torch.zeros(2, device=dev), fused_loss=True)
+        st.iteration()
+        torch.cuda.synchronize()
+        res[nl] = p
+    for k in start:   # (the sum over nine views associates differently with nine lanes than with three: to rounding)
+        assert torch.allclose(res[9][k], res[3][k], rtol=1e-4, atol=1e-6), k
+
+
+def test_tracking_loop_can_leave_the_final_images_behind(hip, oracle):
+    """the fused tracking iteration writes no images, so ws.out is stale afterwards — and the
+    reference's front end reads the last iteration's depth / opacity / render (utils/slam_frontend.py:664-665).
+    iteration(write_images=True) and render_final() leave the images of the pose that was rendered; they equal a plain
+    forward at that pose bit for bit."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    from online_lang_splatting_amd.slam_iterations import PoseState, TrackingLoop
+    W, H, F = 320, 180, 15
+    rs = make_room_scene(20_000, W, H, F, views=3, seed=12)
+    sc, cam = rs.scene, rs.cameras[0]
+    dev = torch.device(DEV)
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    T = torch.eye(4)
+    T[:3, :3], T[:3, 3] = cam.R, cam.T
+    T[0, 3] += 0.02
+    pose = PoseState(T.to(dev), cam.projection_matrix.to(dev), cam.tanfovx, cam.tanfovy)
+    ws = RasterWorkspace(sc.P, W, H, F, 1, 300_000, dev)
+    loop = TrackingLoop(ws, g, 0, pose, rs.targets[0][0].to(dev), rs.targets[0][1].to(dev))
+    ws.out["depth"].fill_(-7.0)
+    for _ in range(4):
+        loop.iteration()
+    torch.cuda.synchronize()
+    assert float(ws.out["depth"].max()) == -7.0                      # stale: the fused iteration wrote nothing
+    cam_before = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in pose.camera().items()}
+    loop.iteration(write_images=True)                                # renders at cam_before, then steps the pose
+    got = {k: ws.out[k].clone() for k in ("color", "depth", "opacity", "language")}
+    ws2 = RasterWorkspace(sc.P, W, H, F, 1, 300_000, dev)
+    ws2.set_scene(sh_degree=0, **cam_before, **g)
+    ref = ws2.forward()
+    for k in got:
+        assert torch.equal(got[k], ref[k]), k
+    fin = loop.render_final()                                        # the images of the pose AFTER the last step
+    ws2.set_scene(sh_degree=0, **pose.camera(), **g)
+    ref = ws2.forward()
+    for k in ("color", "depth", "opacity", "language"):
+        assert torch.equal(fin[k], ref[k]), k
