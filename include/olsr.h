@@ -610,6 +610,13 @@ void olsr_debug_sync_fault(int fault_bits, int spin_limit);
  * touches getenv.  Not for use while frames are in flight (a forward and its backward must see the same plan). */
 void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy);
 
+/* The depth sort of at most 8 192 Gaussians is ONE launch of one workgroup (histogram, the frame's bookkeeping and the four
+ * 8-bit passes inside the block; round 5) instead of a histogram launch and four radix passes with a ~10 us floor each; same
+ * order bit for bit.  enable = 0 sends small frames through the pass kernels as well (tests compare the two), 1 restores the
+ * default, negative leaves it.  Process-wide; seeded once from OLSR_SORT_SMALL.  A keys_per_thread pinned through
+ * olsr_debug_sort_knobs also selects the pass kernels. */
+void olsr_debug_sort_small(int enable);
+
 const char *olsr_last_error(void);
 const char *olsr_version(void);
 

@@ -134,6 +134,62 @@ __device__ __forceinline__ void hint_pick_wave(u32* base, const float* __restric
   }
 }
 
+// The frame's bookkeeping, done by ONE 1024-thread block between two kernels of the frame (block 0 of the depth sort's
+// histogram kernel, or the one-launch small depth sort): R = sum of the per-Gaussian instance counts (preprocess' block
+// partials), the reference's num_rendered (rect binning), overflow against the caller's capacity; work-list and row counters
+// reset; tile ranges set to "empty" (start = UINT_MAX, end = 0: the last tile-sort pass lowers / raises them with atomics).
+// s_red: 2 x FS_W words of LDS.
+__device__ __forceinline__ void frame_housekeeping(const FrameHousekeeping& house, int tid, u32 (*s_red)[FS_W]) {
+  u32 rect = 0, cnt = 0;
+  for (int i = tid; i < house.nparts; i += FS_T) {
+    rect += house.part_rect[i];
+    cnt += house.part_count[i];
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    rect += __shfl_xor(rect, m);
+    cnt += __shfl_xor(cnt, m);
+  }
+  if ((tid & 63) == 0) {
+    s_red[0][tid >> 6] = rect;
+    s_red[1][tid >> 6] = cnt;
+  }
+  for (int i = tid; i < house.nranges; i += FS_T) house.ranges[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
+  __syncthreads();
+  if (tid == 0) {
+    rect = 0;
+    cnt = 0;
+    for (int i = 0; i < FS_W; ++i) {
+      rect += s_red[0][i];
+      cnt += s_red[1][i];
+    }
+    const bool ok = (long long)cnt <= house.capacity && cnt <= 0x7FFFFFFFu;
+    house.counters[0] = (int32_t)cnt;
+    house.counters[1] = ok ? (int32_t)cnt : 0;
+    house.counters[2] = ok ? 0 : 1;
+    house.counters[3] = (int32_t)rect;
+    house.counters[4] = 0;
+    house.counters[5] = 0;
+    house.counters[6] = 0;
+    house.counters[7] = 0;
+    house.counters[8] = 0;  // synchronisation error of this frame (olsr_state.h)
+    house.counters[9] = 0;  // a tile with a depth cut-off did not saturate (include/olsr.h, OLSR_STATUS_CUT_MISS)
+    if (house.live_rows) {
+      house.live_rows[0] = 0;
+      house.live_rows[1] = 0;
+      house.live_rows[3] = 0;
+    }
+    if (house.num_rendered_dev) {
+      house.num_rendered_dev[0] = (int32_t)cnt;
+      house.num_rendered_dev[1] = ok ? 0 : 1;
+    }
+    if (house.host_mailbox) {  // the drop-in entry's host is polling for the count (olsr_api.hip: PinnedCount)
+      __hip_atomic_store(&house.host_mailbox[0], (int32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&house.host_mailbox[1], house.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int passes, int db,
                                                          u32* __restrict__ hist, FrameHousekeeping house,
@@ -192,59 +248,7 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
   }
   if (do_house && blockIdx.x == 0 && house.hint_base != nullptr && (tid >> 6) == 1)
     hint_pick_wave(house.hint_base, house.view, tid & 63);  // (wave 1: wave 0's lane 0 finishes the counters below)
-  if (do_house && blockIdx.x == 0) {
-    // the frame's counters: R = sum of the per-Gaussian instance counts (preprocess' block partials), the reference's
-    // num_rendered (rect binning), overflow against the caller's capacity; work-list and row counters reset;
-    // tile ranges set to "empty" (start = UINT_MAX, end = 0: the last tile-sort pass lowers / raises them with atomics)
-    u32 rect = 0, cnt = 0;
-    for (int i = tid; i < house.nparts; i += FS_T) {
-      rect += house.part_rect[i];
-      cnt += house.part_count[i];
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      rect += __shfl_xor(rect, m);
-      cnt += __shfl_xor(cnt, m);
-    }
-    if ((tid & 63) == 0) {
-      s_red[0][tid >> 6] = rect;
-      s_red[1][tid >> 6] = cnt;
-    }
-    for (int i = tid; i < house.nranges; i += FS_T) house.ranges[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
-    __syncthreads();
-    if (tid == 0) {
-      rect = 0;
-      cnt = 0;
-      for (int i = 0; i < FS_W; ++i) {
-        rect += s_red[0][i];
-        cnt += s_red[1][i];
-      }
-      const bool ok = (long long)cnt <= house.capacity && cnt <= 0x7FFFFFFFu;
-      house.counters[0] = (int32_t)cnt;
-      house.counters[1] = ok ? (int32_t)cnt : 0;
-      house.counters[2] = ok ? 0 : 1;
-      house.counters[3] = (int32_t)rect;
-      house.counters[4] = 0;
-      house.counters[5] = 0;
-      house.counters[6] = 0;
-      house.counters[7] = 0;
-      house.counters[8] = 0;  // synchronisation error of this frame (olsr_state.h)
-      house.counters[9] = 0;  // a tile with a depth cut-off did not saturate (include/olsr.h, OLSR_STATUS_CUT_MISS)
-      if (house.live_rows) {
-        house.live_rows[0] = 0;
-        house.live_rows[1] = 0;
-        house.live_rows[3] = 0;
-      }
-      if (house.num_rendered_dev) {
-        house.num_rendered_dev[0] = (int32_t)cnt;
-        house.num_rendered_dev[1] = ok ? 0 : 1;
-      }
-      if (house.host_mailbox) {  // the drop-in entry's host is polling for the count (olsr_api.hip: PinnedCount)
-        __hip_atomic_store(&house.host_mailbox[0], (int32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&house.host_mailbox[1], house.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
+  if (do_house && blockIdx.x == 0) frame_housekeeping(house, tid, s_red);
 }
 
 // ---- optional phase timing (olsr_debug_sort_timing): block b of every pass launched while it is set records the
@@ -524,6 +528,152 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   FS_STAMP(5);
 }
 
+// ---- the whole depth sort in ONE launch, for at most 8 192 Gaussians (round 5) ----------------
+// A radix pass has a floor of ~10 us whatever it sorts (launch, ticket, publish, look-back: dependent trips through the
+// fabric), and the depth sort is a histogram launch and four passes: BASELINE config 1 spent 48.7 us ordering 10 k depth
+// keys.  Up to SMALL_SORT_MAX keys fit one workgroup's registers and LDS: the four 8-bit LSD passes run inside the block —
+// per-wave digit counters, ballots for the rank inside a round of 64 keys, an exchange through LDS between passes: the ranking
+// of sort_pass_kernel without its publish / look-back — and nothing leaves the CU until the final order is written.  The
+// block also does the frame's bookkeeping and picks the drop-in entry's hint slot (what block 0 of sort_hist_kernel does),
+// so the stage is one launch instead of five.  Same result bit for bit: a stable LSD sort of (depth bits, index).
+// Measured (scripts/probe/small_sort.py, depth_sort stage, one launch against histogram + four passes): 1 000 Gaussians 14.3
+// against 34.6 us, 2 000: 15.7 / 40.1, 4 000: 23.2 / 46.2, 8 000: 36.0 / 47.0 — about 10 + 3.3 us per key and thread, one
+// CU doing what 256 idle ones cannot help with — and 63 / 48 at 10 000 (sixteen keys per thread), so the limit is 8 192:
+// BASELINE config 1 (10 k Gaussians) keeps the pass kernels and its 48 us.
+constexpr int SMALL_SORT_MAX = 8192;
+
+template <int KPT>
+__global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict__ keys_in, int n,
+                                                          u32* __restrict__ vals_out, const u32* __restrict__ inst_count,
+                                                          u32* __restrict__ emit_totals, FrameHousekeeping house) {
+  constexpr u32 NB = 256, DMASK = 255;
+  constexpr int CHUNK = FS_T * KPT;
+  extern __shared__ __attribute__((aligned(16))) u32 fs_smem[];
+  u32* cnt = fs_smem;             // [16][256] per-wave digit counts -> per-wave starts
+  u32* ex_key = cnt + FS_W * NB;  // [CHUNK]
+  u32* ex_val = ex_key + CHUNK;   // [CHUNK]
+  __shared__ u32 s_w[2 * FS_W];
+  __shared__ u32 s_red[2][FS_W];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (house.hint_base != nullptr && w == 1) hint_pick_wave(house.hint_base, house.view, lane);
+  frame_housekeeping(house, tid, s_red);
+  const int wbase = w * (64 * KPT);
+  u32 key[KPT], val[KPT];
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) {
+    const int i = wbase + r * 64 + lane;
+    key[r] = (i < n) ? keys_in[i] : 0xFFFFFFFFu;
+    val[r] = (u32)i;  // (values = Gaussian indices: the position in the first pass)
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 8 * pass;
+    __syncthreads();  // (the previous pass's exchange buffers have been read back; s_w / cnt are free)
+    for (u32 i = tid; i < FS_W * NB; i += FS_T) cnt[i] = 0;
+    __syncthreads();
+    // per-wave digit counts and, kept in registers for the scatter below, every key's rank among the equal digits of its
+    // round and that group's size: ONE ballot match per key and pass (the high digits of depth keys are nearly constant —
+    // 64 lanes adding to one LDS counter would serialise; here the group's first lane adds its population)
+    u32 rk[KPT];
+    {
+      const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        const bool valid = wbase + r * 64 + lane < n;
+        const u32 dg = (key[r] >> shift) & DMASK;
+        u64 peers = ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          const bool one = (dg >> bit) & 1u;
+          const u64 bm = ballot(one);
+          peers &= one ? bm : ~bm;
+        }
+        const u32 rank = (u32)__popcll(peers & lt_mask), pop = (u32)__popcll(peers);
+        rk[r] = rank | (pop << 8);
+        if (valid && rank == 0) atomicAdd(&cnt[w * NB + dg], pop);  // (one lane per distinct digit: no same-address conflict)
+      }
+    }
+    __syncthreads();
+    // thread d owns digit d: counts of the 16 waves -> the digit's start in the block, then per-wave starts
+    const u32 d = (u32)tid;
+    u32 c[FS_W];
+    u32 tot = 0;
+    if (d < NB) {
+#pragma unroll
+      for (int i = 0; i < FS_W; ++i) {
+        c[i] = cnt[i * NB + d];
+        tot += c[i];
+      }
+    }
+    const u32 start = fs_block_excl_scan(d < NB ? tot : 0u, s_w);
+    if (d < NB) {
+      u32 run = start;
+#pragma unroll
+      for (int i = 0; i < FS_W; ++i) {
+        cnt[i * NB + d] = run;
+        run += c[i];
+      }
+    }
+    __syncthreads();
+    {
+      volatile u32* my = cnt + w * NB;
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        const bool valid = wbase + r * 64 + lane < n;
+        const u32 dg = (key[r] >> shift) & DMASK;
+        if (valid) {
+          const u32 rank = rk[r] & 0xFFu;
+          const u32 st0 = my[dg];
+          if (rank == 0) my[dg] = st0 + (rk[r] >> 8);
+          ex_key[st0 + rank] = key[r];
+          ex_val[st0 + rank] = val[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    if (pass < 3) {
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        const int i = wbase + r * 64 + lane;
+        if (i < n) {
+          key[r] = ex_key[i];
+          val[r] = ex_val[i];
+        }
+      }
+    }
+  }
+  // the final order, and every Gaussian's instance count added to the total of the emission block (1024 ranks) its rank falls
+  // in: slot = k * 1024 + tid lies in block k for every thread, so a wave sum per k is all there is
+#pragma unroll
+  for (int k = 0; k < KPT; ++k) {
+    const int slot = k * FS_T + tid;
+    u32 t = 0;
+    if (slot < n) {
+      const u32 vv = ex_val[slot];
+      vals_out[slot] = vv;
+      t = inst_count[vv];
+    }
+    static_assert(EMIT_CHUNK == FS_T, "one emission block per 1024 ranks");
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+    if (lane == 0 && t) atomicAdd(&emit_totals[k], t);
+  }
+}
+
+template <int KPT>
+static void launch_sort_small_t(const u32* keys, int n, u32* vals_out, const u32* inst_count, u32* emit_totals,
+                                const FrameHousekeeping& h, hipStream_t st) {
+  constexpr size_t smem = sizeof(u32) * ((size_t)FS_W * 256 + 2 * (size_t)FS_T * KPT);
+  static bool attr_set = false;  // (per instantiation) blocks above 64 KB of LDS need the opt-in
+  if (!attr_set && smem > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_small_kernel<KPT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  sort_small_kernel<KPT><<<1, FS_T, smem, st>>>(keys, n, vals_out, inst_count, emit_totals, h);
+}
+
 struct PassArgs {
   const u32 *kin, *vin;
   int64_t n_host;
@@ -593,10 +743,7 @@ bool fused_sort_applicable(int64_t n_host, int bits) {
   return n_host > 0 && bits <= 32 && fused_sort_fits(n_host);
 }
 
-void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
-                      const FusedHouse* house, hipStream_t st) {
-  int passes;
-  const int db = fused_sort_digit_bits(bits, &passes);
+static FrameHousekeeping housekeeping_of(const FusedHouse* house) {
   FrameHousekeeping h{};
   if (house) {
     h.part_rect = house->part_rect;
@@ -613,6 +760,29 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
     h.hint_base = house->hint_base;
     h.view = house->view;
   }
+  return h;
+}
+
+// the depth sort of at most SMALL_SORT_MAX (8 192) Gaussians in one launch (sort_small_kernel); false: not applicable
+bool small_depth_sort_applicable(int64_t n) {
+  // (a pinned keys-per-thread or the depth sort's fault hook ask for the pass kernels)
+  return n > 0 && n <= SMALL_SORT_MAX && sort_plan_forced_kpt() == 0 &&
+         sort_knobs().small_sort.load(std::memory_order_relaxed) != 0 &&
+         (sort_knobs().fault.load(std::memory_order_relaxed) & 1) == 0;
+}
+void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, const uint32_t* inst_count,
+                             uint32_t* emit_totals, const FusedHouse* house, hipStream_t st) {
+  const FrameHousekeeping h = housekeeping_of(house);
+  if (n <= 2 * FS_T) launch_sort_small_t<2>(keys, n, order_out, inst_count, emit_totals, h, st);
+  else if (n <= 4 * FS_T) launch_sort_small_t<4>(keys, n, order_out, inst_count, emit_totals, h, st);
+  else launch_sort_small_t<8>(keys, n, order_out, inst_count, emit_totals, h, st);
+}
+
+void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
+                      const FusedHouse* house, hipStream_t st) {
+  int passes;
+  const int db = fused_sort_digit_bits(bits, &passes);
+  const FrameHousekeeping h = housekeeping_of(house);
   int64_t nb = (n_host + (int64_t)FS_T * 4 - 1) / ((int64_t)FS_T * 4);  // 4 keys (one 16-byte load) per thread ...
   if (nb < 1) nb = 1;
 #ifndef OLSR_HIST_BLOCKS

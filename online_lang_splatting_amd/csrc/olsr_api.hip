@@ -244,8 +244,13 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       house.host_mailbox = g_pinned.dp;
       house.host_seq = g_pinned.seq;
     }
-    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, st);
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
+    if (!legacy && small_depth_sort_applicable(s.P)) {
+      // at most 8 192 Gaussians: histogram, bookkeeping and all four passes in ONE launch of one workgroup (k_sort.hip)
+      launch_small_depth_sort(g.key_a, s.P, g.depth_order, g.tiles_touched, g.emit_status, &house, st);
+      STAGE("depth_sort");
+    } else {
+    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, st);
     // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
     if (!legacy && fused_sort_applicable(s.P, 32)) {
       // (values = Gaussian indices: the first pass takes them from the position, preprocess writes no index array)
@@ -257,6 +262,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       launch_emit_totals(g.depth_order, s.P, g.tiles_touched, g.emit_status, st);
     }
     STAGE("depth_sort");
+    }
   }
 
   void* bin_buf = nullptr;
@@ -449,6 +455,7 @@ struct SortKnobsFromEnv {
     sort_knobs().kpt = num("OLSR_SORT_KPT");
     sort_knobs().resident = num("OLSR_SORT_RESIDENT");
     sort_knobs().legacy = num("OLSR_SORT_LEGACY") == 1 ? 1 : 0;
+    if (std::getenv("OLSR_SORT_SMALL")) sort_knobs().small_sort = num("OLSR_SORT_SMALL") != 0 ? 1 : 0;
   }
 } g_sort_knobs_from_env;
 }  // namespace
@@ -979,6 +986,10 @@ void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy)
   if (keys_per_thread >= 0) sort_knobs().kpt = keys_per_thread;
   if (resident_blocks >= 0) sort_knobs().resident = resident_blocks;
   if (legacy >= 0) sort_knobs().legacy = legacy ? 1 : 0;
+}
+
+void olsr_debug_sort_small(int enable) {
+  if (enable >= 0) sort_knobs().small_sort = enable ? 1 : 0;
 }
 
 int olsr_debug_sort_plan(int64_t n, int n_is_capacity, int32_t* keys_per_thread, int32_t* blocks) {

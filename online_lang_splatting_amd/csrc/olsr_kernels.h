@@ -111,6 +111,10 @@ int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host
                       const uint32_t* inst_count, uint32_t* emit_totals, int32_t* sync_error, int fault, hipStream_t st);
 void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_launches);
 // the same totals for a depth order produced by the multi-kernel passes
+// the whole depth sort of n <= 8 192 Gaussians in one launch, incl. the frame's bookkeeping (k_sort.hip: sort_small_kernel)
+bool small_depth_sort_applicable(int64_t n);
+void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, const uint32_t* inst_count,
+                             uint32_t* emit_totals, const FusedHouse* house, hipStream_t st);
 void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
 
 // k_render_fwd.hip

@@ -46,6 +46,7 @@ constexpr int FUSED_SORT_MAX_BLOCKS = 4096;  // beyond: the multi-kernel passes 
 //  inputs; no getenv on a call path)
 struct SortKnobs {
   std::atomic<int> kpt{0}, resident{0}, legacy{0};
+  std::atomic<int> small_sort{1};  // the one-launch depth sort of <= 8 192 Gaussians (k_sort.hip); OLSR_SORT_SMALL=0 / olsr_debug_sort_small(0): off
   // test hooks (olsr_debug_sync_fault): fault bit 0 / 1 = the block holding ticket 0 of the first depth / tile pass never
   // publishes its digit counts (what a status word corrupted mid-frame looks like to its successors); spin_limit = polls a
   // look-back makes before it gives up and raises the frame's synchronisation error

@@ -368,6 +368,36 @@ def test_every_sort_pass_instantiation(hip, oracle, kpt):
         lib().olsr_debug_sort_knobs(0, -1, -1)
 
 
+@pytest.mark.parametrize("P", [1, 2, 63, 64, 65, 1023, 1024, 1025, 2048, 2049, 4096, 4097, 5000, 8191, 8192, 8193, 10000])
+def test_one_launch_depth_sort_equals_the_radix_passes(hip, P):
+    """Round 5: up to 8 192 Gaussians are depth-sorted by ONE launch of one workgroup (k_sort.hip: sort_small_kernel — the
+    histogram, the frame's bookkeeping and the four 8-bit passes inside the block).  Its order, the frame's counters, the
+    emission totals and everything downstream must equal what the histogram launch + four radix passes leave, bit for bit,
+    at every block shape (2 / 4 / 8 keys per thread, ragged tails, one Gaussian); beyond 8 192 the passes run either way."""
+    from online_lang_splatting_amd._lib import lib
+    dev = torch.device(DEV)
+    sc = make_scene(P, 200, 150, 3, seed=300 + P % 97)
+    # equal depths in quantity: the order among them must be the index order (stable)
+    sc.means3D[::3, 2] = sc.means3D[0, 2] if P > 3 else sc.means3D[::3, 2]
+    a = fwd_args(sc, dev)
+    out = {}
+    try:
+        for small in (1, 0):
+            lib().olsr_debug_sort_small(small)
+            R, color, lang, radii, geom, binb, img, depth, opac, nt = hip.rasterize_language_gaussians(*a)
+            order = hip.state_field("geometry", geom, "depth_order", P=P, F=3, dtype=torch.int32, count=P).clone()
+            cnt = hip.state_field("geometry", geom, "counters", P=P, F=3, dtype=torch.int32, count=10).clone()
+            et = hip.state_field("geometry", geom, "emit_totals", P=P, F=3, dtype=torch.int32, count=(P + 1023) // 1024).clone()
+            pl = hip.state_field("binning", binb, "point_list", R=R, F=3, dtype=torch.int32, count=R).clone() if R else None
+            out[small] = (R, order, cnt, et, pl, color.clone(), lang.clone(), depth.clone(), nt.clone())
+    finally:
+        lib().olsr_debug_sort_small(1)
+    assert out[1][0] == out[0][0]
+    for x, y in zip(out[1][1:], out[0][1:]):
+        assert (x is None and y is None) or torch.equal(x, y)
+    assert sorted(out[1][1].tolist()) == list(range(P))
+
+
 def test_repeated_backward_on_one_forward(hip):
     """The row compaction's look-back state is re-armed by the kernel itself: a backward may be repeated on the same
     forward (autograd's retain_graph, or the test above) and must give the same bits every time."""
