@@ -166,12 +166,18 @@ typedef struct olsr_scene {
  * gradients equal up to the order of their per-Gaussian sums; num_rendered counts the kept instances — whenever every tile
  * saturated at an entry in front of its cut-off.  If one did not (the view or the scene moved too much) the frame is flagged
  * OLSR_STATUS_CUT_MISS in num_rendered_dev[1]: its images and gradients may lack contributions in that tile, and the caller
- * re-renders (the array has been updated: the offending tile and its neighbours carry +infinity again).  Exact tile binning
+ * re-renders.  The array has been updated by then: a tile that did not saturate at all carries +infinity again (and so do
+ * its neighbours, through the 3 x 3 maximum); a tile that saturated, but BEHIND its cut-off, carries the finite
+ * 1.1 x (the depth it saturated at) + 0.01 — taken from a list that may have had holes, hence possibly still too near: such a
+ * tile can miss once more and converges from below, every miss moving its cut-off outwards.  Exact tile binning
  * only (OLSR_BINNING_ELLIPSE; ignored with OLSR_BINNING_RECT), default forward accumulation only, and with a fused loss only
  * the tracking loss (OLSR_ERR_ARG otherwise); olsr_forward (the synchronising entry) ignores the field.
  * Without a host read-back: olsr_backward on the state buffers of a CUT_MISS frame writes zero gradients (status_dev[1] = 3),
  * and olsr_pose_step_gated given that frame's num_rendered_dev takes no step — an iteration whose frame missed is a no-op on
- * the device, the next one renders the offending tiles uncut, and the sequence of poses is the one without cut-offs. */
+ * the device, and the k-th COUNTED step sees the pose the k-th step of the loop without cut-offs sees.  A missed iteration
+ * still consumes one of a caller's fixed budget of iterations (the reference's tracking_itr_num): a caller that wants the
+ * same NUMBER of optimiser steps iterates until status[1] of olsr_pose_step_gated (steps done, on the device) has reached
+ * it — slam_iterations.TrackingLoop.run(steps) does, reading the count back every few iterations. */
 #define OLSR_STATUS_CUT_MISS 3
 
 /* Sizes of the three opaque state buffers (bytes).  Replace

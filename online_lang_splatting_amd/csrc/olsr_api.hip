@@ -198,7 +198,9 @@ int32_t* sticky_sync_error_dev() { return g_rows.p.load(std::memory_order_acquir
 const char* const STICKY_MSG =
     "device-side synchronisation error in an earlier frame of this process: a look-back of its radix sort / row compaction "
     "never received a predecessor's counts (state buffer corrupted mid-frame?); that frame's images are invalid and its "
-    "gradients are zeros";
+    "gradients are zeros.  (The flag is process-wide, like an asynchronous HIP error: the frame it belongs to was issued "
+    "through the reference-shaped entry on ANY thread or stream of this process, not necessarily by this call; callers that "
+    "need the error attributed use the sync-free entries, whose status words are per frame.)";
 
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
@@ -396,6 +398,12 @@ struct OrderHints {
   };
   std::mutex m;
   std::vector<Entry> v;
+  // evicted buffers, never freed while anything may still use them: a thread that fetched the pointer a
+  // moment before the eviction still launches kernels on it, and the evicted stream may have a forward in flight.  They are
+  // handed to the next new key of the same (device, tile count) — any content is a legal hint (the header's slot index is
+  // always 0..15, whoever wrote it last; orders that are no permutations are ignored entry by entry) — and only when more
+  // than 64 of them wait is the oldest freed, after a synchronisation of its device.
+  std::vector<Entry> spare;
 } g_order_hints;
 
 // the hint buffer of (current device, st, ntiles): header + HINT_SLOTS orders (layout above); nullptr: run without a hint
@@ -411,16 +419,32 @@ uint32_t* order_hint_of(int ntiles, hipStream_t st) {
       v.push_back(e);
       return e.buf;
     }
+  auto& spare = g_order_hints.spare;
   if (v.size() >= 64) {
-    // a caller that keeps creating streams / resolutions: drop the least recently used hint.  Its stream may still have a
-    // forward in flight that writes it, so this is a plain (device-synchronising) hipFree — rare by construction, and the
-    // only synchronisation this path ever causes (the allocation below used to synchronise, and after 64
-    // keys the hint was silently dropped for good)
-    (void)hipFree(v.front().buf);
+    // a caller that keeps creating streams / resolutions: the least recently used hint is retired to the spare list (see
+    // above), not freed — its pointer may be in another thread's hands, its stream may still be writing it
+    spare.push_back(v.front());
     v.erase(v.begin());
+    if (spare.size() > 64) {
+      const OrderHints::Entry old = spare.front();
+      spare.erase(spare.begin());
+      int cur = dev;
+      (void)hipSetDevice(old.dev);
+      (void)hipDeviceSynchronize();  // nothing that could still touch it is in flight after this (rare by construction)
+      (void)hipFree(old.buf);
+      (void)hipSetDevice(cur);
+    }
   }
-  uint32_t* buf = nullptr;
   const size_t words = (size_t)HINT_HDR + (size_t)HINT_SLOTS * (size_t)ntiles;
+  for (size_t i = 0; i < spare.size(); ++i)
+    if (spare[i].dev == dev && spare[i].ntiles == ntiles) {
+      uint32_t* reuse = spare[i].buf;
+      spare.erase(spare.begin() + (long)i);
+      hint_init_kernel<<<(unsigned)((words + 255) / 256), 256, 0, st>>>(reuse, ntiles);
+      v.push_back({dev, st, ntiles, reuse});
+      return reuse;
+    }
+  uint32_t* buf = nullptr;
   // stream-ordered allocation: no device synchronisation on the hot olsr_forward path the first time a key is seen
   if (hipMallocAsync((void**)&buf, sizeof(uint32_t) * words, st) != hipSuccess) {
     (void)hipGetLastError();
@@ -535,11 +559,13 @@ int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* ge
   int rc = check_scene(scene, false);
   if (rc != OLSR_OK) return rc;
   if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(OLSR_ERR_ARG, "allocation callbacks are required");
+  // (before the allocation callbacks run: a call that fails for an EARLIER frame's error must not have resized the caller's
+  //  buffers — ADVICE round 4)
+  if (take_sticky_sync_error()) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
   void* geom = geometry_alloc(geometry_user, olsr_geometry_bytes(scene->P, scene->F));
   if (!geom) return fail(OLSR_ERR_ALLOC, "geometry allocation callback returned NULL");
   void* img = image_alloc(image_user, olsr_image_bytes(scene->width, scene->height, scene->tile));
   if (!img) return fail(OLSR_ERR_ALLOC, "image allocation callback returned NULL");
-  if (take_sticky_sync_error()) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
   BinningProvider bp;
   bp.fn = binning_alloc;
   bp.user = binning_user;

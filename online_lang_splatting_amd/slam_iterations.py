@@ -145,12 +145,38 @@ class TrackingLoop:
         # Per-tile depth cut-offs (RasterWorkspace(depth_cut=True), include/olsr.h): every iteration renders with the cut-offs
         # the previous one left.  A frame whose cut-offs hid something is flagged on the device; its backward writes zeros and
         # the gated pose step does nothing, so the iteration is a no-op and the next one renders the offending tiles uncut:
-        # the poses are those of the loop without cut-offs, `steps_done()` says how many iterations counted.
+        # the k-th COUNTED step sees the pose the k-th step of the loop without cut-offs sees; `steps_done()` says how many
+        # iterations counted, and run(steps) iterates until that many did (a fixed budget of iterations would otherwise take
+        # fewer optimiser steps than the reference's tracking_itr_num - ADVICE round 4).
         self.pose.step(g["dL_dtau_sum"], lo["dL_dexposure"],
                        frame_status=ws.num_rendered if ws.depth_cut is not None else None)
         if read_convergence:
             return bool(int(self.pose.status[0].item()))  # one 4-byte read-back, like the reference
         return False
+
+    def run(self, steps: int, check_every: int = 16, max_iterations: Optional[int] = None, write_final_images=False) -> int:
+        """Iterate until `steps` optimiser steps have been taken (the reference's tracking_itr_num), the way its loop does
+        with a fixed budget — but counting only iterations whose frame was usable: with per-tile depth cut-offs an iteration
+        whose frame missed is a device-side no-op.  The count lives on the device; it is read back every `check_every`
+        iterations (one 4-byte copy each), so the loop overshoots by at most nothing: it first issues the iterations that are
+        certainly needed (steps - done), then looks again.  Without cut-offs every iteration counts and nothing is read back.
+        Returns the number of iterations issued."""
+        issued = 0
+        limit = max_iterations if max_iterations is not None else 4 * steps + 16
+        if self.ws.depth_cut is None:
+            for k in range(steps):
+                self.iteration(write_images=write_final_images and k == steps - 1)
+            return steps
+        done = self.steps_done()
+        target = done + steps
+        while done < target and issued < limit:
+            for _ in range(min(target - done, check_every, limit - issued)):
+                self.iteration()
+                issued += 1
+            done = self.steps_done()
+        if write_final_images:
+            self.render_final()
+        return issued
 
     def render_final(self) -> Dict[str, torch.Tensor]:
         """The images of the CURRENT pose (after the last pose step): one plain forward into ws.out — what the reference's front

@@ -206,3 +206,37 @@ def test_combinations_without_a_cut_off_kernel_are_refused(hip):
     weight.set_scene(sh_degree=sc.sh_degree, **cam, **g)
     with pytest.raises(RuntimeError, match="tile_depth_cut"):
         weight.forward()
+
+
+def test_tracking_loop_run_takes_the_requested_number_of_steps(hip):
+    """with depth cut-offs an iteration whose frame missed is a device-side no-op, so a fixed budget of
+    iterations takes fewer optimiser steps than the reference's tracking_itr_num.  TrackingLoop.run(steps) iterates until
+    that many steps were TAKEN (the count is read back every few iterations); without cut-offs it is `steps` iterations."""
+    from online_lang_splatting_amd.frame_shard import RasterWorkspace
+    from online_lang_splatting_amd.scene import make_scene
+    from online_lang_splatting_amd.slam_iterations import PoseState, TrackingLoop
+    dev = torch.device("cuda:0")
+    W, H, F, P = 320, 240, 15, 30000
+    sc = make_scene(P, W, H, F, seed=31)
+    cam = sc.camera
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev))
+    ws0 = RasterWorkspace(P, W, H, F, sc.shs.shape[1], 1_200_000, dev)
+    c = dict(viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+             projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx, tanfovy=cam.tanfovy)
+    ws0.set_scene(sh_degree=sc.sh_degree, **c, **g)
+    o = ws0.forward()
+    gt_image, gt_depth = o["color"].clone(), o["depth"][0].clone()
+    T0 = torch.eye(4)
+    T0[0, 3], T0[1, 3] = 0.03, -0.02
+    for cut in (True, False):
+        ws = RasterWorkspace(P, W, H, F, sc.shs.shape[1], 1_200_000, dev, depth_cut=cut)
+        pose = PoseState(T0.to(dev), cam.projection_matrix.to(dev), cam.tanfovx, cam.tanfovy, device_step_count=True)
+        loop = TrackingLoop(ws, g, sc.sh_degree, pose, gt_image, gt_depth)
+        issued = loop.run(25, check_every=8)
+        assert loop.steps_done() == 25 and issued >= 25, (cut, issued, loop.steps_done())
+        if not cut:
+            assert issued == 25
+        fin = loop.run(3, write_final_images=True)
+        assert loop.steps_done() == 28 and fin >= 3
+        assert float(ws.out["opacity"].max()) > 0      # the final images were left behind
