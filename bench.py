@@ -81,7 +81,7 @@ def algorithmic_bytes(P, R, N, C=3, F=15, M=1):
     return per
 
 
-PROFILE_TAG = "r4"  # the committed counter summaries of the current kernels: profiles/<tag>_pmc_{traffic,valu}.json
+PROFILE_TAG = "r5"  # the committed counter summaries of the current kernels: profiles/<tag>_pmc_{traffic,valu}.json
 
 
 def _pmc_summary(kind):

@@ -42,9 +42,29 @@ json.dump(dict(tag=tag, formula="(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per laun
 shutil.copy(os.path.join(src, "stats", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "stats1", "s_kernel_stats.csv")):
     shutil.copy(os.path.join(src, "stats1", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_1_in_flight.csv"))
-for name in ("bench", "bench_cfg1", "bench_cfg2", "bench_cfg5"):
+for name in ("bench", "bench_cfg1", "bench_cfg2", "bench_cfg5", "bench_room"):
     if os.path.exists(os.path.join(src, name + ".json")) and os.path.getsize(os.path.join(src, name + ".json")):
         shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
+# the forced single-rank exchange legs (round 5): one summary
+ex = {}
+for sc in ("volume", "room"):
+    for mode in ("none", "auto", "reduce_scatter"):
+        pth = os.path.join(src, f"bench_exchange_{sc}_{mode}.json")
+        if os.path.exists(pth) and os.path.getsize(pth):
+            d = json.load(open(pth))
+            c = d["config"]
+            ex[f"{sc}:{mode}"] = dict(frames_per_s=d["value"], p10=c["value_runs"]["p10"], p90=c["value_runs"]["p90"],
+                                      runs=c["value_runs"]["runs"], exchange=c.get("exchange"), detail=c.get("exchange_detail"))
+if ex:
+    for sc in ("volume", "room"):
+        base = ex.get(f"{sc}:none", {}).get("frames_per_s")
+        for mode in ("auto", "reduce_scatter"):
+            if base and f"{sc}:{mode}" in ex:
+                ex[f"{sc}:{mode}"]["against_no_exchange"] = round(ex[f"{sc}:{mode}"]["frames_per_s"] / base - 1.0, 4)
+    json.dump(dict(tag=tag, what="bench.py weak-scaling step, four frames in flight, K = 60, on ONE GPU: no exchange against a group of "
+                                  "one rank over RCCL with every collective of the exchange issued (OLSR_BENCH_FORCE_EXCHANGE=1) - "
+                                  "everything of the exchange but the wire", legs=ex),
+              open(os.path.join(dst, f"{tag}_exchange_overhead.json"), "w"), indent=1)
 # ---- SQ passes: what bounds the kernels (VALU issue).  Durations from the one-frame-in-flight trace.
 stats1 = {}
 p1 = os.path.join(src, "stats1", "s_kernel_stats.csv")

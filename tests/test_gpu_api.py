@@ -846,6 +846,28 @@ def test_a_guessed_backward_scratch_is_verified_and_redone_exactly(hip, binding,
     assert float(ref["dL_dmeans3D"].abs().max()) > 0
 
 
+def test_more_than_64_hint_keys_retire_buffers_instead_of_freeing_them(hip):
+    """the synchronising entry keeps one hint buffer per (device, stream, tile count), at most 64; a 65th key
+    used to hipFree() the least recently used one although another thread might hold its pointer and its stream might still
+    be writing it.  Evicted buffers are now retired to a spare list and handed to later keys of the same size.  Seventy
+    streams and three resolutions through the drop-in forward, twice over: every result equals the first stream's."""
+    from parity_common import fwd_args
+    dev = torch.device(DEV)
+    scenes = [make_scene(1500, w, h, 15, seed=40 + i) for i, (w, h) in enumerate(((160, 120), (128, 96), (200, 90)))]
+    args = [fwd_args(sc, dev) for sc in scenes]
+    ref = [hip.rasterize_language_gaussians(*a)[1].clone() for a in args]
+    streams = [torch.cuda.Stream(dev) for _ in range(70)]
+    torch.cuda.synchronize()
+    for rnd in range(2):
+        outs = []
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs.append((i % 3, hip.rasterize_language_gaussians(*args[i % 3])[1]))
+        torch.cuda.synchronize()
+        for k, o in outs:
+            assert torch.equal(o, ref[k])
+
+
 def run_fwd_only(hip, sc, dev):
     from parity_common import fwd_args
     return hip.rasterize_language_gaussians(*fwd_args(sc, dev))
