@@ -269,6 +269,36 @@ void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_laun
     if (timing != nullptr && tid == 0) timing[(size_t)b * 8 + (k)] = __builtin_readcyclecounter(); \
   } while (0)
 
+// ---- the rank of a key among the equal digits of its round of 64 (round 5: written out by hand) ------------------------------
+// peers = the lanes of the wave that hold the same DB-bit digit.  Per bit: one ballot of the bit, and the lane keeps the lanes
+// that agree with it — peers &= (bit set ? ballot : ~ballot) = peers & ~(ballot ^ m) with m = 0 - bit (all ones where the bit is
+// set): an extract, a compare, a subtract and an xnor + and per half — 7 vector instructions per bit.  The compiler's rendering
+// of `peers &= one ? bm : ~bm` on 64-bit values took 13 (two compares, a select, a 64-bit add to build the mask, two xors, two
+// ands); the sorts are a tenth of the frame's vector instructions and every one of them is in this loop.  The rank below the
+// lane and the group's size come from v_mbcnt / v_bcnt on the halves.  Scalar masks stay out of it: the halves live in VGPRs.
+typedef __attribute__((address_space(3))) u32 lds_u32;
+template <int DB>
+__device__ __forceinline__ void wave_match_rank(u32 dg, bool valid, u32& rank, u32& pop) {
+  const u64 vm = ballot(valid);
+  u32 lo = (u32)vm, hi = (u32)(vm >> 32);
+#pragma unroll
+  for (int bit = 0; bit < DB; ++bit) {
+    const u32 b = (dg >> bit) & 1u;
+    const u64 bm = ballot(b != 0u);
+    const u32 m = 0u - b;
+    lo &= ~((u32)bm ^ m);
+    hi &= ~((u32)(bm >> 32) ^ m);
+  }
+  rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));  // peers in lanes below this one
+  pop = (u32)__builtin_popcount(lo) + (u32)__builtin_popcount(hi);
+}
+// the per-wave running start of a digit, in LDS: plain ds_read / ds_write that the compiler neither caches nor reorders (the
+// `volatile u32*` this replaces was lowered to FLAT loads and stores with a vmcnt(0) wait after each)
+__device__ __forceinline__ u32 lds_load(const u32* p) {
+  return *reinterpret_cast<const volatile lds_u32*>((const lds_u32*)p);
+}
+__device__ __forceinline__ void lds_store(u32* p, u32 v) { *reinterpret_cast<volatile lds_u32*>((lds_u32*)p) = v; }
+
 // ---- one pass ---------------------------------------------------------------------------------------------
 // FLAGS (runtime, uniform): bit 0 = values are the identity (first tile-sort pass; also clears flags_clear[i]),
 // bit 1 = do not write the sorted keys (last pass of a sort), bit 2 = derive tile ranges (last tile-sort pass).
@@ -382,24 +412,17 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   // (Done BEFORE the look-back: it needs nothing from other blocks, and meanwhile their counts become visible — a
   // look-back issued right after the publish finds nothing ready and thousands of polling waves slow every publish.)
   {
-    volatile u32* my = cnt + w * NB;
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u32* my = cnt + w * NB;
 #pragma unroll
     for (int r = 0; r < KPT; ++r) {
       const int64_t i = wbase + r * 64 + lane;
       const bool valid = i < n;
       const u32 dg = (key[r] >> shift) & DMASK;
-      u64 peers = ballot(valid);
-#pragma unroll
-      for (int bit = 0; bit < DB; ++bit) {
-        const bool one = (dg >> bit) & 1u;
-        const u64 bm = ballot(one);
-        peers &= one ? bm : ~bm;
-      }
+      u32 rank, pop;
+      wave_match_rank<DB>(dg, valid, rank, pop);
       if (valid) {
-        const u32 rank = (u32)__popcll(peers & lt_mask);
-        const u32 st0 = my[dg];
-        if (rank == 0) my[dg] = st0 + (u32)__popcll(peers);
+        const u32 st0 = lds_load(&my[dg]);
+        if (rank == 0) lds_store(&my[dg], st0 + pop);
         ex_key[st0 + rank] = key[r];
         ex_val[st0 + rank] = val[r];
       }
@@ -575,23 +598,14 @@ __global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict_
     // round and that group's size: ONE ballot match per key and pass (the high digits of depth keys are nearly constant —
     // 64 lanes adding to one LDS counter would serialise; here the group's first lane adds its population)
     u32 rk[KPT];
-    {
-      const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-      for (int r = 0; r < KPT; ++r) {
-        const bool valid = wbase + r * 64 + lane < n;
-        const u32 dg = (key[r] >> shift) & DMASK;
-        u64 peers = ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-          const bool one = (dg >> bit) & 1u;
-          const u64 bm = ballot(one);
-          peers &= one ? bm : ~bm;
-        }
-        const u32 rank = (u32)__popcll(peers & lt_mask), pop = (u32)__popcll(peers);
-        rk[r] = rank | (pop << 8);
-        if (valid && rank == 0) atomicAdd(&cnt[w * NB + dg], pop);  // (one lane per distinct digit: no same-address conflict)
-      }
+    for (int r = 0; r < KPT; ++r) {
+      const bool valid = wbase + r * 64 + lane < n;
+      const u32 dg = (key[r] >> shift) & DMASK;
+      u32 rank, pop;
+      wave_match_rank<8>(dg, valid, rank, pop);
+      rk[r] = rank | (pop << 8);
+      if (valid && rank == 0) atomicAdd(&cnt[w * NB + dg], pop);  // (one lane per distinct digit: no same-address conflict)
     }
     __syncthreads();
     // thread d owns digit d: counts of the 16 waves -> the digit's start in the block, then per-wave starts
@@ -616,15 +630,15 @@ __global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict_
     }
     __syncthreads();
     {
-      volatile u32* my = cnt + w * NB;
+      u32* my = cnt + w * NB;
 #pragma unroll
       for (int r = 0; r < KPT; ++r) {
         const bool valid = wbase + r * 64 + lane < n;
         const u32 dg = (key[r] >> shift) & DMASK;
         if (valid) {
           const u32 rank = rk[r] & 0xFFu;
-          const u32 st0 = my[dg];
-          if (rank == 0) my[dg] = st0 + (rk[r] >> 8);
+          const u32 st0 = lds_load(&my[dg]);
+          if (rank == 0) lds_store(&my[dg], st0 + (rk[r] >> 8));
           ex_key[st0 + rank] = key[r];
           ex_val[st0 + rank] = val[r];
         }

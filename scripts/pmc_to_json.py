@@ -8,7 +8,7 @@ import collections, csv, json, os, re, shutil, sys
 
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
-dst = "profiles"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"   # (on the GPU box: gpurun_out/<tag>/summary, copied into profiles/ afterwards)
 os.makedirs(dst, exist_ok=True)
 
 

@@ -18,7 +18,7 @@ python bench.py --scene room --steps 60 --warmup 12 --no-cpu-baseline > $OUT/ben
 for sc in volume room; do for ex in auto reduce_scatter; do
   OLSR_BENCH_FORCE_EXCHANGE=1 timeout 300 python bench.py --scene $sc --steps 60 --warmup 12 --no-cpu-baseline --no-extra-legs --isolated-steps 0 --exchange $ex > $OUT/bench_exchange_${sc}_$ex.json 2> $OUT/bench_exchange_${sc}_$ex.err
 done; timeout 300 python bench.py --scene $sc --steps 60 --warmup 12 --no-cpu-baseline --no-extra-legs --isolated-steps 0 > $OUT/bench_exchange_${sc}_none.json 2> /dev/null; done
-B="python bench.py --no-cpu-baseline --no-extra-legs"
+B="python bench.py --no-cpu-baseline --no-extra-legs --repeats 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B --steps $STEPS --warmup 5 > $OUT/bench_stats.log 2>&1
 # the same kernels with ONE frame in flight (no co-scheduling): per-kernel durations of the `isolated` leg
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- $B --steps $STEPS --warmup 5 --streams 1 --isolated-steps 0 > $OUT/bench_stats1.log 2>&1
@@ -27,4 +27,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq_a -o p -- $B --steps 3 --warmup 1 --streams 1 --isolated-steps 0 > $OUT/bench_sq_a.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq_b -o p -- $B --steps 3 --warmup 1 --streams 1 --isolated-steps 0 > $OUT/bench_sq_b.log 2>&1
 rm -f $OUT/*/*.db
-ls -R $OUT | head -40
+# summarise ON the box (the raw traces exceed what gpurun carries back) into $OUT/summary/, then drop the raw directories
+python scripts/pmc_to_json.py $TAG $OUT/summary
+rm -rf $OUT/stats $OUT/stats1 $OUT/fetch $OUT/write $OUT/sq_a $OUT/sq_b
+ls -R $OUT | head -60
