@@ -301,7 +301,7 @@ def room_scene_leg(dev, dims, steps, seed=3):
             step(pick_lane(), pick_cam(i))
         torch.cuda.synchronize(dev)
         return n / (time.perf_counter() - t0)
-    lane0 = lanes.lanes[0]
+    lane0 = FrameLanes(1, sc.P, W, H, F, M, cap, dev).lanes[0]   # (one frame in flight: without OLSR_FLAG_FRAMES_IN_FLIGHT)
     n = max(steps, 20)
     out["isolated"] = {"value": round(rate(n, lambda: lane0, lambda i: camd[0]), 1), "unit": "frames/s", "frames_in_flight": 1}
     out["four_in_flight"] = {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[0], warm=40), 1), "unit": "frames/s",
@@ -1215,16 +1215,22 @@ def main():
     order_ = sorted(range(len(runs)), key=lambda i: run_fps[i])
     elapsed, avg, lat = runs[order_[len(runs) // 2]]   # the median run (the upper one of an even count), as value_runs.median
     iso = prof = nonco = None
+    # ONE frame in flight is its own workspace: the lanes' workspaces carry OLSR_FLAG_FRAMES_IN_FLIGHT (four-wave radix blocks,
+    # which get onto the CUs beside another lane's composite: + 2 % with four frames in flight, - 11 % with one)
+    iso_lane = FrameLanes(1, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning, flags=fwd_flags).lanes[0] \
+        if (a.isolated_steps > 0 and len(lanes) > 1) else lanes.lanes[0]
     if a.isolated_steps > 0:
-        iso = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
-        prof = timed(a.isolated_steps, 3, lambda: lanes.lanes[0], profile=True)
+        for _ in range(8):
+            one_step(iso_lane)
+        iso = timed(a.isolated_steps, 3, lambda: iso_lane)
+        prof = timed(a.isolated_steps, 3, lambda: iso_lane, profile=True)
         if world == 1 and not a.no_extra_legs:
             # non-coherent frames: the camera changes EVERY step (eight arc views, yaw -14 .. +14 degrees), so a lane's
             # tile-order hint comes from another view and nothing of the previous frame can be reused
             view_cycle[0] = [device_inputs(sc, c_, dev)[1] for c_ in (arc_cameras(W, H, n=8) if room is None else room.cameras)]
             step_no[0] = 0
             nc4 = timed(a.steps, a.warmup, lanes.next_lane, events=False)
-            nc1 = timed(a.isolated_steps, 3, lambda: lanes.lanes[0])
+            nc1 = timed(a.isolated_steps, 3, lambda: iso_lane)
             view_cycle[0] = None
             nonco = {"what": "the camera changes every step (8 arc views, yaw -14..+14 deg, 0.15 m apart): the tile-order hint "
                              "a lane carries belongs to another view",
@@ -1234,8 +1240,9 @@ def main():
             # (back to the coherent steady state for the legs below)
             for _ in range(2 * len(lanes)):
                 one_step(lanes.next_lane())
+            one_step(iso_lane)
             torch.cuda.synchronize(dev)
-    ws0 = lanes.lanes[0][0]
+    ws0 = iso_lane[0] if a.isolated_steps > 0 else lanes.lanes[0][0]
     exch_detail = None
     if dist is not None:
         b0 = lanes.lanes[0][1]
@@ -1412,7 +1419,9 @@ def main():
                 out["config4_substitute"] = config4_substitute(sc, g_dev, dev, dims)
                 out["config4_substitute"]["room_scene"] = room_scene_leg(dev, dims, a.isolated_steps)
         if world == 1 and not a.no_cpu_baseline:
-            lane0 = lanes.lanes[0]
+            lane0 = iso_lane
+            one_step(lane0)
+            torch.cuda.synchronize(dev)
             sl = lane0[1].layout.slices()
             out["cpu_baseline"] = cpu_baseline(sc, a.config, gpu=(lane0[0].out, lane0[1].flat.cpu(), sl),
                                                single_thread=(a.config in (1, 3)))

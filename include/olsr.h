@@ -103,6 +103,16 @@ typedef void *(*olsr_alloc_fn)(void *user, size_t nbytes);
  *       then one fma(w, f, C) per channel instead of the reference's mul + fma (half the lane operations of the
  *       accumulation).  Decisions unchanged and bit-identical; images to ~1e-7 relative of the reference's rounding. */
 #define OLSR_FLAG_FWD_ACCUM_WEIGHT 4
+/*   OLSR_FLAG_FRAMES_IN_FLIGHT  (forward; round 5) the caller keeps SEVERAL frames in flight on several HIP streams (the views of
+ *       a mapping iteration, a benchmark's lanes).  One composite kernel fills the chip, and the workgroup dispatcher keeps
+ *       feeding it while it has workgroups left: a 1024-thread workgroup of ANOTHER frame's radix sort needs sixteen free wave
+ *       slots on one CU and gets them only in the composite's tail, so the frames' dependent binning chains stalled behind each
+ *       other's composites (kernel trace, four frames in flight: radix passes of 15 us stretched to 147 us, no composite
+ *       executing during 26 % of the wall time).  With the flag the histogram and pass kernels of this frame run as four-wave
+ *       workgroups with sixteen keys per thread, which are placed sooner: + 2 % frames/s with four frames in flight at config 3
+ *       (2 304 -> 2 350, K = 60) — and - 11 % with ONE frame in flight (the depth sort 69 -> 108 us), which is why it is a
+ *       statement about the caller and not the default.  Lists, images and gradients are bit-identical either way. */
+#define OLSR_FLAG_FRAMES_IN_FLIGHT 8
 
 /* How Gaussians are binned into tiles.
  *   OLSR_BINNING_RECT     every tile of the reference's bounding square (getRect, CR/auxiliary.h:46-56):
@@ -622,6 +632,12 @@ void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy)
  * default, negative leaves it.  Process-wide; seeded once from OLSR_SORT_SMALL.  A keys_per_thread pinned through
  * olsr_debug_sort_knobs also selects the pass kernels. */
 void olsr_debug_sort_small(int enable);
+
+/* Test / experiment knob: threads per workgroup of the radix passes and their histogram kernels.  0 (default): the call
+ * decides — 1024, or 256 for a scene that carries OLSR_FLAG_FRAMES_IN_FLIGHT; 256 / 1024: forced for every later forward.
+ * Any other argument only reads the value back.  Same lists bit for bit.  Process-wide; seeded once from OLSR_SORT_THREADS.
+ * Returns the value in force. */
+int olsr_debug_sort_threads(int threads);
 
 const char *olsr_last_error(void);
 const char *olsr_version(void);

@@ -19,6 +19,7 @@ ACT_ROTATION_NORMALIZE = 4
 ACT_ALL = 7
 FLAG_SIGNED_EMPTY_RADII = 1  # OLSR_FLAG_SIGNED_EMPTY_RADII: radii = -radius for a bounding square that covers no tile
 FLAG_FWD_ACCUM_WEIGHT = 4    # OLSR_FLAG_FWD_ACCUM_WEIGHT: fma(alpha T, f, C) on the vector ALU (images to ~1e-7)
+FLAG_FRAMES_IN_FLIGHT = 8    # OLSR_FLAG_FRAMES_IN_FLIGHT: several frames in flight on several streams -> four-wave radix blocks
 FLAG_FWD_ACCUM_MFMA = 2      # OLSR_FLAG_FWD_ACCUM_MFMA: the forward's feature accumulation on the matrix cores (images to ~1e-7)
 
 BINNING_RECT = 0     # every tile of the reference's bounding square (bit-identical instance lists)

@@ -919,11 +919,15 @@ __global__ __launch_bounds__(CH_THREADS) void pb_chain_kernel(
   }
 }
 
-// one block: 1024 threads stride over the block partials (six consecutive floats each), fixed-order reduction
-__global__ __launch_bounds__(1024) void tau_final_kernel(const float* __restrict__ partials, int nb,
+// one block: TAU_T threads stride over the block partials (six consecutive floats each), fixed-order reduction.  Four waves
+// since round 5 (sixteen before): with several frames in flight a 1024-thread block needs sixteen free wave slots on ONE CU,
+// which another frame's composite kernel leaves only in its tail — a kernel trace showed this 5 us kernel, the last of a
+// frame's backward, waiting 88 us for a CU.
+constexpr int TAU_T = 256;
+__global__ __launch_bounds__(TAU_T) void tau_final_kernel(const float* __restrict__ partials, int nb,
                                                          float* __restrict__ out, const int32_t* __restrict__ counters,
                                                          int32_t* __restrict__ status_dev, int32_t* sticky) {
-  __shared__ float red[16][6];
+  __shared__ float red[TAU_T / 64][6];
   // the backward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
   if (threadIdx.x == 0 && counters[8] != 0) {
     if (status_dev != nullptr) status_dev[1] = 2;
@@ -933,7 +937,7 @@ __global__ __launch_bounds__(1024) void tau_final_kernel(const float* __restrict
   }
   if (out == nullptr) return;
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int b = threadIdx.x; b < nb; b += 1024) {
+  for (int b = threadIdx.x; b < nb; b += TAU_T) {
     const float2* p = reinterpret_cast<const float2*>(partials + (size_t)b * 6);  // 24-byte records: 8-byte aligned
     const float2 a0 = p[0], a1 = p[1], a2 = p[2];
     acc[0] += a0.x; acc[1] += a0.y; acc[2] += a1.x; acc[3] += a1.y; acc[4] += a2.x; acc[5] += a2.y;
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(1024) void tau_final_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x < 6) {
     float v = 0.f;
-    for (int w = 0; w < 16; ++w) v += red[w][threadIdx.x];
+    for (int w = 0; w < TAU_T / 64; ++w) v += red[w][threadIdx.x];
     out[threadIdx.x] = v;
   }
 }
@@ -993,7 +997,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
 #endif
 #undef OLSR_PB_ARGS
   if (o.dL_dtau_sum)
-    tau_final_kernel<<<1, 1024, 0, st>>>(tau_partials, n_partials, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
+    tau_final_kernel<<<1, TAU_T, 0, st>>>(tau_partials, n_partials, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
   else if (o.status_dev || o.sticky_error)
     tau_final_kernel<<<1, 64, 0, st>>>(tau_partials, 0, nullptr, g.counters, o.status_dev, o.sticky_error);
 }

@@ -52,7 +52,8 @@ __device__ __forceinline__ u32 fs_wave_incl_scan(u32 v) {
   }
   return v;
 }
-// exclusive prefix across the 1024 threads of a block; s_w: 16 words of LDS scratch (reusable after return)
+// exclusive prefix across the threads of a block of NW waves; s_w: NW words of LDS scratch (reusable after return)
+template <int NW = FS_W>
 __device__ __forceinline__ u32 fs_block_excl_scan(u32 v, u32* s_w) {
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const u32 incl = fs_wave_incl_scan(v);
@@ -60,7 +61,7 @@ __device__ __forceinline__ u32 fs_block_excl_scan(u32 v, u32* s_w) {
   __syncthreads();
   u32 base = 0;
 #pragma unroll
-  for (int i = 0; i < FS_W; ++i) base += (i < w) ? s_w[i] : 0u;
+  for (int i = 0; i < NW; ++i) base += (i < w) ? s_w[i] : 0u;
   __syncthreads();
   return base + incl - v;
 }
@@ -138,10 +139,11 @@ __device__ __forceinline__ void hint_pick_wave(u32* base, const float* __restric
 // histogram kernel, or the one-launch small depth sort): R = sum of the per-Gaussian instance counts (preprocess' block
 // partials), the reference's num_rendered (rect binning), overflow against the caller's capacity; work-list and row counters
 // reset; tile ranges set to "empty" (start = UINT_MAX, end = 0: the last tile-sort pass lowers / raises them with atomics).
-// s_red: 2 x FS_W words of LDS.
-__device__ __forceinline__ void frame_housekeeping(const FrameHousekeeping& house, int tid, u32 (*s_red)[FS_W]) {
+// s_red: 2 x (T / 64) words of LDS; T = threads of the block.
+template <int T>
+__device__ __forceinline__ void frame_housekeeping(const FrameHousekeeping& house, int tid, u32 (*s_red)[T / 64]) {
   u32 rect = 0, cnt = 0;
-  for (int i = tid; i < house.nparts; i += FS_T) {
+  for (int i = tid; i < house.nparts; i += T) {
     rect += house.part_rect[i];
     cnt += house.part_count[i];
   }
@@ -154,12 +156,12 @@ __device__ __forceinline__ void frame_housekeeping(const FrameHousekeeping& hous
     s_red[0][tid >> 6] = rect;
     s_red[1][tid >> 6] = cnt;
   }
-  for (int i = tid; i < house.nranges; i += FS_T) house.ranges[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
+  for (int i = tid; i < house.nranges; i += T) house.ranges[i] = (i & 1) ? 0u : 0xFFFFFFFFu;
   __syncthreads();
   if (tid == 0) {
     rect = 0;
     cnt = 0;
-    for (int i = 0; i < FS_W; ++i) {
+    for (int i = 0; i < T / 64; ++i) {
       rect += s_red[0][i];
       cnt += s_red[1][i];
     }
@@ -190,21 +192,21 @@ __device__ __forceinline__ void frame_housekeeping(const FrameHousekeeping& hous
   }
 }
 
-__global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
+template <int T>
+__global__ __launch_bounds__(T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int passes, int db,
                                                          u32* __restrict__ hist, FrameHousekeeping house,
                                                          int do_house) {
   __shared__ u32 h[4][256];
-  __shared__ u32 s_red[2][FS_W];
+  __shared__ u32 s_red[2][T / 64];
   const int tid = threadIdx.x;
-  h[0][tid & 255] = 0;  // 1024 threads: four of them per bin, same value
-  h[tid >> 8][tid & 255] = 0;
+  for (int i = tid; i < 4 * 256; i += T) (&h[0][0])[i] = 0;
   __syncthreads();
   const int64_t n = fs_bounded_n(n_host, n_dev);
   const u32 mask = (1u << db) - 1u;
-  const int64_t stride = (int64_t)gridDim.x * FS_T * 4;
+  const int64_t stride = (int64_t)gridDim.x * T * 4;
   constexpr int HU = 4;  // independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
-  for (int64_t i00 = ((int64_t)blockIdx.x * FS_T + tid) * 4; i00 < n; i00 += stride * HU) {
+  for (int64_t i00 = ((int64_t)blockIdx.x * T + tid) * 4; i00 < n; i00 += stride * HU) {
     u32 k[HU][4];
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
     for (int u = 0; u < HU; ++u) {
       const int64_t i0 = i00 + (int64_t)u * stride;
       // (block-uniform: nothing of this block's u-th slice lies below n)
-      if ((int64_t)blockIdx.x * FS_T * 4 + (i00 - ((int64_t)blockIdx.x * FS_T + tid) * 4) + (int64_t)u * stride >= n) continue;
+      if ((int64_t)blockIdx.x * T * 4 + (i00 - ((int64_t)blockIdx.x * T + tid) * 4) + (int64_t)u * stride >= n) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool valid = i0 + j < n;
@@ -242,13 +244,13 @@ __global__ __launch_bounds__(FS_T) void sort_hist_kernel(const u32* __restrict__
     }
   }
   __syncthreads();
-  {
-    const int p = tid >> 8, d = tid & 255;
-    if (p < passes && h[p][d] != 0) atomicAdd(&hist[p * 256 + d], h[p][d]);
+  for (int i = tid; i < passes * 256; i += T) {
+    const u32 c = (&h[0][0])[i];
+    if (c != 0) atomicAdd(&hist[i], c);
   }
   if (do_house && blockIdx.x == 0 && house.hint_base != nullptr && (tid >> 6) == 1)
     hint_pick_wave(house.hint_base, house.view, tid & 63);  // (wave 1: wave 0's lane 0 finishes the counters below)
-  if (do_house && blockIdx.x == 0) frame_housekeeping(house, tid, s_red);
+  if (do_house && blockIdx.x == 0) frame_housekeeping<T>(house, tid, s_red);
 }
 
 // ---- optional phase timing (olsr_debug_sort_timing): block b of every pass launched while it is set records the
@@ -306,8 +308,8 @@ __device__ __forceinline__ void lds_store(u32* p, u32 v) { *reinterpret_cast<vol
 // its final depth rank falls in (emit_totals[rank / EMIT_CHUNK]), so the emission needs no scan of its own.
 constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4, FSF_EMIT_TOTALS = 8;
 
-template <int DB, int KPT>
-__global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num_sgpr(80))) void sort_pass_kernel(const u32* __restrict__ keys_in,
+template <int DB, int KPT, int T>
+__global__ __launch_bounds__(T, (T == 1024 ? (KPT <= 8 ? 8 : 4) : (KPT <= 8 ? 8 : 6))) __attribute__((amdgpu_num_sgpr(80))) void sort_pass_kernel(const u32* __restrict__ keys_in,
                                                          const u32* __restrict__ vals_in, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int shift,
                                                          const u32* __restrict__ ghist, u16* status, u32* ticket,
@@ -316,21 +318,24 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
                                                          const u32* __restrict__ inst_count, u32* emit_totals,
                                                          unsigned long long* timing, int32_t* sync_error, int spin_limit,
                                                          int fault) {
+  constexpr int TW = T / 64;  // waves of the block
+  static_assert(T == 1024 || T == 256, "block sizes of the radix passes");
   constexpr u32 NB = 1u << DB;
+  static_assert((int)NB <= T, "a thread per digit");
   constexpr u32 DMASK = NB - 1u;
-  constexpr int CHUNK = FS_T * KPT;
+  constexpr int CHUNK = T * KPT;
   constexpr int C = (int)NB / 8;   // 16-byte status granules per block row
-  constexpr int RPB = FS_T / C;    // predecessor rows read per batch (one granule per thread)
+  constexpr int RPB = T / C;    // predecessor rows read per batch (one granule per thread)
   constexpr int U = (DB <= 6) ? 4 : 8;  // batches in flight per thread: one round covers U * RPB >= 256 predecessors
   extern __shared__ __attribute__((aligned(16))) u32 fs_smem[];
   u32* cnt = fs_smem;              // [16][NB] per-wave digit counts -> per-wave local starts; later the look-back partials
-  u32* dstart = cnt + FS_W * NB;   // [NB + 1] local start of digit d inside the block (+ sentinel)
+  u32* dstart = cnt + TW * NB;   // [NB + 1] local start of digit d inside the block (+ sentinel)
   u32* gbase = dstart + NB + 4;    // [NB] global start of this block's run of digit d
   u16* pub = reinterpret_cast<u16*>(gbase + NB);  // [NB] this block's published row (16-byte aligned)
   u32* ex_key = gbase + NB + NB / 2;  // [CHUNK]
   u32* ex_val = ex_key + CHUNK;       // [CHUNK]
   __shared__ u32 s_bid;
-  __shared__ u32 s_w[2 * FS_W];
+  __shared__ u32 s_w[2 * TW];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // Chunk index = a TICKET, always: a block only ever waits for blocks that hold a smaller ticket, i.e. that have
   // started — deadlock-free under any dispatch order and any co-tenancy.  (Round 2 took the launch order instead while
@@ -338,9 +343,9 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   // and wait for predecessors that can no longer be placed — ADVICE round 2.)  The ticket's round trip to the fabric
   // (~2 us) is covered by what needs no chunk: clearing the counters and the prefix of the global digit totals.
   if (tid == 0) s_bid = atomicAdd(ticket, 1u);
-  for (u32 i = tid; i < FS_W * NB; i += FS_T) cnt[i] = 0;
+  for (u32 i = tid; i < TW * NB; i += T) cnt[i] = 0;
   const u32 gh = ((u32)tid < NB) ? ghist[tid] : 0u;
-  const u32 gdig = fs_block_excl_scan(gh, s_w);  // global start of every digit (two barriers: s_bid is visible after them)
+  const u32 gdig = fs_block_excl_scan<TW>(gh, s_w);  // global start of every digit (two barriers: s_bid is visible after them)
   const u32 b = s_bid;
   FS_STAMP(0);
   if (timing != nullptr && tid == 0) {
@@ -376,18 +381,18 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
 
   // thread d owns digit d: counts of the 16 waves -> block total (published) and per-wave starts
   const u32 d = (u32)tid;
-  u32 c[FS_W];
+  u32 c[TW];
   u32 tot = 0;
   if (d < NB) {
 #pragma unroll
-    for (int i = 0; i < FS_W; ++i) {
+    for (int i = 0; i < TW; ++i) {
       c[i] = cnt[i * NB + d];
       tot += c[i];
     }
     pub[d] = (u16)(FS_READY16 | tot);
   }
   // local start of every digit inside the block
-  const u32 start = fs_block_excl_scan(d < NB ? tot : 0u, s_w);
+  const u32 start = fs_block_excl_scan<TW>(d < NB ? tot : 0u, s_w);
   // publish this block's row: NB / 8 granules of eight 16-bit counts, write-through (sc1)
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)(gridDim.x * NB * 2u), 0x00020000);
   if (tid < C && !(fault != 0 && b == 0)) {  // (fault: test hook — this block's counts never arrive)
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
     dstart[d] = start;
     u32 run = start;
 #pragma unroll
-    for (int i = 0; i < FS_W; ++i) {
+    for (int i = 0; i < TW; ++i) {
       cnt[i * NB + d] = run;
       run += c[i];
     }
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   if (d < NB) {
     u32 pred = 0;
 #pragma unroll
-    for (int i = 0; i < FS_W; ++i) pred += cnt[i * NB + d];
+    for (int i = 0; i < TW; ++i) pred += cnt[i * NB + d];
     gbase[d] = gdig + pred;
   }
   __syncthreads();
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(FS_T, (KPT <= 8 ? 8 : 4)) __attribute__((amdgpu_num
   const u32 nvalid = rem >= CHUNK ? (u32)CHUNK : (u32)rem;
 #pragma unroll
   for (int k = 0; k < KPT; ++k) {
-    const u32 slot = (u32)k * FS_T + (u32)tid;
+    const u32 slot = (u32)k * T + (u32)tid;
     if (slot < nvalid) {
       const u32 kk = ex_key[slot];
       const u32 dg = (kk >> shift) & DMASK;
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict_
   __shared__ u32 s_red[2][FS_W];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (house.hint_base != nullptr && w == 1) hint_pick_wave(house.hint_base, house.view, lane);
-  frame_housekeeping(house, tid, s_red);
+  frame_housekeeping<FS_T>(house, tid, s_red);
   const int wbase = w * (64 * KPT);
   u32 key[KPT], val[KPT];
 #pragma unroll
@@ -707,42 +712,47 @@ struct PassArgs {
   int fault;
 };
 
-template <int DB, int KPT>
+template <int DB, int KPT, int T>
 static void launch_pass_t(const PassArgs& a, hipStream_t st) {
   constexpr size_t NB = 1u << DB;
-  constexpr size_t smem = sizeof(u32) * (FS_W * NB + NB + 4 + NB + NB / 2 + 2 * (size_t)FS_T * KPT);
+  constexpr size_t smem = sizeof(u32) * ((T / 64) * NB + NB + 4 + NB + NB / 2 + 2 * (size_t)T * KPT);
   static bool attr_set = false;  // (per instantiation) blocks above 64 KB of LDS need the opt-in
   if (!attr_set && smem > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_pass_kernel<DB, KPT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_pass_kernel<DB, KPT, T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   static bool printed = std::getenv("OLSR_SORT_DEBUG") == nullptr;  // (read once per instantiation)
   if (!printed) {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sort_pass_kernel<DB, KPT>, FS_T, smem);
-    std::fprintf(stderr, "[olsr] sort_pass_kernel<%d,%d>: %zu B dynamic LDS, occupancy API: %d blocks/CU, grid %d\n", DB, KPT,
-                 smem, nb, a.nblk);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sort_pass_kernel<DB, KPT, T>, T, smem);
+    std::fprintf(stderr, "[olsr] sort_pass_kernel<%d,%d,%d>: %zu B dynamic LDS, occupancy API: %d blocks/CU, grid %d\n", DB,
+                 KPT, T, smem, nb, a.nblk);
     printed = true;
   }
   unsigned long long* timing = nullptr;
   if (g_timing.buf && g_timing.launch < g_timing.max_launches && a.nblk <= g_timing.max_blocks)
     timing = g_timing.buf + (size_t)(g_timing.launch++) * g_timing.max_blocks * 8;
-  sort_pass_kernel<DB, KPT><<<a.nblk, FS_T, smem, st>>>(a.kin, a.vin, a.n_host, a.n_dev, a.shift, a.ghist, a.status,
+  sort_pass_kernel<DB, KPT, T><<<a.nblk, T, smem, st>>>(a.kin, a.vin, a.n_host, a.n_dev, a.shift, a.ghist, a.status,
                                                         a.ticket, a.kout, a.vout, a.fsf, a.flags, a.ranges,
                                                         a.inst_count, a.emit_totals, timing, a.sync_error,
                                                         sort_knobs().spin_limit.load(std::memory_order_relaxed), a.fault);
 }
 
-template <int DB>
-static void launch_pass_k(int kpt, const PassArgs& a, hipStream_t st) {
+template <int DB, int T>
+static void launch_pass_kt(int kpt, const PassArgs& a, hipStream_t st) {
   switch (kpt) {
-    case 2: launch_pass_t<DB, 2>(a, st); break;
-    case 4: launch_pass_t<DB, 4>(a, st); break;
-    case 8: launch_pass_t<DB, 8>(a, st); break;
-    case 12: launch_pass_t<DB, 12>(a, st); break;
-    default: launch_pass_t<DB, 16>(a, st); break;
+    case 2: launch_pass_t<DB, 2, T>(a, st); break;
+    case 4: launch_pass_t<DB, 4, T>(a, st); break;
+    case 8: launch_pass_t<DB, 8, T>(a, st); break;
+    case 12: launch_pass_t<DB, 12, T>(a, st); break;
+    default: launch_pass_t<DB, 16, T>(a, st); break;
   }
+}
+template <int DB>
+static void launch_pass_k(const SortPlan& plan, const PassArgs& a, hipStream_t st) {
+  if (plan.threads == 256) launch_pass_kt<DB, 256>(plan.kpt, a, st);
+  else launch_pass_kt<DB, 1024>(plan.kpt, a, st);
 }
 
 int fused_sort_digit_bits(int bits, int* passes_out) {
@@ -793,18 +803,20 @@ void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, c
 }
 
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
-                      const FusedHouse* house, hipStream_t st) {
+                      const FusedHouse* house, int threads, hipStream_t st) {
   int passes;
   const int db = fused_sort_digit_bits(bits, &passes);
   const FrameHousekeeping h = housekeeping_of(house);
-  int64_t nb = (n_host + (int64_t)FS_T * 4 - 1) / ((int64_t)FS_T * 4);  // 4 keys (one 16-byte load) per thread ...
+  const int T = threads;
+  int64_t nb = (n_host + (int64_t)T * 4 - 1) / ((int64_t)T * 4);  // 4 keys (one 16-byte load) per thread ...
   if (nb < 1) nb = 1;
 #ifndef OLSR_HIST_BLOCKS
 #define OLSR_HIST_BLOCKS 256  // (measured on 2.7 M keys: 64 / 128 / 256 / 384 / 512 blocks: 21 / 13 / 10 / 12 / 12 us)
 #endif
   if (nb > OLSR_HIST_BLOCKS) nb = OLSR_HIST_BLOCKS;  // ... then a grid-stride loop: every block ends with one global atomic per non-empty bin,
                            // and same-address atomics serialise (~10-20 ns each), so few, fat blocks
-  sort_hist_kernel<<<(int)nb, FS_T, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0);
+  if (T == 256) sort_hist_kernel<256><<<(int)nb, 256, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0);
+  else sort_hist_kernel<1024><<<(int)nb, 1024, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0);
 }
 
 // Sorts (key, val) pairs on the low `bits` bits of key, ceil(bits / 8) passes.  hist / status / tickets must have been
@@ -826,11 +838,11 @@ int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host
                reinterpret_cast<u16*>(status) + (size_t)p * plan.nblk * NB, tickets + p, kout, vout, fsf, flags_clear,
                ranges, inst_count, emit_totals, plan.nblk, sync_error, p == 0 ? fault : 0};
     switch (db) {
-      case 4: launch_pass_k<4>(plan.kpt, a, st); break;
-      case 5: launch_pass_k<5>(plan.kpt, a, st); break;
-      case 6: launch_pass_k<6>(plan.kpt, a, st); break;
-      case 7: launch_pass_k<7>(plan.kpt, a, st); break;
-      case 8: launch_pass_k<8>(plan.kpt, a, st); break;
+      case 4: launch_pass_k<4>(plan, a, st); break;
+      case 5: launch_pass_k<5>(plan, a, st); break;
+      case 6: launch_pass_k<6>(plan, a, st); break;
+      case 7: launch_pass_k<7>(plan, a, st); break;
+      case 8: launch_pass_k<8>(plan, a, st); break;
       default: break;
     }
     u32* t = kin; kin = kout; kout = t;

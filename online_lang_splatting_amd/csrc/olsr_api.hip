@@ -92,7 +92,7 @@ int check_scene(const olsr_scene* s, bool backward) {
   if (!s->means3D || !s->background || !s->viewmatrix || !s->projmatrix || !s->cam_pos)
     return fail(OLSR_ERR_ARG, "means3D, background, viewmatrix, projmatrix and cam_pos are required");
   if (!backward && !s->opacities) return fail(OLSR_ERR_ARG, "opacities are required");
-  if (s->flags & ~(OLSR_FLAG_SIGNED_EMPTY_RADII | OLSR_FLAG_FWD_ACCUM_MFMA | OLSR_FLAG_FWD_ACCUM_WEIGHT)) return fail(OLSR_ERR_ARG, "flags holds unknown OLSR_FLAG_* bits");
+  if (s->flags & ~(OLSR_FLAG_SIGNED_EMPTY_RADII | OLSR_FLAG_FWD_ACCUM_MFMA | OLSR_FLAG_FWD_ACCUM_WEIGHT | OLSR_FLAG_FRAMES_IN_FLIGHT)) return fail(OLSR_ERR_ARG, "flags holds unknown OLSR_FLAG_* bits");
   if (s->activations & ~(OLSR_ACT_OPACITY_SIGMOID | OLSR_ACT_SCALE_EXP | OLSR_ACT_ROTATION_NORMALIZE))
     return fail(OLSR_ERR_ARG, "activations holds unknown OLSR_ACT_* bits");
   if (backward && (s->activations & OLSR_ACT_OPACITY_SIGMOID) && !s->opacities)
@@ -252,11 +252,13 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       launch_small_depth_sort(g.key_a, s.P, g.depth_order, g.tiles_touched, g.emit_status, &house, st);
       STAGE("depth_sort");
     } else {
-    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, st);
+    const bool in_flight = (s.flags & OLSR_FLAG_FRAMES_IN_FLIGHT) != 0;
+    const SortPlan depth_plan = sort_plan(s.P, false, 85, in_flight);
+    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, depth_plan.threads, st);
     // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
     if (!legacy && fused_sort_applicable(s.P, 32)) {
       // (values = Gaussian indices: the first pass takes them from the position, preprocess writes no index array)
-      launch_sort_fused(sb, sort_plan(s.P), s.P, nullptr, 32, true, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
+      launch_sort_fused(sb, depth_plan, s.P, nullptr, 32, true, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
                         g.tiles_touched, g.emit_status, &g.counters[8],
                         sort_knobs().fault.load(std::memory_order_relaxed) & 1, st);
     } else {
@@ -312,7 +314,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     //  quarter —, and a pass is bound by the latency of its fattest block: plan the chunks for that, the uncut first frame of a
     //  sequence pays a few rounds more)
     const bool cut_mode = !sync_mode && s.tile_depth_cut != nullptr && s.binning == OLSR_BINNING_ELLIPSE;
-    const SortPlan tile_plan = sort_plan(n_host, /*n_is_capacity=*/!sync_mode, cut_mode ? 25 : 85);
+    const SortPlan tile_plan = sort_plan(n_host, /*n_is_capacity=*/!sync_mode, cut_mode ? 25 : 85,
+                                         (s.flags & OLSR_FLAG_FRAMES_IN_FLIGHT) != 0);
     // synchronisation words of the binning buffer that this frame uses (zeroed by the emission kernel)
     const int64_t bin_sync_words =
         (b.tile_status - b.sync_words) +
@@ -324,7 +327,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       const bool odd = tile_sort_where(d.ntiles) != 0;
       SortBuffers sb{b.key_a, b.key_b, odd ? b.val_b : b.src, odd ? b.src : b.val_b, b.radix_table, b.scan_partials};
       if (fused_tiles) {
-        launch_sort_hist(b.key_a, n_host, n_dev, tbits, b.tile_hist, nullptr, st);
+        launch_sort_hist(b.key_a, n_host, n_dev, tbits, b.tile_hist, nullptr, tile_plan.threads, st);
         // the first pass also clears the liveness flags, the last one derives the tile ranges
         launch_sort_fused(sb, tile_plan, n_host, n_dev, tbits, true, b.tile_hist, b.tile_status, b.tickets, b.flags, im.ranges,
                           nullptr, nullptr, &g.counters[8], sort_knobs().fault.load(std::memory_order_relaxed) & 2, st);
@@ -480,6 +483,7 @@ struct SortKnobsFromEnv {
     sort_knobs().resident = num("OLSR_SORT_RESIDENT");
     sort_knobs().legacy = num("OLSR_SORT_LEGACY") == 1 ? 1 : 0;
     if (std::getenv("OLSR_SORT_SMALL")) sort_knobs().small_sort = num("OLSR_SORT_SMALL") != 0 ? 1 : 0;
+    if (num("OLSR_SORT_THREADS") == 1024 || num("OLSR_SORT_THREADS") == 256) sort_knobs().threads = num("OLSR_SORT_THREADS");
   }
 } g_sort_knobs_from_env;
 }  // namespace
@@ -1012,6 +1016,11 @@ void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy)
   if (keys_per_thread >= 0) sort_knobs().kpt = keys_per_thread;
   if (resident_blocks >= 0) sort_knobs().resident = resident_blocks;
   if (legacy >= 0) sort_knobs().legacy = legacy ? 1 : 0;
+}
+
+int olsr_debug_sort_threads(int threads) {
+  if (threads == 0 || threads == 256 || threads == 1024) sort_knobs().threads = threads;
+  return sort_knobs().threads.load();
 }
 
 void olsr_debug_sort_small(int enable) {

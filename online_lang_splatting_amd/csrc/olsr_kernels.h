@@ -100,7 +100,7 @@ bool fused_sort_applicable(int64_t n_host, int bits);
 int fused_sort_digit_bits(int bits, int* passes_out);
 // digit totals of all passes (hist[pass][256], zeroed beforehand); optionally the frame's bookkeeping
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
-                      const FusedHouse* house, hipStream_t st);
+                      const FusedHouse* house, int threads /* 256 or 1024: SortPlan::threads */, hipStream_t st);
 // stable sort on the low `bits` bits; status: [passes][plan.nblk][1 << digit bits] zeroed 16-bit words (plan = sort_plan(n_host, ...)), tickets:
 // one zeroed word per pass.  flags_clear (with vals_in_identity): byte i is cleared for every element; ranges: the
 // last pass derives per-key [start, end) (keys must then be tile ids).  Returns where the result ends (0: a, 1: b);

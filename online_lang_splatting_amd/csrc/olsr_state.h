@@ -38,14 +38,22 @@ inline int scan_blocks(long long n) { return (int)((n + SCAN_CHUNK - 1) / SCAN_C
 struct SortPlan {
   int kpt;
   int nblk;
+  int threads;  // 256 or 1024 threads per block
 };
-constexpr int FUSED_SORT_THREADS = 1024;
-constexpr int FUSED_SORT_MAX_BLOCKS = 4096;  // beyond: the multi-kernel passes (histogram, device-wide scan, scatter)
+constexpr int FUSED_SORT_THREADS = 1024;     // the one-launch small sort, and the radix passes' larger block shape
+constexpr int FUSED_SORT_MAX_BLOCKS = 16384;  // beyond: the multi-kernel passes (histogram, device-wide scan, scatter)
 // (tuning / test knobs, process-wide: seeded from OLSR_SORT_KPT / OLSR_SORT_RESIDENT / OLSR_SORT_LEGACY once at load and
 //  set by olsr_debug_sort_knobs — the tests that walk every kernel instantiation and the multi-round ticket order on small
 //  inputs; no getenv on a call path)
 struct SortKnobs {
   std::atomic<int> kpt{0}, resident{0}, legacy{0};
+  // threads per block of the histogram and pass kernels: 0 (default) = the call decides — 1024, or 256 when the scene carries
+  // OLSR_FLAG_FRAMES_IN_FLIGHT; 256 / 1024 = forced (tests, experiments).  With several frames in flight a 1024-thread block
+  // cannot be placed while another frame's composite kernel fills the CUs — it needs sixteen free wave slots on ONE CU, which
+  // only the composite's tail offers — so the radix passes of the other frames stalled until that composite ended (a kernel
+  // trace of four frames in flight: 15 us passes stretched to 147 us).  Four-wave blocks with sixteen keys per thread get on
+  // sooner: + 2 % frames/s with four frames in flight — and - 11 % with one (the depth sort 69 -> 108 us), hence per call.
+  std::atomic<int> threads{0};
   std::atomic<int> small_sort{1};  // the one-launch depth sort of <= 8 192 Gaussians (k_sort.hip); OLSR_SORT_SMALL=0 / olsr_debug_sort_small(0): off
   // test hooks (olsr_debug_sync_fault): fault bit 0 / 1 = the block holding ticket 0 of the first depth / tile pass never
   // publishes its digit counts (what a status word corrupted mid-frame looks like to its successors); spin_limit = polls a
@@ -57,6 +65,11 @@ inline int sort_plan_resident_blocks() {
   const int x = sort_knobs().resident.load(std::memory_order_relaxed);
   return x > 0 ? x : 256;
 }
+inline int sort_plan_threads(bool frames_in_flight = false) {
+  const int forced = sort_knobs().threads.load(std::memory_order_relaxed);
+  if (forced == 1024 || forced == 256) return forced;
+  return frames_in_flight ? 256 : 1024;
+}
 inline int sort_plan_forced_kpt() {
   const int x = sort_knobs().kpt.load(std::memory_order_relaxed);
   return (x == 2 || x == 4 || x == 8 || x == 12 || x == 16) ? x : 0;
@@ -65,34 +78,42 @@ inline int sort_plan_forced_kpt() {
 // for 85 % of it — callers size a capacity with headroom, blocks past the real count exit at once, and the choice only
 // moves time, never the result.
 // fill_pct: the share of a capacity the caller expects to be used (per-tile depth cut-offs leave a fraction of the instances).
-inline SortPlan sort_plan(long long n, bool n_is_capacity = false, int fill_pct = 85) {
+inline SortPlan sort_plan(long long n, bool n_is_capacity = false, int fill_pct = 85, bool frames_in_flight = false) {
   static const int cand[5] = {2, 4, 8, 12, 16};
-  const long long res = sort_plan_resident_blocks();
+  const long long T = sort_plan_threads(frames_in_flight);
+  // blocks of a round: 256 resident 1024-thread blocks (one per CU), or four times as many four-wave blocks
+  const long long res = sort_plan_resident_blocks() * (1024 / T);
   const long long n_est = n_is_capacity ? (n * fill_pct + 99) / 100 : n;
   int best = sort_plan_forced_kpt();
+  if (best == 2 && T == 256) best = 4;  // (a four-wave block takes at least 1024 keys: the status rows are reserved for that)
   // (a forced kpt whose block count would overrun the status rows reserved for FUSED_SORT_MAX_BLOCKS is ignored)
-  if (best != 0 && (n + 1024LL * best - 1) / (1024LL * best) > FUSED_SORT_MAX_BLOCKS) best = 0;
+  if (best != 0 && (n + T * best - 1) / (T * best) > FUSED_SORT_MAX_BLOCKS) best = 0;
+  // four-wave blocks: sixteen keys per thread, measured (config 3, four frames in flight, K = 60: kpt 4 / 8 / 12 / 16 ->
+  // 2 233 / 2 177 / 2 327 / 2 350 frames/s against 2 304 with 1024-thread blocks): few blocks keep the look-back short
+  if (best == 0 && T == 256) best = 16;
   if (best == 0) {
     double best_cost = 0.0;
-    for (int i = 0; i < 5; ++i) {
-      const long long chunk = 1024LL * cand[i];
+    for (int i = (T == 256 ? 1 : 0); i < 5; ++i) {
+      const long long chunk = T * cand[i];
       if ((n + chunk - 1) / chunk > FUSED_SORT_MAX_BLOCKS && i < 4) continue;
       const long long nb = (n_est + chunk - 1) / chunk;
-      const double cost = (double)((nb + res - 1) / res) * (cand[i] + 11.0);
+      // a round costs kpt + 11 us (measured with 1024-thread blocks); with four-wave blocks a block's look-back reads the
+      // published counts of up to four times as many predecessors: ~1 us per 128 of them
+      const double cost = (double)((nb + res - 1) / res) * (cand[i] + 11.0) + (T == 256 ? (double)nb / 128.0 : 0.0);
       if (best == 0 || cost < best_cost) {
         best = cand[i];
         best_cost = cost;
       }
     }
   }
-  return SortPlan{best, (int)((n + 1024LL * best - 1) / (1024LL * best))};
+  return SortPlan{best, (int)((n + T * best - 1) / (T * best)), (int)T};
 }
-inline bool fused_sort_fits(long long n) { return (n + 16383) / 16384 <= FUSED_SORT_MAX_BLOCKS; }
+inline bool fused_sort_fits(long long n) { return (n + 4095) / 4096 <= FUSED_SORT_MAX_BLOCKS; }  // (256 threads x 16 keys)
 // status words reserved for a sort of n keys: whatever kpt the plan picks (it may differ between a sized and a
 // capacity-bounded launch of the same n), the rows of the smallest chunk cover it
 inline size_t fused_status_words(long long n, int passes) {
   if (!fused_sort_fits(n)) return 0;
-  long long nb = (n + 2047) / 2048;
+  long long nb = (n + 1023) / 1024;  // the smallest chunk: 256 threads x 4 keys (1024 threads x 2 keys is twice that)
   if (nb > FUSED_SORT_MAX_BLOCKS) nb = FUSED_SORT_MAX_BLOCKS;
   return (size_t)passes * (size_t)nb * 128;  // 256 16-bit counts per row
 }

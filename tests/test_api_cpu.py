@@ -169,6 +169,18 @@ def test_sort_plan_host_logic(L, monkeypatch):
     def plan(n, cap=0):
         ok = L.olsr_debug_sort_plan(n, cap, ctypes.byref(kpt), ctypes.byref(nblk))
         return ok, kpt.value, nblk.value
+    # round 5: a scene with OLSR_FLAG_FRAMES_IN_FLIGHT sorts with four-wave (256-thread) blocks of sixteen keys per thread — they
+    # get onto the CUs beside another frame's composite workgroups; olsr_debug_sort_threads forces a shape for every call
+    assert L.olsr_debug_sort_threads(-1) == 0      # (default: the call decides; 1024 without the flag)
+    assert L.olsr_debug_sort_threads(256) == 256
+    for n in (1, 1023, 1024, 1025, 500_000, 2_700_146, 10_000_000, 60_000_000):
+        ok, k, b = plan(n)
+        assert ok == 1 and k == 16 and b == -(-n // (256 * 16)) and b <= 16384
+    assert plan(16384 * 4096 + 1)[0] == 0          # more than 16 384 blocks even at kpt 16: the multi-kernel passes
+    L.olsr_debug_sort_knobs(2, -1, -1)             # (kpt 2 does not exist for four-wave blocks: 4 runs)
+    assert plan(500_000)[1] == 4
+    L.olsr_debug_sort_knobs(0, -1, -1)
+    assert L.olsr_debug_sort_threads(0) == 0       # the 1024-thread shape of rounds 2-4, below
     assert plan(500_000) == (1, 2, 245)            # the depth sort of the headline frame: one round at kpt 2
     assert plan(2_700_146) == (1, 12, 220)         # its tile sort: one round of 220 fat blocks
     ok, k, b = plan(3_440_000, 1)                  # the same sort launched against a capacity: planned for 85 % fill
@@ -177,14 +189,14 @@ def test_sort_plan_host_logic(L, monkeypatch):
     assert plan(0)[2] == 0
     for n in (1, 2047, 2048, 2049, 10_000_000, 60_000_000):
         ok, k, b = plan(n)
-        assert ok == 1 and k in (2, 4, 8, 12, 16) and b == -(-n // (1024 * k)) and b <= 4096
-    assert plan(4096 * 16384 + 1)[0] == 0          # more than 4096 blocks even at kpt 16: the multi-kernel passes
+        assert ok == 1 and k in (2, 4, 8, 12, 16) and b == -(-n // (1024 * k)) and b <= 16384
+    assert plan(4096 * 16384 + 1)[0] == 0          # beyond what the status rows are reserved for: the multi-kernel passes
     # the tuning knobs: set through the library (the environment is read once, at load), a forced value that would
     # overrun the status rows is ignored, a negative argument leaves a knob alone
     try:
         L.olsr_debug_sort_knobs(4, -1, -1)
         assert plan(500_000)[1:] == (4, 123)
-        assert plan(40_000_000)[1] != 4 and plan(40_000_000)[2] <= 4096
+        assert plan(40_000_000)[2] <= 16384
         L.olsr_debug_sort_knobs(-1, 64, -1)
         assert plan(500_000)[1:] == (4, 123)
         L.olsr_debug_sort_knobs(0, -1, -1)
@@ -192,6 +204,7 @@ def test_sort_plan_host_logic(L, monkeypatch):
     finally:
         L.olsr_debug_sort_knobs(0, 0, 0)
     assert plan(500_000) == (1, 2, 245)
+    assert L.olsr_debug_sort_threads(-1) == 0
 
 
 def test_backward_row_policy_without_a_posted_count(L):

@@ -398,6 +398,50 @@ def test_one_launch_depth_sort_equals_the_radix_passes(hip, P):
     assert sorted(out[1][1].tolist()) == list(range(P))
 
 
+@pytest.mark.parametrize("threads", [256, 1024])
+@pytest.mark.parametrize("kpt", [0, 4, 8, 12])
+def test_radix_block_shapes_give_the_same_lists(hip, oracle, threads, kpt):
+    """Round 5: the radix passes and their histogram kernels run as 1024-thread or — for a scene that says frames are in flight
+    on other streams (OLSR_FLAG_FRAMES_IN_FLIGHT) — as four-wave workgroups; olsr_debug_sort_threads forces a shape.  Every
+    shape and keys-per-thread leaves the reference's lists and the oracle's images, bit for bit."""
+    from online_lang_splatting_amd._lib import lib
+    try:
+        lib().olsr_debug_sort_threads(threads)
+        lib().olsr_debug_sort_knobs(kpt, -1, -1)
+        _check(hip, oracle, make_scene(60000, 640, 480, 15, seed=81), seed=8)
+        _check(hip, oracle, make_scene(9000, 200, 150, 0, seed=82), seed=9, tile=16)
+    finally:
+        lib().olsr_debug_sort_threads(0)
+        lib().olsr_debug_sort_knobs(0, -1, -1)
+
+
+def test_frames_in_flight_flag_changes_no_result(hip):
+    """The per-call form: a workspace whose scenes carry FLAG_FRAMES_IN_FLIGHT (FrameLanes with more than one lane sets it)
+    renders the same frame and the same gradients as one without."""
+    from online_lang_splatting_amd.frame_shard import GradLayout, GradientBucket, RasterWorkspace
+    dev = torch.device(DEV)
+    sc = make_scene(40000, 400, 300, 15, seed=83)
+    cam = sc.camera
+    g = dict(bg=sc.bg.to(dev), means3D=sc.means3D.to(dev), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev), shs=sc.shs.to(dev), language=sc.language.to(dev),
+             viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+             projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
+             tanfovy=cam.tanfovy, sh_degree=sc.sh_degree)
+    cot = [t.to(dev) for t in sc.cotangents(2)]
+    res = []
+    for flags in (0, _abi.FLAG_FRAMES_IN_FLIGHT):
+        ws = RasterWorkspace(sc.P, 400, 300, 15, sc.shs.shape[1], 1_500_000, dev, flags=flags)
+        b = GradientBucket(sc.P, GradLayout(sc.shs.shape[1], 15), dev)
+        ws.set_scene(**g)
+        out = {k: v.clone() for k, v in ws.forward().items()}
+        ws.backward(*cot, bucket=b, first=True, bucket_only=True)
+        torch.cuda.synchronize()
+        res.append((out, b.flat.clone(), ws.rendered()))
+    for k in res[0][0]:
+        assert torch.equal(res[0][0][k], res[1][0][k]), k
+    assert torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
 def test_repeated_backward_on_one_forward(hip):
     """The row compaction's look-back state is re-armed by the kernel itself: a backward may be repeated on the same
     forward (autograd's retain_graph, or the test above) and must give the same bits every time."""
