@@ -422,7 +422,7 @@ def room_scene_leg(dev, dims, steps, seed=3):
     stp = MappingStep(lanes, params, g_dev["bg"], 0, camd, rs.targets, lrs, exposure=torch.zeros(2, device=dev))
     for _ in range(10):
         stp.iteration()
-    torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(6):
         stp.iteration()
@@ -786,10 +786,11 @@ def config4_substitute(sc, g_dev, dev, dims, tracking_iters=60, mapping_iters=4,
         if v is not None:
             v.copy_(start[k])
     st_auto = MappingStep(lanes, params, g_dev["bg"], sc.sh_degree, camd, targets, lrs, exposure=torch.zeros(2, device=dev))
-    for _ in range(9):
+    for _ in range(9):   # (synchronised like a caller that reads the loss every iteration: the calibration's events complete)
         st_auto.iteration()
-    torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)
     st_auto.iteration()
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(mapping_iters):
         st_auto.iteration()
