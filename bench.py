@@ -430,6 +430,41 @@ def room_scene_leg(dev, dims, steps, seed=3):
     mp["auto_loss"] = {"ms_per_iteration": round(1e3 * (time.perf_counter() - t0) / 6, 3), "calibration": stp.calibration}
     del stp
     out["mapping"] = dict(mp, views=len(camd), views_in_flight=len(lanes))
+    # ... and the map the loop renders MOST of the time: after 150 mapping iterations on those 12 views (BackEnd.map runs
+    # mapping_itr_num = 150 per keyframe, configs/rgbd/replicav2/base_config.yaml:38) the opacities have left 0.5, the scales
+    # have grown over the gaps and gone anisotropic.  The same workload statistics and rates on the trained parameters.
+    for k, v in params.items():
+        if v is not None:
+            v.copy_(start[k])
+    stp = MappingStep(lanes, params, g_dev["bg"], 0, camd, rs.targets, lrs, exposure=torch.zeros(2, device=dev), fused_loss=True)
+    stp.iteration()
+    loss0 = float(stp.last_loss[0])
+    for _ in range(149):
+        stp.iteration()
+    loss1 = float(stp.last_loss[0])
+    del stp
+    rot_n = params["rotations"] / params["rotations"].norm(dim=1, keepdim=True).clamp_min(1e-12)
+    g_tr = dict(g_dev, means3D=params["means3D"], shs=params["shs"], opacities=torch.sigmoid(params["opacities"]).contiguous(),
+                scales=torch.exp(params["scales"]).contiguous(), rotations=rot_n.contiguous(), language=params["language"])
+    g_fresh, g_dev = g_dev, g_tr          # (step() renders from g_dev)
+    R1 = max(_sized_capacity(F, g_dev, c_, H, W, 0, dev, cfg0) for c_ in camd[:3])
+    if int(1.3 * R1) + (1 << 16) > cap:
+        lanes = FrameLanes(4, sc.P, W, H, F, M, int(1.5 * R1) + (1 << 16), dev)
+        lane0 = FrameLanes(1, sc.P, W, H, F, M, int(1.5 * R1) + (1 << 16), dev).lanes[0]
+    tr = {"mapping_iterations": 150, "loss_first": round(loss0, 6), "loss_last": round(loss1, 6),
+          "isolated": {"value": round(rate(n, lambda: lane0, lambda i: camd[0]), 1), "unit": "frames/s"},
+          "four_in_flight": {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[0], warm=40), 1), "unit": "frames/s"}}
+    step(lane0, camd[0])
+    st_tr = workload_stats(lane0[0], sc.P, W, H, F)
+    st_tr["live_gradient_rows_gaussians"] = int((lane0[1].flat != 0).any(dim=1).sum())
+    st_tr["live_rows_of_visible"] = round(st_tr["live_gradient_rows_gaussians"] / max(st_tr["visible_gaussians"], 1), 4)
+    st_tr["mean_opacity_image"] = round(float(lane0[0].out["opacity"].mean()), 4)
+    st_tr["opacity_parameter_quantiles_5_50_95"] = [round(float(x), 3) for x in
+                                                    torch.quantile(g_tr["opacities"].flatten().float()[::7], torch.tensor([0.05, 0.5, 0.95], device=dev))]
+    st_tr["scale_anisotropy_median"] = round(float((g_tr["scales"].max(1).values / g_tr["scales"].min(1).values).median()), 3)
+    tr["workload"] = st_tr
+    out["after_150_mapping_iterations"] = tr
+    g_dev = g_fresh
     del lanes
     torch.cuda.empty_cache()
     return out
