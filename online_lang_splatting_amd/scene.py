@@ -357,6 +357,8 @@ def make_room_scene(P=500_000, W=1200, H=680, F=15, views=10, seed=0, max_sh_deg
         # cast (the depth image of a keyframe is never needed whole; the median depth of adaptive_pointsize is taken over the
         # kept pixels — in this room it is above 1 m from every pose, so point_size = 0.05 either way)
         n_take = min(n_first if k == 0 else n_next, left)
+        if 0 < left - n_take < 4:   # (a last keyframe of fewer than four points has no three neighbours: it takes them along)
+            n_take = min(left, N)
         pick = torch.randperm(N, generator=g)[:n_take]
         depth, hitp, sid = _raycast_room(cam, W, H, pick)
         col = _room_colour(hitp, sid)

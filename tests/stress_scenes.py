@@ -47,3 +47,36 @@ def random_scene(k, seed0=0, generation="base"):
         kw["scale_modifier"] = 0.5 + r()
     desc = f"scene {k}: P={P} {W}x{H} tile={tile} F={F} deg={deg} mode={mode} {sorted(kw)}"
     return sc, tile, mode, kw, desc
+
+
+def random_room_scene(k, seed0=0):
+    """A random SURFACE scene (round 5): scene.make_room_scene at a random size / resolution / language width, seen from a
+    random keyframe of its window, with the perturbations a SLAM map goes through between keyframes — scales grown and made
+    anisotropic, rotations off identity, opacities spread, a camera nudged off the keyframe pose.
+    -> (scene, tile, backward mode, keyword arguments of _check, description)."""
+    from online_lang_splatting_amd.scene import Camera, knn_mean_dist2_host, make_room_scene
+    g = torch.Generator().manual_seed(88_000 + seed0 + k)
+    r = lambda: float(torch.rand(1, generator=g))  # noqa: E731
+    W, H = int(96 + r() * 380), int(64 + r() * 260)
+    P = int(1500 + r() * 30000)
+    F = (0, 3, 15, 16, 32)[int(r() * 5) % 5]
+    views = 3 + int(r() * 4)
+    rs = make_room_scene(P, W, H, F, views=views, seed=500 + seed0 + k, knn=knn_mean_dist2_host)
+    v = int(r() * views) % views
+    sc = rs.view(v)
+    n = sc.P
+    if r() < 0.7:   # a map that has been optimised for a while
+        sc.scales = (sc.scales * torch.exp(0.5 * torch.randn(n, 3, generator=g) + 0.6 * r())).contiguous()
+        q = sc.rotations + 0.3 * torch.randn(n, 4, generator=g)
+        sc.rotations = (q / q.norm(dim=1, keepdim=True)).contiguous()
+        sc.opacities = torch.sigmoid(torch.randn(n, 1, generator=g) * 2.0 + 1.0).contiguous()
+    if r() < 0.5:   # the tracked pose is never exactly a keyframe's
+        c = sc.camera
+        a_ = (r() - 0.5) * 0.2
+        Ry = torch.tensor([[math.cos(a_), 0.0, math.sin(a_)], [0.0, 1.0, 0.0], [-math.sin(a_), 0.0, math.cos(a_)]])
+        sc.camera = Camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy, (Ry @ c.R).contiguous(),
+                           (Ry @ c.T + torch.tensor([(r() - 0.5) * 0.2, (r() - 0.5) * 0.1, (r() - 0.5) * 0.2])).contiguous())
+    tile = 16 if r() < 0.4 else 15
+    mode = _abi.BWD_EXACT if r() < 0.3 else _abi.BWD_REFERENCE
+    desc = f"room scene {k}: P={n} {W}x{H} tile={tile} F={F} view {v}/{views} mode={mode}"
+    return sc, tile, mode, {}, desc
