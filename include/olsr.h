@@ -633,6 +633,13 @@ void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy)
  * olsr_debug_sort_knobs also selects the pass kernels. */
 void olsr_debug_sort_small(int enable);
 
+/* Diagnostic: while a device buffer of 2 x capacity uint64 is set, every forward / backward composite launch of this process
+ * is bracketed by two one-thread kernels on its stream that write {device wall clock (100 MHz), stream << 8 | kind} — kind 0 / 1:
+ * in front of / behind the forward composite (+ its tile-order kernel), 2 / 3: the backward composite — into consecutive
+ * entries.  Reads the overlap of several frames in flight without a profiler (scripts/probe/composite_overlap.py).  The stamps
+ * cost four tiny launches per frame.  NULL switches it off. */
+void olsr_debug_composite_stamps(unsigned long long *device_buffer, int capacity);
+
 /* Test / experiment knob: threads per workgroup of the radix passes and their histogram kernels.  0 (default): the call
  * decides — 1024, or 256 for a scene that carries OLSR_FLAG_FRAMES_IN_FLIGHT; 256 / 1024: forced for every later forward.
  * Any other argument only reads the value back.  Same lists bit for bit.  Process-wide; seeded once from OLSR_SORT_THREADS.

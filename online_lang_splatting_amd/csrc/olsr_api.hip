@@ -202,6 +202,25 @@ const char* const STICKY_MSG =
     "through the reference-shaped entry on ANY thread or stream of this process, not necessarily by this call; callers that "
     "need the error attributed use the sync-free entries, whose status words are per frame.)";
 
+// Diagnostic (olsr_debug_composite_stamps): one-thread kernels in front of and behind every composite launch write the
+// device's wall clock (100 MHz, common to all XCDs) into a caller's buffer — when did each composite become eligible, when had
+// it finished, on which stream — so that the overlap of several frames in flight can be read without a profiler in the way.
+struct StampState {
+  unsigned long long* buf = nullptr;
+  int capacity = 0;
+  std::atomic<int> next{0};
+} g_stamps;
+__global__ void stamp_kernel(unsigned long long* slot, unsigned long long tag) {
+  slot[0] = wall_clock64();
+  slot[1] = tag;
+}
+void stamp(hipStream_t st, int kind) {
+  if (!g_stamps.buf) return;
+  const int i = g_stamps.next.fetch_add(1);
+  if (i >= g_stamps.capacity) return;
+  stamp_kernel<<<1, 1, 0, st>>>(g_stamps.buf + 2 * (size_t)i, ((unsigned long long)(uintptr_t)st << 8) | (unsigned)kind);
+}
+
 int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const BinningProvider& bp, float* out_color,
                  float* out_language, float* out_depth, float* out_opacity, int32_t* radii, int32_t* n_touched,
                  int32_t* num_rendered_host, int32_t* num_rendered_dev, uint32_t* tile_order_inout, hipStream_t st,
@@ -365,8 +384,10 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     g_rows_call.hint_slot = view_hints;
     tile_order_inout = view_hints + HINT_HDR;
   }
+  stamp(st, 0);
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
                         num_rendered_dev, (s.P > 0) ? loss : nullptr, st);
+  stamp(st, 1);
   g_rows_call = RowsMailbox{};
   STAGE("render_forward");
 
@@ -706,10 +727,12 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   }
   float* rows = (float*)(((uintptr_t)scratch + ALIGN - 1) / ALIGN * ALIGN);
 
+  stamp(st, 2);
   if (s.bwd_mode == OLSR_BWD_REFERENCE)
     launch_render_backward_reference(s, F_rows, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
   else
     launch_render_backward_exact(s, F_rows, d, g, b, im, dL_dout_color, dL_dout_language, dL_dout_depth, rows, st);
+  stamp(st, 3);
   STAGE("render_backward");
   GradOut o{dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dlanguage, dL_ddepths, dL_dmeans3D,
             dL_dcov3D,   dL_dsh,    dL_dscales,  dL_drotations, dL_dtau,    dL_dtau_sum};
@@ -1016,6 +1039,12 @@ void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy)
   if (keys_per_thread >= 0) sort_knobs().kpt = keys_per_thread;
   if (resident_blocks >= 0) sort_knobs().resident = resident_blocks;
   if (legacy >= 0) sort_knobs().legacy = legacy ? 1 : 0;
+}
+
+void olsr_debug_composite_stamps(unsigned long long* device_buffer, int capacity) {
+  g_stamps.buf = device_buffer;
+  g_stamps.capacity = device_buffer ? capacity : 0;
+  g_stamps.next = 0;
 }
 
 int olsr_debug_sort_threads(int threads) {
