@@ -55,6 +55,7 @@ def _flags(keep_temps):
          "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
     if keep_temps:
         f += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    f += os.environ.get("OLSR_EXTRA_DEFS", "").split()  # (experiments: variant builds of the kernels)
     return f
 
 

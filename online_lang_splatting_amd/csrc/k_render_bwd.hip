@@ -117,6 +117,9 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
     const float* __restrict__ lang, const float* __restrict__ depths, const float* __restrict__ final_Ts,
     const u32* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_lang,
     const float* __restrict__ dL_dpixels_depth, float* __restrict__ rows) {
+#ifdef OLSR_COMPOSITE_VGPR_FLOOR
+  asm volatile("; vgpr floor" ::: OLSR_COMPOSITE_VGPR_FLOOR);  // (experiment: fewer resident waves, room for other frames' kernels)
+#endif
   typedef typename bwd_pair<F>::type bv2;
   constexpr int BS = TILE * TILE;
   constexpr int FR = feat_row(F);

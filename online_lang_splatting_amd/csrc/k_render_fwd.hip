@@ -76,6 +76,9 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
     u32* __restrict__ tile_work, const u32* __restrict__ order_hint, const int32_t* __restrict__ counters,
     const u32* __restrict__ hint_slot, float* __restrict__ depth_cut, int32_t* __restrict__ cut_miss,
     uint8_t* __restrict__ blended, const FusedLossArgs fl) {
+#ifdef OLSR_COMPOSITE_VGPR_FLOOR
+  asm volatile("; vgpr floor" ::: OLSR_COMPOSITE_VGPR_FLOOR);  // (experiment: fewer resident waves, room for other frames' kernels)
+#endif
   // a radix pass of this frame lost a predecessor's counts (olsr_state.h, counters[8]): the lists are garbage and must not be
   // used as indices — render nothing; the tile-order kernel behind this one reports OLSR_STATUS_SYNC_ERROR
   if (counters[8] != 0) return;
