@@ -36,7 +36,6 @@ DGR-D/cuda_rasterizer/config.h:17-18):
                                and pose gradients dropped.
 """
 import torch
-import torch.nn as nn
 
 from . import _C, _abi
 from .rasterizer import (GaussianRasterizationSettings, _check_exclusive, _cotangent, _or_empty,  # noqa: F401

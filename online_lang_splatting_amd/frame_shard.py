@@ -19,7 +19,7 @@ Two things the reference does not have:
 """
 import ctypes as C
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Sequence
 
 import torch
 

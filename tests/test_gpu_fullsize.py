@@ -89,8 +89,8 @@ def test_config3_against_the_contract_everywhere_model_of_the_reference(hip, ora
     blend decisions flip: 12 of 54.9 M between the two oracles, profiles/r2_cuda_sensitivity.json), the tensors behind the
     per-Gaussian chain at >= 99.99 % — and the figures are written to gpurun_out/parity_fullsize.json next to the default
     model's."""
-    from parity_common import assert_elementwise, elementwise_report, run_backend
-    from test_gpu_parity import COMPOSITE_GRADS, DEV
+    from parity_common import elementwise_report, run_backend
+    from test_gpu_parity import DEV
     sc = make_config_scene(3)
     log = []
     oracle.use_variant("contract_fast")

@@ -6,7 +6,6 @@ import numpy as np
 import pytest
 import torch
 
-from online_lang_splatting_amd import _abi
 from online_lang_splatting_amd.scene import default_camera, make_scene
 
 pytestmark = pytest.mark.gpu

@@ -2,7 +2,6 @@
 restates — gaussian_splatting/scene/gaussian_model.py:180-281 (depth back-projection per keyframe, random down-sampling by
 32 / 64, scale = sqrt(distCUDA2 * point_size) on three equal axes, identity rotation, opacity 0.5, RGB2SH) — and the oracle
 rendering it: a map built by back-projecting ray-cast depth must render that depth again."""
-import math
 
 import torch
 
