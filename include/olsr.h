@@ -163,6 +163,12 @@ typedef struct olsr_scene {
   int32_t flags;       /* OLSR_FLAG_* bit mask, 0 = the reference's behaviour */
   float *tile_depth_cut; /* NULL (the default), or device float[2 x tiles], in/out — see "Per-tile depth cut-offs" below.
                           * Used by olsr_forward_async / olsr_forward_async_loss only. */
+  int64_t backward_row_capacity; /* 0 (the default), or — for a caller that owns a fixed backward scratch — its row capacity
+                          * (`scratch_rows` of the olsr_backward that will follow, with this bwd_mode and tile).  The forward's last
+                          * launch then also compacts the backward's rows (which depend on the forward alone), and an
+                          * olsr_backward given a scene with the same non-zero value skips its own compaction launch: one launch
+                          * and ~8 us less per frame.  Both calls must see the same value, bwd_mode and tile; the backward
+                          * verifies scratch_rows == backward_row_capacity (OLSR_ERR_ARG) and needs scratch_alloc == NULL. */
 } olsr_scene;
 
 /* Per-tile depth cut-offs (round 4; an opt-in for SEQUENCES of nearly identical views: the ~100 tracking iterations of a

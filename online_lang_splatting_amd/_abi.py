@@ -67,6 +67,7 @@ class OlsrScene(C.Structure):
         ("activations", C.c_int32),
         ("flags", C.c_int32),
         ("tile_depth_cut", _fp),
+        ("backward_row_capacity", C.c_int64),
     ]
 
 
@@ -118,7 +119,8 @@ def _ptr(t):
 
 def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode, tan_fovx, tan_fovy,
                scale_modifier, binning=BINNING_RECT, activations=0, flags=0, background, means3D, shs, colors_precomp, language_precomp, opacities,
-               scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos, tile_depth_cut=None):
+               scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos, tile_depth_cut=None,
+               backward_row_capacity=0):
     s = OlsrScene()
     s.P, s.D, s.M, s.F = int(P), int(D), int(M), int(F)
     s.width, s.height, s.tile = int(width), int(height), int(tile)
@@ -141,4 +143,5 @@ def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode,
     s.projmatrix_raw = _ptr(projmatrix_raw)
     s.cam_pos = _ptr(cam_pos)
     s.tile_depth_cut = _ptr(tile_depth_cut)
+    s.backward_row_capacity = int(backward_row_capacity)
     return s

@@ -762,10 +762,36 @@ __device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, i
 constexpr int ROWS_THREADS = 1024;
 static_assert(ROWS_CHUNK == ROWS_THREADS * 16, "one 16-byte load of flags per thread");
 
-__global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
-    const uint8_t* __restrict__ flags, int64_t n_host, const int32_t* __restrict__ n_dev, int shift, u32 mask,
-    u32* __restrict__ rowbase, u32* status, u32* sync /* [0] ticket, [1] finished blocks */,
-    long long row_capacity, int32_t* counters, int32_t* __restrict__ status_dev, int spin_limit) {
+struct RowCompactionArgs {
+  const uint8_t* flags;
+  int64_t n_host;
+  const int32_t* n_dev;
+  int shift;
+  u32 mask;
+  u32* rowbase;
+  u32* status;
+  u32* sync;  // [0] ticket, [1] finished blocks
+  long long row_capacity;
+  int32_t* counters;
+  int32_t* status_dev;
+  int spin_limit;
+};
+
+// one block's share; nblocks = the blocks of the launch that run this body (the whole grid of row_compaction_kernel, the
+// row part of forward_tail_kernel)
+__device__ __forceinline__ void row_compaction_block(const RowCompactionArgs& ra, const u32 nblocks) {
+  const uint8_t* __restrict__ flags = ra.flags;
+  const int64_t n_host = ra.n_host;
+  const int32_t* __restrict__ n_dev = ra.n_dev;
+  const int shift = ra.shift;
+  const u32 mask = ra.mask;
+  u32* __restrict__ rowbase = ra.rowbase;
+  u32* status = ra.status;
+  u32* sync = ra.sync;
+  const long long row_capacity = ra.row_capacity;
+  int32_t* counters = ra.counters;
+  int32_t* __restrict__ status_dev = ra.status_dev;
+  const int spin_limit = ra.spin_limit;
   __shared__ u32 s_bid;
   __shared__ u32 s_wsum[ROWS_THREADS / 64 + 1];
   __shared__ u32 s_last;
@@ -778,8 +804,8 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
   const int64_t n = bounded_n(n_host, n_dev);  // flags beyond the instances of this frame are stale
   const int64_t bbase = (int64_t)b * ROWS_CHUNK;
   // (a ticket beyond the grid: the ticket word was not the zero the emission left — corrupted from outside)
-  if (b >= gridDim.x && threadIdx.x == 0) atomicOr(&counters[8], 1);
-  if (b < gridDim.x && bbase <= n) {  // (the block that holds index n writes the total; later blocks have nothing to do)
+  if (b >= nblocks && threadIdx.x == 0) atomicOr(&counters[8], 1);
+  if (b < nblocks && bbase <= n) {  // (the block that holds index n writes the total; later blocks have nothing to do)
     const int64_t base = bbase + (int64_t)threadIdx.x * 16;
     u32 v[16];
     load_popc16(flags, base, n, shift, mask, v);
@@ -844,15 +870,19 @@ __global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(
   }
   // self-reset for a repeated backward on the same forward: whoever finishes last has seen every block done
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(&sync[1], 1u) == gridDim.x - 1u) ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = (atomicAdd(&sync[1], 1u) == nblocks - 1u) ? 1u : 0u;
   __syncthreads();
   if (s_last) {
-    for (u32 i = threadIdx.x; i < 2 * gridDim.x; i += ROWS_THREADS) lb_store(&status[i], 0u);
+    for (u32 i = threadIdx.x; i < 2 * nblocks; i += ROWS_THREADS) lb_store(&status[i], 0u);
     if (threadIdx.x == 0) {
       __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+__global__ __launch_bounds__(ROWS_THREADS) void row_compaction_kernel(const RowCompactionArgs ra) {
+  row_compaction_block(ra, gridDim.x);
 }
 
 void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* n_dev, bool packed_ref15,
@@ -862,10 +892,9 @@ void launch_row_compaction(const uint8_t* flags, int64_t n_host, const int32_t* 
   const u32 mask = packed_ref15 ? 3u : 15u;
   if (n_host < 0) n_host = 0;
   const int nb = (int)((n_host + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK);  // index n itself belongs to a block
-  row_compaction_kernel<<<nb, ROWS_THREADS, 0, st>>>(flags, n_host, n_dev, shift, mask, rowbase,
-                                                     row_status, sync,
-                                                     (long long)row_capacity, counters, status_dev,
-                                                     sort_knobs().spin_limit.load(std::memory_order_relaxed));
+  const RowCompactionArgs ra{flags, n_host, n_dev, shift, mask, rowbase, row_status, sync, (long long)row_capacity, counters,
+                             status_dev, sort_knobs().spin_limit.load(std::memory_order_relaxed)};
+  row_compaction_kernel<<<nb, ROWS_THREADS, 0, st>>>(ra);
 }
 
 // ------------------------------------------------------------------------------- ranges
@@ -958,51 +987,76 @@ __device__ __forceinline__ void dilate_depth_cuts(const CutDilate& cd, int threa
   }
 }
 
-__global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__ work, u32* __restrict__ order,
-                                                         u32* __restrict__ order_copy, int ntiles,
-                                                         u32* __restrict__ live_rows, int32_t* mailbox, int32_t seq,
-                                                         const int32_t* __restrict__ counters,
-                                                         int32_t* __restrict__ num_rendered_dev, int32_t* sticky,
-                                                         const u32* __restrict__ hint_slot, const CutDilate cd,
-                                                         const LossFinalArgs lfa) {
+struct TileOrderArgs {
+  const u32* work;
+  u32* order;
+  u32* order_copy;
+  int ntiles;
+  u32* live_rows;
+  int32_t* mailbox;
+  int32_t seq;
+  const int32_t* counters;
+  int32_t* num_rendered_dev;
+  int32_t* sticky;
+  const u32* hint_slot;
+  CutDilate cd;
+  LossFinalArgs lfa;
+};
+
+// block (bx, by) of a logical (8, ny) grid of 256-thread blocks (tile_order_kernel's own grid, or the first 8 ny blocks of
+// forward_tail_kernel, whose threads beyond 256 have left)
+__device__ __forceinline__ void tile_order_block(const TileOrderArgs& ta, const int bx, const int by, const int ny) {
+  const u32* __restrict__ work = ta.work;
+  u32* __restrict__ order = ta.order;
+  u32* __restrict__ order_copy = ta.order_copy;
+  const int ntiles = ta.ntiles;
+  u32* __restrict__ live_rows = ta.live_rows;
+  int32_t* mailbox = ta.mailbox;
+  const int32_t seq = ta.seq;
+  const int32_t* __restrict__ counters = ta.counters;
+  int32_t* __restrict__ num_rendered_dev = ta.num_rendered_dev;
+  int32_t* sticky = ta.sticky;
+  const u32* __restrict__ hint_slot = ta.hint_slot;
+  const CutDilate& cd = ta.cd;
+  const LossFinalArgs& lfa = ta.lfa;
   extern __shared__ __attribute__((aligned(16))) u32 s_work[];  // the chunk's weights, padded to a multiple of 64
   // the loss of a forward with the fused epilogue: its per-tile partial sums are reduced here, by the grid's last block
   // (uniform branch; the block then does its share of the tile order like every other)
-  if (lfa.partials != nullptr && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) {
+  if (lfa.partials != nullptr && bx == 7 && by == ny - 1) {
     __shared__ double s_red[4][LOSS_SUMS];
     loss_final_block(lfa, s_red);
   }
   if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
-  dilate_depth_cuts(cd, (int)((blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x),
-                    (int)(gridDim.x * gridDim.y * blockDim.x));
+  dilate_depth_cuts(cd, (int)((by * 8 + bx) * 256 + threadIdx.x),
+                    (int)(8 * ny * 256));
   // the forward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && counters[8] != 0) {
+  if (bx == 0 && by == 0 && threadIdx.x == 0 && counters[8] != 0) {
     if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
     if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  } else if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && counters[9] != 0) {
+  } else if (bx == 0 && by == 0 && threadIdx.x == 0 && counters[9] != 0) {
     // a tile's depth cut-off may have hidden contributions (OLSR_STATUS_CUT_MISS); an overflow (1) stays
     if (num_rendered_dev != nullptr && num_rendered_dev[1] == 0) num_rendered_dev[1] = 3;
   }
-  const int x = blockIdx.x;  // XCD
+  const int x = bx;  // XCD
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   const int len = q + (x < r ? 1 : 0);
   const int len64 = (len + 63) & ~63;
   u32 sum0 = 0, sum1 = 0;
-  const bool summing = mailbox != nullptr && blockIdx.y == 0;  // the first block of each chunk also sums its two planes
-  for (int j = threadIdx.x; j < len64; j += blockDim.x) {
+  const bool summing = mailbox != nullptr && by == 0;  // the first block of each chunk also sums its two planes
+  for (int j = threadIdx.x; j < len64; j += 256) {
     const u32 w = (j < len) ? work[start + j] : 0u;
     s_work[j] = w;
     sum0 += w;
     if (summing && j < len) sum1 += work[ntiles + start + j];
   }
-  if (summing) sum_and_post_live_rows(sum0, sum1, gridDim.x, live_rows, mailbox, seq);  // (block-uniform; syncs inside)
+  if (summing) sum_and_post_live_rows(sum0, sum1, 8u, live_rows, mailbox, seq);  // (block-uniform; syncs inside)
   if (len == 0) return;  // (fewer than 8 tiles: this XCD's chunk is empty)
   __syncthreads();
   // 16 tiles per block, 16 lanes per tile: lane s of a tile's row compares against the entries j = 4 s + 64 k ..
   // (one 16-byte LDS read each), the 16 partial ranks are summed inside the row with DPP rotations.  The zero padding
   // never outranks anything (a padded slot j >= len has weight 0 <= wi and j > i).
-  const int i = blockIdx.y * 16 + (threadIdx.x >> 4);  // tile (clamped: every lane takes part in the row sum)
+  const int i = by * 16 + (threadIdx.x >> 4);  // tile (clamped: every lane takes part in the row sum)
   const int sub = threadIdx.x & 15;
   const int ii = i < len ? i : len - 1;
   const u32 wi = s_work[ii];
@@ -1024,6 +1078,24 @@ __global__ __launch_bounds__(256) void tile_order_kernel(const u32* __restrict__
     order[start + rk] = (u32)(start + i);
     if (order_copy != nullptr) order_copy[start + rk] = (u32)(start + i);  // the caller's hint for its next frame
   }
+}
+
+__global__ __launch_bounds__(256) void tile_order_kernel(const TileOrderArgs ta) {
+  tile_order_block(ta, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// The forward's last launch when its caller has announced the backward's row capacity (olsr_scene.backward_row_capacity): the
+// tile order and the row compaction depend on the forward composite only, not on each other — one launch, the 8 ny light
+// tile-order blocks first (the first four waves of a block; the others leave at once), then the row compaction's blocks.
+__global__ __launch_bounds__(ROWS_THREADS) void forward_tail_kernel(const TileOrderArgs ta, const int ny,
+                                                                    const RowCompactionArgs ra, const u32 nb_rows) {
+  const int nb_order = 8 * ny;
+  if ((int)blockIdx.x < nb_order) {
+    if (threadIdx.x >= 256) return;  // (wave-uniform; a finished wave no longer counts at the block's barriers)
+    tile_order_block(ta, (int)blockIdx.x & 7, (int)blockIdx.x >> 3, ny);
+    return;
+  }
+  row_compaction_block(ra, nb_rows);
 }
 
 // images beyond ~120 k tiles (8K x 8K): a chunk no longer fits the LDS rank sort; keep the natural order
@@ -1058,19 +1130,34 @@ __global__ __launch_bounds__(256) void tile_order_identity_kernel(const u32* __r
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
                        int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, float* depth_cut,
-                       int gx, int gy, const LossFinalArgs& loss_final, hipStream_t st) {
+                       int gx, int gy, const LossFinalArgs& loss_final, const ForwardTailRows* rows, hipStream_t st) {
   if (ntiles <= 0) return;
   const CutDilate cd{depth_cut, gx, gy};
   const int len = (ntiles >> 3) + 1;
   if (sizeof(u32) * (size_t)(len + 64) > 60 * 1024) {
+    if (rows != nullptr)  // (no merged form for the identity order: the compaction is its own launch, in front)
+      launch_row_compaction(rows->flags, rows->n_host, rows->n_dev, rows->packed_ref15, rows->rowbase, rows->row_status,
+                            rows->sync, rows->row_capacity, rows->counters, nullptr, st);
     tile_order_identity_kernel<<<(ntiles + 255) / 256, 256, 0, st>>>(tile_work, tile_order, order_copy, ntiles, live_rows,
                                                                      rows_mailbox, rows_seq, counters, num_rendered_dev,
                                                                      sticky_error, hint_slot, cd, loss_final);
     return;
   }
-  tile_order_kernel<<<dim3(8, (len + 15) / 16), 256, sizeof(u32) * (size_t)(len + 64), st>>>(
-      tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq, counters, num_rendered_dev, sticky_error,
-      hint_slot, cd, loss_final);
+  const TileOrderArgs ta{tile_work, tile_order, order_copy, ntiles, live_rows, rows_mailbox, rows_seq, counters,
+                         num_rendered_dev, sticky_error, hint_slot, cd, loss_final};
+  const int ny = (len + 15) / 16;
+  if (rows != nullptr) {
+    const int shift = rows->packed_ref15 ? 4 : 0;
+    const u32 mask = rows->packed_ref15 ? 3u : 15u;
+    const int64_t n_host = rows->n_host < 0 ? 0 : rows->n_host;
+    const int nb = (int)((n_host + 1 + ROWS_CHUNK - 1) / ROWS_CHUNK);
+    const RowCompactionArgs ra{rows->flags, n_host, rows->n_dev, shift, mask, rows->rowbase, rows->row_status, rows->sync,
+                               (long long)rows->row_capacity, rows->counters, nullptr,
+                               sort_knobs().spin_limit.load(std::memory_order_relaxed)};
+    forward_tail_kernel<<<8 * ny + nb, ROWS_THREADS, sizeof(u32) * (size_t)(len + 64), st>>>(ta, ny, ra, (u32)nb);
+    return;
+  }
+  tile_order_kernel<<<dim3(8, ny), 256, sizeof(u32) * (size_t)(len + 64), st>>>(ta);
 }
 
 }  // namespace olsr

@@ -926,8 +926,16 @@ __global__ __launch_bounds__(CH_THREADS) void pb_chain_kernel(
 constexpr int TAU_T = 256;
 __global__ __launch_bounds__(TAU_T) void tau_final_kernel(const float* __restrict__ partials, int nb,
                                                          float* __restrict__ out, const int32_t* __restrict__ counters,
-                                                         int32_t* __restrict__ status_dev, int32_t* sticky) {
+                                                         int32_t* __restrict__ status_dev, int32_t* sticky,
+                                                         int status_rows) {
   __shared__ float red[TAU_T / 64][6];
+  // rows compacted by the forward's last launch (olsr_scene.backward_row_capacity): what launch_row_compaction would have
+  // told the caller — {live rows, row / instance overflow}; a cut-off miss (counters[9], folded into counters[7]) is
+  // reported as 3 below
+  if (threadIdx.x == 0 && status_rows != 0 && status_dev != nullptr) {
+    status_dev[0] = counters[6];
+    status_dev[1] = (counters[7] != 0 && counters[9] == 0) ? 1 : 0;
+  }
   // the backward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
   if (threadIdx.x == 0 && counters[8] != 0) {
     if (status_dev != nullptr) status_dev[1] = 2;
@@ -997,9 +1005,11 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
 #endif
 #undef OLSR_PB_ARGS
   if (o.dL_dtau_sum)
-    tau_final_kernel<<<1, TAU_T, 0, st>>>(tau_partials, n_partials, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error);
+    tau_final_kernel<<<1, TAU_T, 0, st>>>(tau_partials, n_partials, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error,
+                                          o.status_rows ? 1 : 0);
   else if (o.status_dev || o.sticky_error)
-    tau_final_kernel<<<1, 64, 0, st>>>(tau_partials, 0, nullptr, g.counters, o.status_dev, o.sticky_error);
+    tau_final_kernel<<<1, 64, 0, st>>>(tau_partials, 0, nullptr, g.counters, o.status_dev, o.sticky_error,
+                                       o.status_rows ? 1 : 0);
 }
 
 void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,

@@ -671,9 +671,12 @@ void launch_render_forward(const olsr_scene& s, const FrameDims& d, const Geomet
     lfa = loss_final_args(reinterpret_cast<const float*>(lf.scratch), d.ntiles, p, lf.tracking != 0, lang_term, use_exposure,
                           lf.loss, lf.dL_dexposure);
   }
+  const ForwardTailRows rows{b.flags, rm.compact_rows_n, &g.counters[1], s.bwd_mode == OLSR_BWD_REFERENCE && s.tile == 15,
+                             b.rowbase, b.row_status, b.tickets + 8, s.backward_row_capacity, g.counters};
   launch_tile_order(im.tile_work, im.tile_order, tile_order_inout, d.ntiles, im.live_rows, rm.dev, rm.seq, g.counters,
                     num_rendered_dev, rm.sticky, rm.hint_slot,
-                    (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), d.gx, d.gy, lfa, st);
+                    (s.binning == OLSR_BINNING_ELLIPSE ? s.tile_depth_cut : nullptr), d.gx, d.gy, lfa,
+                    rm.compact_rows_n >= 0 ? &rows : nullptr, st);
 }
 #endif
 

@@ -108,6 +108,9 @@ int check_scene(const olsr_scene* s, bool backward) {
   if (s->shs && (s->M < (s->D + 1) * (s->D + 1))) return fail(OLSR_ERR_ARG, "shs holds fewer coefficients than the degree needs");
   if (s->F > 0 && !s->language_precomp) return fail(OLSR_ERR_ARG, "language_precomp is required when F > 0");
   if (backward && !s->projmatrix_raw) return fail(OLSR_ERR_ARG, "projmatrix_raw is required by backward");
+  if (s->backward_row_capacity < 0) return fail(OLSR_ERR_ARG, "backward_row_capacity must be >= 0");
+  if (s->backward_row_capacity > 0 && s->bwd_mode != OLSR_BWD_REFERENCE && s->bwd_mode != OLSR_BWD_EXACT)
+    return fail(OLSR_ERR_ARG, "backward_row_capacity needs a valid bwd_mode in the forward as well");
   return OLSR_OK;
 }
 
@@ -384,6 +387,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     g_rows_call.hint_slot = view_hints;
     tile_order_inout = view_hints + HINT_HDR;
   }
+  // the caller announced its backward's row capacity: the forward's last launch compacts the rows as well (include/olsr.h)
+  if (s.backward_row_capacity > 0 && s.P > 0 && bin_buf != nullptr) g_rows_call.compact_rows_n = n_host;
   stamp(st, 0);
   launch_render_forward(s, d, g, b, im, out_color, out_language, out_depth, out_opacity, n_touched, tile_order_inout,
                         num_rendered_dev, (s.P > 0) ? loss : nullptr, st);
@@ -708,11 +713,18 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   const ImageState im = ImageState::carve(const_cast<void*>(image_buffer), (size_t)d.W * d.H, (size_t)d.ntiles, ib);
   BinningState b = BinningState::carve(binning_buffer, (size_t)num_rendered, bb);
 
-  // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended
+  // compact the partial-gradient rows: one row per (instance, slot) pair the forward blended — unless the forward did
+  // (olsr_scene.backward_row_capacity: rowbase, counters[6] and counters[7] are in place, the backward's last kernel
+  // copies them to status_dev)
   const bool packed_ref15 = (s.bwd_mode == OLSR_BWD_REFERENCE && s.tile == 15);
-  launch_row_compaction(b.flags, num_rendered, &g.counters[1], packed_ref15, b.rowbase, b.row_status, b.tickets + 8,
-                        scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, status_dev, st);
-  STAGE("row_compaction");
+  const bool rows_compacted = s.backward_row_capacity > 0;
+  if (rows_compacted && (scratch_alloc || scratch_rows != s.backward_row_capacity))
+    return fail(OLSR_ERR_ARG, "backward_row_capacity: the backward needs a caller-owned scratch of exactly that many rows");
+  if (!rows_compacted) {
+    launch_row_compaction(b.flags, num_rendered, &g.counters[1], packed_ref15, b.rowbase, b.row_status, b.tickets + 8,
+                          scratch_alloc ? 0x7FFFFFFFLL : scratch_rows, g.counters, status_dev, st);
+    STAGE("row_compaction");
+  }
   if (scratch_alloc) {
     int32_t c3[3] = {0, 0, 0};  // {live rows, row / instance overflow, synchronisation error}
     HIP_TRY(hipMemcpyAsync(c3, &g.counters[6], 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -744,6 +756,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
     o.bucket_row_mask = reinterpret_cast<unsigned long long*>(bucket->row_mask);
   }
   o.status_dev = status_dev;
+  o.status_rows = rows_compacted;
   // (a caller that passes status_dev reads the report there; one that does not — the reference-shaped bindings — gets it
   //  from the library's next call)
   o.sticky_error = status_dev ? nullptr : sticky_sync_error_dev();

@@ -59,15 +59,29 @@ struct LossFinalArgs {
   float* d_exposure;       // written if use_exposure, zeroed if zero_exposure, may be null
   int use_exposure, zero_exposure;
 };
+// rows (may be null): the row compaction of launch_row_compaction in the same launch (forward_tail_kernel) — for a forward
+// whose caller announced the backward's row capacity (olsr_scene.backward_row_capacity); the backward then skips its own
+struct ForwardTailRows {
+  const uint8_t* flags;
+  int64_t n_host;
+  const int32_t* n_dev;
+  bool packed_ref15;
+  uint32_t* rowbase;
+  uint32_t* row_status;
+  uint32_t* sync;
+  int64_t row_capacity;
+  int32_t* counters;
+};
 void launch_tile_order(const uint32_t* tile_work, uint32_t* tile_order, uint32_t* order_copy, int ntiles,
                        uint32_t* live_rows, int32_t* rows_mailbox, int32_t rows_seq, const int32_t* counters,
                        int32_t* num_rendered_dev, int32_t* sticky_error, const uint32_t* hint_slot, float* depth_cut,
-                       int gx, int gy, const LossFinalArgs& loss_final, hipStream_t st);
+                       int gx, int gy, const LossFinalArgs& loss_final, const ForwardTailRows* rows, hipStream_t st);
 struct RowsMailbox {  // set by olsr_forward for the duration of one call (thread-local in olsr_api.hip)
   int32_t* dev = nullptr;
   int32_t seq = 0;
   int32_t* sticky = nullptr;  // device view of the process-wide "a frame had a synchronisation error" host word (may be null)
   const uint32_t* hint_slot = nullptr;  // word 0 = which of the stream's per-view tile orders this frame uses (olsr_api.hip)
+  int64_t compact_rows_n = -1;  // >= 0: the forward's last launch also compacts the backward's rows (the instance capacity)
 };
 RowsMailbox& rows_mailbox_of_this_call();
 // ranges must have been zeroed (launch_instance_offsets); also clears flags[0, n)
@@ -146,6 +160,7 @@ struct GradOut {
   unsigned long long* bucket_row_mask = nullptr;  // olsr_grad_bucket.row_mask (include/olsr.h)
   int32_t* status_dev = nullptr;  // olsr_backward's {L, overflow}: the last kernel raises [1] to 2 on a synchronisation error
   int32_t* sticky_error = nullptr;  // ... and sets this mapped host word (RowsMailbox::sticky), if there is one
+  bool status_rows = false;  // the rows were compacted by the forward: the last kernel also writes status_dev = {L, overflow}
 };
 // F_rows: language channels of `rows` (see above); with F_rows == 0 < s.F the language gradients are written as zeros
 void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,

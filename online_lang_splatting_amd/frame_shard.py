@@ -18,6 +18,7 @@ Two things the reference does not have:
   gaussian_model.py:965-969).  Pose gradients stay on the owning rank.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Sequence
 
@@ -512,7 +513,7 @@ class RasterWorkspace:
     """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
 
     def __init__(self, P, W, H, F, M, capacity, device, tile=15, bwd_mode=_abi.BWD_REFERENCE, row_capacity=None,
-                 binning=_abi.BINNING_ELLIPSE, flags=0, depth_cut=False):
+                 binning=_abi.BINNING_ELLIPSE, flags=0, depth_cut=False, rows_in_forward=None):
         self.P, self.W, self.H, self.F, self.M = int(P), int(W), int(H), int(F), int(M)
         self.capacity, self.tile, self.bwd_mode = int(capacity), int(tile), int(bwd_mode)
         self.binning_mode = int(binning)
@@ -520,6 +521,16 @@ class RasterWorkspace:
         # rows of the backward scratch: live (instance, slot) pairs, at most 4 per instance; one per
         # instance covers ordinary scenes several times over (config 3 needs 0.24), overflow is reported
         self.row_capacity = int(row_capacity) if row_capacity is not None else self.capacity
+        # the forward's last launch also compacts the backward's rows (olsr_scene.backward_row_capacity, include/olsr.h): one
+        # launch less per frame; False keeps the compaction in the backward (a forward that is never followed by one)
+        # None: on for a workspace that renders alone (isolated frame + 0.7 %, tracking iteration - 1.5 %), off with
+        # OLSR_FLAG_FRAMES_IN_FLIGHT: the merged launch is made of sixteen-wave blocks, and beside another lane's composite those
+        # are placed late — the tile order's light blocks too, which the separate launch starts as four waves (measured: headline
+        # - 1 %, 12-view mapping iteration - 1 %).  OLSR_ROWS_IN_FORWARD=0 / 1 overrides (the A/B switch of the measurement).
+        if rows_in_forward is None:
+            env = os.environ.get("OLSR_ROWS_IN_FORWARD")
+            rows_in_forward = (env != "0") if env is not None else not (self.flags & _abi.FLAG_FRAMES_IN_FLIGHT)
+        self.rows_in_forward = bool(rows_in_forward) and self.row_capacity > 0
         self.device = torch.device(device)
         L = lib()
         u8 = dict(dtype=torch.uint8, device=self.device)
@@ -581,7 +592,8 @@ class RasterWorkspace:
             means3D=means3D, shs=shs,
             colors_precomp=colors_precomp, language_precomp=language, opacities=opacities, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix,
-            projmatrix_raw=projmatrix_raw, cam_pos=campos, tile_depth_cut=self._depth_cut_buf)
+            projmatrix_raw=projmatrix_raw, cam_pos=campos, tile_depth_cut=self._depth_cut_buf,
+            backward_row_capacity=self.row_capacity if self.rows_in_forward else 0)
 
     def forward(self):
         o = self.out

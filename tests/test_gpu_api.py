@@ -882,7 +882,7 @@ def _bwd_args(sc, fwd, dev, seed):
 
 
 # ---- synchronisation errors are reported, never silent -----------------------------------------
-def _sync_error_workspace(dev, P=20000, W=320, H=240, F=15):
+def _sync_error_workspace(dev, P=20000, W=320, H=240, F=15, **ws_kw):
     from online_lang_splatting_amd.frame_shard import RasterWorkspace
     from online_lang_splatting_amd.scene import make_scene
     sc = make_scene(P, W, H, F, seed=123)
@@ -892,7 +892,7 @@ def _sync_error_workspace(dev, P=20000, W=320, H=240, F=15):
     c = dict(viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
              projmatrix_raw=cam.projection_matrix.to(dev), campos=cam.camera_center.to(dev), tanfovx=cam.tanfovx,
              tanfovy=cam.tanfovy)
-    ws = RasterWorkspace(P, W, H, F, sc.shs.shape[1], 600000, dev)
+    ws = RasterWorkspace(P, W, H, F, sc.shs.shape[1], 600000, dev, **ws_kw)
     ws.set_scene(sh_degree=sc.sh_degree, **c, **g)
     cot = [t.to(dev) for t in sc.cotangents(1)]
     return sc, ws, cot
@@ -905,7 +905,9 @@ def test_corrupted_row_compaction_ticket_is_reported_and_gradients_are_zero(hip)
     OLSR_STATUS_SYNC_ERROR on the sync-free path (zero gradients), OLSR_ERR_DEVICE from the synchronising olsr_backward."""
     from online_lang_splatting_amd._lib import lib
     dev = torch.device(DEV)
-    sc, ws, cot = _sync_error_workspace(dev)
+    # (rows_in_forward=False: the compaction is the backward's own first launch, so a word corrupted between the forward and
+    #  the backward reaches it; the default workspace compacts in the forward's last launch, covered below)
+    sc, ws, cot = _sync_error_workspace(dev, rows_in_forward=False)
     L = lib()
     L.olsr_debug_sync_fault(-1, 2000)   # give up after 2000 polls instead of 2^22 (keeps the test short)
     try:
@@ -930,6 +932,52 @@ def test_corrupted_row_compaction_ticket_is_reported_and_gradients_are_zero(hip)
             assert torch.equal(again[k], good[k]), k
     finally:
         L.olsr_debug_sync_fault(0, 0)
+
+
+@pytest.mark.parametrize("tile,mode", [(15, 0), (15, 1), (16, 0)])
+def test_rows_compacted_by_the_forwards_last_launch(hip, tile, mode):
+    """olsr_scene.backward_row_capacity (RasterWorkspace(rows_in_forward=True), the default): the forward's last launch is the
+    tile order AND the row compaction; the backward skips its own.  Gradients, the status words and a repeated backward on the
+    same forward are bit-identical to the workspace whose backward compacts; a too-small row capacity is reported the same
+    way; a backward whose scratch does not match the announced capacity is refused."""
+    from online_lang_splatting_amd._lib import lib
+    dev = torch.device(DEV)
+    res = {}
+    for rif in (True, False):
+        sc, ws, cot = _sync_error_workspace(dev, P=30000, tile=tile, bwd_mode=mode, rows_in_forward=rif)
+        ws.forward()
+        g1 = {k: v.clone() for k, v in ws.backward(*cot).items()}
+        st1 = ws.backward_status()
+        g2 = {k: v.clone() for k, v in ws.backward(*cot).items()}   # the same forward, once more
+        assert ws.backward_status() == st1
+        for k in g1:
+            assert torch.equal(g1[k], g2[k]), (rif, k)
+        ws.forward()                                                  # and a second frame on the same buffers
+        g3 = ws.backward(*cot)
+        for k in g1:
+            assert torch.equal(g1[k], g3[k]), (rif, k)
+        res[rif] = (g1, st1, ws)
+    assert res[True][1] == res[False][1] and res[True][1][0] > 0 and not res[True][1][1]
+    for k in res[True][0]:
+        assert torch.equal(res[True][0][k], res[False][0][k]), k
+    assert float(res[True][0]["dL_dmeans3D"].abs().max()) > 0
+    L_rows = res[True][1][0]
+    # too few rows: reported as an overflow, zero gradients
+    sc, tight, cot = _sync_error_workspace(dev, P=30000, tile=tile, bwd_mode=mode, row_capacity=L_rows - 1)
+    tight.forward()
+    gz = tight.backward(*cot)
+    assert tight.backward_status() == (L_rows, True)
+    assert all(float(v.abs().max()) == 0.0 for v in gz.values())
+    # the backward must be given the scratch the forward was told about
+    ws = res[True][2]
+    ws.forward()
+    ws.row_capacity -= 1
+    try:
+        with pytest.raises(RuntimeError, match="backward_row_capacity"):
+            ws.backward(*cot)
+    finally:
+        ws.row_capacity += 1
+    assert lib().olsr_last_error() is not None
 
 
 @pytest.mark.parametrize("which,bit", [("depth sort", 1), ("tile sort", 2)])
