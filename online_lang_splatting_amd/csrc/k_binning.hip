@@ -759,7 +759,7 @@ __device__ __forceinline__ void load_popc16(const uint8_t* __restrict__ flags, i
   for (int k = 0; k < 16; ++k) v[k] = (u32)__popc((w4[k >> 2] >> (8 * (k & 3) + shift)) & mask);
 }
 
-constexpr int ROWS_THREADS = 1024;
+constexpr int ROWS_THREADS = OLSR_ROWS_THREADS;
 static_assert(ROWS_CHUNK == ROWS_THREADS * 16, "one 16-byte load of flags per thread");
 
 struct RowCompactionArgs {

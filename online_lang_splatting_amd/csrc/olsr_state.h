@@ -119,7 +119,10 @@ inline size_t fused_status_words(long long n, int passes) {
 }
 // single-pass scans (emission offsets, row compaction): elements per 1024-thread block
 constexpr int EMIT_CHUNK = 1024;
-constexpr int ROWS_CHUNK = 16384;
+#ifndef OLSR_ROWS_THREADS
+#define OLSR_ROWS_THREADS 1024  // threads of a row-compaction block (16 instances each)
+#endif
+constexpr int ROWS_CHUNK = 16 * OLSR_ROWS_THREADS;
 
 struct Carver {
   char* base;
