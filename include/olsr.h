@@ -169,7 +169,26 @@ typedef struct olsr_scene {
                           * olsr_backward given a scene with the same non-zero value skips its own compaction launch: one launch
                           * and ~8 us less per frame.  Both calls must see the same value, bwd_mode and tile; the backward
                           * verifies scratch_rows == backward_row_capacity (OLSR_ERR_ARG) and needs scratch_alloc == NULL. */
+  uint32_t *depth_order_carry; /* NULL (the default), or device uint32[P], in/out — see "Carried depth order" below.  Used by
+                          * olsr_forward_async / olsr_forward_async_loss only. */
 } olsr_scene;
+
+/* Carried depth order (round 6; a performance hint for SEQUENCES of nearly identical views of the same Gaussians: the ~100
+ * dependent tracking iterations of a frame, utils/slam_frontend.py:163-277, and the ~150 mapping iterations over one window of
+ * keyframes, utils/slam_backend.py:499-670 — one array per VIEW).  The depth sort (hist + four radix passes: five dependent
+ * launches, ~70 us whatever it sorts) orders the P Gaussians by (depth bits, index); between two iterations of such a loop
+ * the pose or the parameters move by a step of the optimiser and the order changes only locally.  With
+ * scene->depth_order_carry the forward REPAIRS the order the previous forward left in the array instead of sorting from
+ * scratch: two launches of independent workgroups (no look-back, no ticket) merge-sort windows of 2048 ranks of the old
+ * order under the new keys, first aligned, then offset by half a window, which is a complete sort whenever no Gaussian moved
+ * by more than 1024 ranks; the second launch proves the result — every adjacent pair of (depth bits, index) strictly
+ * ascending, which also proves that the array is a permutation — and otherwise raises a device-side flag that makes the
+ * radix passes, which are enqueued behind the repair in any case, run instead of returning at once.  The lists are therefore
+ * ALWAYS the reference's, bit for bit, whatever the array held on entry (zeros, another view's order, garbage: the frame then
+ * simply pays for both); on exit the array holds this frame's order.  Sort keys are defined for all P Gaussians (the view-space
+ * depth also for Gaussians outside the frustum, a monotone function of it behind the near plane), so that the order is a
+ * property of the pose and not of what is visible.  olsr_forward (the synchronising entry) ignores the field, and so do
+ * sorts that take the multi-kernel passes (more than 67 M Gaussians). */
 
 /* Per-tile depth cut-offs (round 4; an opt-in for SEQUENCES of nearly identical views: the ~100 tracking iterations of a
  * frame).  The forward composite reads a tile's depth-sorted list only until every pixel of the tile is saturated — at config 3

@@ -68,6 +68,7 @@ class OlsrScene(C.Structure):
         ("flags", C.c_int32),
         ("tile_depth_cut", _fp),
         ("backward_row_capacity", C.c_int64),
+        ("depth_order_carry", _fp),
     ]
 
 
@@ -120,7 +121,7 @@ def _ptr(t):
 def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode, tan_fovx, tan_fovy,
                scale_modifier, binning=BINNING_RECT, activations=0, flags=0, background, means3D, shs, colors_precomp, language_precomp, opacities,
                scales, rotations, cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, cam_pos, tile_depth_cut=None,
-               backward_row_capacity=0):
+               backward_row_capacity=0, depth_order_carry=None):
     s = OlsrScene()
     s.P, s.D, s.M, s.F = int(P), int(D), int(M), int(F)
     s.width, s.height, s.tile = int(width), int(height), int(tile)
@@ -144,4 +145,5 @@ def make_scene(*, P, D, M, F, width, height, tile, prefiltered, debug, bwd_mode,
     s.cam_pos = _ptr(cam_pos)
     s.tile_depth_cut = _ptr(tile_depth_cut)
     s.backward_row_capacity = int(backward_row_capacity)
+    s.depth_order_carry = _ptr(depth_order_carry)
     return s

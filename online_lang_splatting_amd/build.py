@@ -25,6 +25,7 @@ UNITS = [
     ("k_preprocess.hip", "k_preprocess.o", []),
     ("k_binning.hip", "k_binning.o", []),
     ("k_sort.hip", "k_sort.o", []),
+    ("k_order_carry.hip", "k_order_carry.o", []),
     ("k_render_fwd.hip", "k_render_fwd.o", ["-DOLSR_FWD_TU_LOSS=0"]),
     ("k_render_fwd.hip", "k_render_fwd_loss.o", ["-DOLSR_FWD_TU_LOSS=1"]),
     ("k_render_bwd.hip", "k_render_bwd_ref.o", ["-DOLSR_BWD_TU_MODE=0"]),

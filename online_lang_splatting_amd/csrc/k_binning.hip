@@ -426,11 +426,17 @@ __device__ __forceinline__ u32 block_list_base(u32 cnt, int32_t* counter, u32* s
 
 __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
     int P, const u32* __restrict__ order, const u32* __restrict__ inst_count, int32_t* __restrict__ counters,
-    const u32* __restrict__ block_totals, uint4* __restrict__ bin_sync, int bin_sync_quads,
-    u32* __restrict__ rank_off, u32* __restrict__ win_start, u32* __restrict__ inst_start,
-    uint4* __restrict__ big_list, u32 eb_shift) {
-  __shared__ u32 s_wsum[EO_T / 64 + 1];
+    const u64* __restrict__ block_totals_sort, uint4* __restrict__ bin_sync, int bin_sync_quads,
+    u32* __restrict__ c_off, u32* __restrict__ c_gid, u32* __restrict__ win_start, u32* __restrict__ inst_start,
+    uint4* __restrict__ big_list, u32 eb_shift, const u64* __restrict__ alt_totals, const u32* __restrict__ alt_unless) {
+  __shared__ u64 s_wsum[EO_T / 64 + 1];
+  __shared__ u32 s_lsum[EO_T / 64 + 1];
   __shared__ u32 s_lbase;
+  // (the carried depth order, k_order_carry.hip: a repaired order comes with its own block totals; the radix passes' totals
+  //  count when the repair missed.  Uniform.)
+  const u64* __restrict__ block_totals =
+      (alt_totals != nullptr && __hip_atomic_load(alt_unless, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ? alt_totals
+                                                                                                                 : block_totals_sort;
   const u32 eb_out = 1u << eb_shift;  // output window of an emission block (a power of two)
   // the words the tile sort and the row compaction synchronise through live in the binning buffer, which exists only
   // from here on (the drop-in entry allocates it after the instance count is known)
@@ -449,36 +455,42 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
 #pragma unroll
     for (int k = 0; k < EO_PER; ++k) g[k] = (r0 + k < P) ? order[r0 + k] : 0u;
   }
-  u32 mine = 0;
+  // (instances | emitting Gaussians << 40, like the block totals: ONE scan yields the first instance of every rank and its
+  //  place among the ranks that emit anything)
+  u64 mine = 0;
 #pragma unroll
   for (int k = 0; k < EO_PER; ++k) {
     n[k] = (r0 + k < P) ? inst_count[g[k]] : 0u;  // 0 when culled
-    mine += n[k];
+    mine += emit_total_pack(n[k]);
   }
-  u32 incl = mine;
+  u64 incl = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const u32 o = __shfl_up(incl, d);
+    const u64 o = __shfl_up(incl, d);
     if (lane >= d) incl += o;
   }
   if (lane == 63) s_wsum[w] = incl;
   __syncthreads();
-  u32 wbase = 0;
+  u64 wbase = 0;
 #pragma unroll
-  for (int i = 0; i < EO_T / 64; ++i) wbase += (i < w) ? s_wsum[i] : 0u;
+  for (int i = 0; i < EO_T / 64; ++i) wbase += (i < w) ? s_wsum[i] : 0ull;
   __syncthreads();
-  // first instance of this block = instances of all earlier blocks (left behind by the depth sort's last pass)
-  u32 pre = 0;
+  // first instance (and first emitting rank) of this block = the totals of all earlier blocks (left behind by the depth
+  // sort's last pass, or by the repair of a carried order)
+  u64 pre = 0;
   for (u32 j = threadIdx.x; j < b; j += EO_T) pre += block_totals[j];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) pre += __shfl_xor(pre, m);
   if (lane == 0) s_wsum[w] = pre;
   __syncthreads();
-  u32 base = 0;
+  u64 base = 0;
 #pragma unroll
   for (int i = 0; i < EO_T / 64; ++i) base += s_wsum[i];
+  const u64 first = base + wbase + incl - mine;
+  constexpr u64 LOW = (1ull << EMIT_TOTAL_SHIFT) - 1ull;
   u32 off[EO_PER];
-  u32 run = base + wbase + incl - mine;
+  u32 run = (u32)(first & LOW);
+  u32 ci = (u32)(first >> EMIT_TOTAL_SHIFT);  // this thread's first rank among the emitting ones
   u32 nbig = 0, nmid = 0;
 #pragma unroll
   for (int k = 0; k < EO_PER; ++k) {
@@ -487,28 +499,30 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
     nbig += (n[k] > EMIT_BIG) ? 1u : 0u;
     nmid += (n[k] > OLSR_MID_FOOTPRINT && n[k] <= EMIT_BIG) ? 1u : 0u;
   }
-  if (r0 + EO_PER <= P) {
-    *reinterpret_cast<uint4*>(rank_off + r0) = make_uint4(off[0], off[1], off[2], off[3]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < EO_PER; ++k)
-      if (r0 + k < P) rank_off[r0 + k] = off[k];
-  }
+  // The emission walks the ranks that EMIT: {first instance, Gaussian} of the j-th of them, and per output window the one
+  // that owns its first instance.  (Round 6: with a sort key for every Gaussian the silent ones stand between the emitting
+  // ones instead of behind them — a view that sees a fifth of the map — and emit_balanced_kernel's batches of 256 ranks
+  // were four fifths empty: 22 -> 77 us on the room map.  Compacted, a batch is 256 emitting Gaussians whatever the view sees.)
 #pragma unroll
   for (int k = 0; k < EO_PER; ++k) {
     if (n[k] > 0) {
       inst_start[g[k]] = off[k];
+      c_off[ci] = off[k];
+      c_gid[ci] = g[k];
       // this rank owns the first instance of every output window [j * EB_OUT, ...) that starts inside its run
       for (u32 j = (off[k] + eb_out - 1u) >> eb_shift; (j << eb_shift) < off[k] + n[k]; ++j)
-        win_start[j] = (u32)(r0 + k);
+        win_start[j] = ci;
+      ++ci;
     }
   }
+  // (the last thread of the last block has seen every rank: the number of emitting Gaussians)
+  if (b == gridDim.x - 1 && threadIdx.x == EO_T - 1) counters[10] = (int32_t)ci;
   // the two work lists of the backward's row sums: big footprints from the front, medium ones from the back
-  u32 slot = block_list_base(nbig, &counters[5], s_wsum, &s_lbase);
+  u32 slot = block_list_base(nbig, &counters[5], s_lsum, &s_lbase);
 #pragma unroll
   for (int k = 0; k < EO_PER; ++k)
     if (n[k] > EMIT_BIG) big_list[slot++] = make_uint4(g[k], off[k], n[k], 0u);
-  u32 mslot = block_list_base(nmid, &counters[4], s_wsum, &s_lbase);
+  u32 mslot = block_list_base(nmid, &counters[4], s_lsum, &s_lbase);
 #pragma unroll
   for (int k = 0; k < EO_PER; ++k)
     if (n[k] > OLSR_MID_FOOTPRINT && n[k] <= EMIT_BIG) big_list[(u32)P - 1u - (mslot++)] = make_uint4(g[k], off[k], n[k], 0u);
@@ -546,9 +560,11 @@ struct EbGauss {
 
 template <int TILE>
 __global__ __launch_bounds__(EB_T) void emit_balanced_kernel(
-    int P, const u32* __restrict__ order, const u32* __restrict__ rank_off, const u32* __restrict__ win_start,
+    const u32* __restrict__ order, const u32* __restrict__ rank_off, const u32* __restrict__ win_start,
     const float4* __restrict__ emit_rec, int ellipse, int W, int H, int gx, const int32_t* __restrict__ counters,
     u32* __restrict__ keys, u32* __restrict__ inst_gid, u32 eb_out) {
+  // (order / rank_off: the Gaussian and the first instance of the j-th EMITTING depth rank, j < P = counters[10] —
+  //  emit_offsets_kernel's compacted list; "rank" below means a position in that list)
   __shared__ EbGauss s_gs[EB_T];
   __shared__ u32 s_g[EB_T], s_first[EB_T], s_rowoff[EB_T];
   __shared__ uint8_t s_owner[EB_ROWCAP];
@@ -556,6 +572,7 @@ __global__ __launch_bounds__(EB_T) void emit_balanced_kernel(
   __shared__ u32 s_flag;
   if (counters[2] != 0 || counters[8] != 0) return;
   const u32 R = (u32)counters[1];
+  const int P = counters[10];
   const u32 o0 = blockIdx.x * eb_out;
   if (o0 >= R) return;
   const u32 o1 = min(o0 + eb_out, R);
@@ -684,55 +701,60 @@ __global__ __launch_bounds__(EB_T) void emit_balanced_kernel(
 // per-emission-block instance totals for a depth order that did not come from the fused sort (multi-kernel passes)
 __global__ __launch_bounds__(EMIT_THREADS) void emit_totals_kernel(int P, const u32* __restrict__ order,
                                                                    const u32* __restrict__ inst_count,
-                                                                   u32* __restrict__ totals) {
-  __shared__ u32 s_w[EMIT_THREADS / 64];
+                                                                   u64* __restrict__ totals) {
+  __shared__ u64 s_w[EMIT_THREADS / 64];
   const int r = (int)(blockIdx.x * EMIT_THREADS + threadIdx.x);
-  u32 n = (r < P) ? inst_count[order[r]] : 0u;
+  u64 n = (r < P) ? emit_total_pack(inst_count[order[r]]) : 0ull;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) n += __shfl_xor(n, m);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
   __syncthreads();
   if (threadIdx.x == 0) {
-    u32 t = 0;
+    u64 t = 0;
     for (int i = 0; i < EMIT_THREADS / 64; ++i) t += s_w[i];
     totals[blockIdx.x] = t;
   }
 }
 void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st) {
   if (P <= 0) return;
-  emit_totals_kernel<<<(P + EMIT_THREADS - 1) / EMIT_THREADS, EMIT_THREADS, 0, st>>>(P, order, inst_count, emit_totals);
+  emit_totals_kernel<<<(P + EMIT_THREADS - 1) / EMIT_THREADS, EMIT_THREADS, 0, st>>>(P, order, inst_count,
+                                                                                     reinterpret_cast<u64*>(emit_totals));
 }
 
 template <int TILE>
 static void launch_emit_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                          int64_t bin_sync_words, int64_t n_host, hipStream_t st) {
+                          int64_t bin_sync_words, int64_t n_host, const u32* order, const u32* alt_totals,
+                          const u32* alt_unless, hipStream_t st) {
   const int nb = (s.P + EMIT_THREADS - 1) / EMIT_THREADS;
   const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
   const u32* totals = g.emit_status;  // per-block instance totals, accumulated by the depth sort's last pass
   uint4* bsync = reinterpret_cast<uint4*>(b.sync_words);
   const int quads = (int)((bin_sync_words + 3) / 4);
-  u32* rank_off = g.key_b;   // the depth keys are dead once the order exists
+  u32* rank_off = g.key_b;   // the depth keys are dead once the order exists: first instance of the j-th emitting rank ...
+  u32* rank_gid = g.val_b;   // ... and its Gaussian (the sort's / the repair's second value buffer is dead as well)
   u32* win_start = b.key_b;  // the tile sort's second key buffer is not in use yet
   // Output window of an emission block.  With per-tile depth cut-offs most depth ranks emit nothing: a window's instances
   // come from four times as many ranks, walked in serial batches of 256 — a quarter of the window keeps the per-block
   // chain where it was (emit_balanced 38.9 -> see profiles/r4_experiments.json).
   const bool cut_mode = ellipse && s.tile_depth_cut != nullptr;
   const int eb_out = cut_mode ? EB_OUT / 4 : EB_OUT;
-  emit_offsets_kernel<<<nb, EO_T, 0, st>>>(s.P, g.depth_order, g.tiles_touched, g.counters, totals, bsync, quads,
-                                                   rank_off, win_start, g.inst_start, g.big_list,
-                                                   (u32)__builtin_ctz((unsigned)eb_out));
+  emit_offsets_kernel<<<nb, EO_T, 0, st>>>(s.P, order, g.tiles_touched, g.counters, reinterpret_cast<const u64*>(totals), bsync,
+                                           quads, rank_off, rank_gid, win_start, g.inst_start, g.big_list,
+                                           (u32)__builtin_ctz((unsigned)eb_out), reinterpret_cast<const u64*>(alt_totals),
+                                           alt_unless);
   const int64_t nblk = (n_host + eb_out - 1) / eb_out;
   if (nblk > 0)
-    emit_balanced_kernel<TILE><<<(int)nblk, EB_T, 0, st>>>(s.P, g.depth_order, rank_off, win_start, g.emit_rec,
+    emit_balanced_kernel<TILE><<<(int)nblk, EB_T, 0, st>>>(rank_gid, rank_off, win_start, g.emit_rec,
                                                            ellipse, d.W, d.H, d.gx, g.counters, b.key_a, b.inst_gid,
                                                            (u32)eb_out);
 }
 
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                 int64_t bin_sync_words, int64_t n_host, hipStream_t st) {
+                 int64_t bin_sync_words, int64_t n_host, const uint32_t* order, const uint32_t* alt_totals,
+                 const uint32_t* alt_unless, hipStream_t st) {
   if (s.P <= 0) return;
-  if (d.tile == 15) launch_emit_t<15>(s, d, g, b, bin_sync_words, n_host, st);
-  else launch_emit_t<16>(s, d, g, b, bin_sync_words, n_host, st);
+  if (d.tile == 15) launch_emit_t<15>(s, d, g, b, bin_sync_words, n_host, order, alt_totals, alt_unless, st);
+  else launch_emit_t<16>(s, d, g, b, bin_sync_words, n_host, order, alt_totals, alt_unless, st);
 }
 
 // ------------------------------------------------------------------------------- row compaction

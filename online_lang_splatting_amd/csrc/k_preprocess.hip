@@ -3,8 +3,8 @@
 // Replaces preprocessCUDA / languagePreprocessCUDA (CR/forward.cu:158-259, 262-371) and
 // checkFrustum (CR/rasterizer_impl.cu:54-66).  One lane per Gaussian; the 4x4 matrices are
 // wave-uniform and arrive through the scalar cache.  Besides the reference's outputs the
-// kernel seeds the depth sort: key = depth bits (0xFFFFFFFF for culled Gaussians, which
-// emit no instances anyway), value = Gaussian index.
+// kernel seeds the depth sort: key = depth bits (for every Gaussian, culled or not: see
+// preprocess_one), value = Gaussian index.
 #include "olsr_device.h"
 #include "olsr_kernels.h"
 
@@ -167,13 +167,19 @@ __device__ __forceinline__ u32 preprocess_one(
   pend.nrows = 0;
   n_touched[idx] = 0;  // the forward composite counts into it with integer atomics
   radii[idx] = 0;
-  sort_key[idx] = 0xFFFFFFFFu;
   // (the emission record of a Gaussian without instances is never read — the emission goes by tiles_touched — so culled
   //  Gaussians leave theirs untouched)
 
   // in_frustum, CR/auxiliary.h:139-164
   const f3 p_orig = {orig_points[3 * (size_t)idx], orig_points[3 * (size_t)idx + 1], orig_points[3 * (size_t)idx + 2]};
   const f3 p_view = transformPoint4x3(p_orig, viewmatrix);
+  // The depth-sort key is defined for EVERY Gaussian (round 6): the view-space depth's bits whenever z > 0.2 — also for a
+  // Gaussian the tests below cull —, and a monotone function of z below bits(0.2) behind the near plane.  Only Gaussians that
+  // emit instances matter to the lists, and those have z > 0.2 and the reference's key (CR/forward.cu:247, duplicateWithKeys);
+  // the others may stand anywhere.  Ordering them by depth as well makes the order a function of the pose alone, not of what
+  // is visible, so that the order of one frame is nearly the order of the next (k_order_carry.hip: a Gaussian that enters the
+  // frustum must not jump from the tail of the order into its middle).  Keys are never 0 (the repair's padding lies below them).
+  sort_key[idx] = (p_view.z <= 0.2f) ? 0x3E4CCCCCu - min(f2bits(0.2f - p_view.z) >> 1, 0x3E4CCCCBu) : f2bits(p_view.z);
   if (p_view.z <= 0.2f) {
     if (prefiltered) {
       printf("Point is filtered although prefiltered is set. This shouldn't happen!");
@@ -242,7 +248,6 @@ __device__ __forceinline__ u32 preprocess_one(
   means2D[2 * (size_t)idx + 1] = pix_y;
   float4 co = make_float4(conic.x, conic.y, conic.z, opacity);
   reinterpret_cast<float4*>(conic_opacity)[idx] = co;
-  sort_key[idx] = f2bits(p_view.z);
 
   u32 count = area;
   float t2 = 0.f;

@@ -196,10 +196,19 @@ template <int T>
 __global__ __launch_bounds__(T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int passes, int db,
                                                          u32* __restrict__ hist, FrameHousekeeping house,
-                                                         int do_house) {
+                                                         int do_house, const u32* __restrict__ run_if) {
   __shared__ u32 h[4][256];
   __shared__ u32 s_red[2][T / 64];
   const int tid = threadIdx.x;
+  // run_if (may be null): the sort is only needed when *run_if != 0 — the carried depth order could not be repaired
+  // (k_order_carry.hip).  The frame's bookkeeping of block 0 happens either way.
+  if (run_if != nullptr && __hip_atomic_load(run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    if (do_house && blockIdx.x == 0) {
+      if (house.hint_base != nullptr && (tid >> 6) == 1) hint_pick_wave(house.hint_base, house.view, tid & 63);
+      frame_housekeeping<T>(house, tid, s_red);
+    }
+    return;
+  }
   for (int i = tid; i < 4 * 256; i += T) (&h[0][0])[i] = 0;
   __syncthreads();
   const int64_t n = fs_bounded_n(n_host, n_dev);
@@ -315,9 +324,11 @@ __global__ __launch_bounds__(T, (T == 1024 ? (KPT <= 8 ? 8 : 4) : (KPT <= 8 ? 8 
                                                          const u32* __restrict__ ghist, u16* status, u32* ticket,
                                                          u32* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                          int fsf, uint8_t* __restrict__ flags_clear, u32* ranges,
-                                                         const u32* __restrict__ inst_count, u32* emit_totals,
+                                                         const u32* __restrict__ inst_count, u64* emit_totals,
                                                          unsigned long long* timing, int32_t* sync_error, int spin_limit,
-                                                         int fault) {
+                                                         int fault, const u32* __restrict__ run_if) {
+  // (run_if: see sort_hist_kernel — a pass of a sort nobody needs returns before it draws a ticket)
+  if (run_if != nullptr && __hip_atomic_load(run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   constexpr int TW = T / 64;  // waves of the block
   static_assert(T == 1024 || T == 256, "block sizes of the radix passes");
   constexpr u32 NB = 1u << DB;
@@ -515,21 +526,22 @@ __global__ __launch_bounds__(T, (T == 1024 ? (KPT <= 8 ? 8 : 4) : (KPT <= 8 ? 8 
         // pos is the Gaussian's final depth rank.  Lanes are consecutive slots: runs of consecutive ranks, so the
         // emission block (rank / 1024) is piecewise constant across the wave — a segmented scan, and only the last
         // lane of every piece adds its piece's sum: one to three atomics per wave instead of 64.
-        const u32 cntg = inst_count[vv];  // (P x 4 bytes: stays in L2, unlike the 32-byte emission records)
+        // (packed: instances in the low 40 bits, the number of Gaussians that emit any above — emit_total_pack, olsr_state.h)
+        const u64 cntg = emit_total_pack(inst_count[vv]);  // (P x 4 bytes: stays in L2, unlike the 32-byte emission records)
         const u32 bucket = pos / (u32)EMIT_CHUNK;
         const u64 act = ballot(true);  // (evaluated by every active lane)
         const u32 b0 = (u32)__builtin_amdgcn_readfirstlane((int)bucket);
         if (act == ~0ull && ballot(bucket != b0) == 0ull) {
           // the common case: a full wave inside one emission block — a plain wave sum
-          u32 t = cntg;
+          u64 t = cntg;
 #pragma unroll
           for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
           if (lane == 0 && t) atomicAdd(&emit_totals[b0], t);
         } else {
-          u32 run = cntg;
+          u64 run = cntg;
 #pragma unroll
           for (int sft = 1; sft < 64; sft <<= 1) {
-            const u32 o = __shfl_up(run, sft);
+            const u64 o = __shfl_up(run, sft);
             const u32 ob = __shfl_up(bucket, sft);
             if (lane >= sft && ob == bucket) run += o;
           }
@@ -573,7 +585,8 @@ constexpr int SMALL_SORT_MAX = 8192;
 template <int KPT>
 __global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict__ keys_in, int n,
                                                           u32* __restrict__ vals_out, const u32* __restrict__ inst_count,
-                                                          u32* __restrict__ emit_totals, FrameHousekeeping house) {
+                                                          u64* __restrict__ emit_totals, FrameHousekeeping house,
+                                                          const u32* __restrict__ run_if) {
   constexpr u32 NB = 256, DMASK = 255;
   constexpr int CHUNK = FS_T * KPT;
   extern __shared__ __attribute__((aligned(16))) u32 fs_smem[];
@@ -585,6 +598,8 @@ __global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (house.hint_base != nullptr && w == 1) hint_pick_wave(house.hint_base, house.view, lane);
   frame_housekeeping<FS_T>(house, tid, s_red);
+  // (run_if: see sort_hist_kernel — the carried order was repaired, only the bookkeeping above was needed; uniform)
+  if (run_if != nullptr && __hip_atomic_load(run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   const int wbase = w * (64 * KPT);
   u32 key[KPT], val[KPT];
 #pragma unroll
@@ -667,11 +682,11 @@ __global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict_
 #pragma unroll
   for (int k = 0; k < KPT; ++k) {
     const int slot = k * FS_T + tid;
-    u32 t = 0;
+    u64 t = 0;
     if (slot < n) {
       const u32 vv = ex_val[slot];
       vals_out[slot] = vv;
-      t = inst_count[vv];
+      t = emit_total_pack(inst_count[vv]);
     }
     static_assert(EMIT_CHUNK == FS_T, "one emission block per 1024 ranks");
 #pragma unroll
@@ -681,8 +696,8 @@ __global__ __launch_bounds__(FS_T) void sort_small_kernel(const u32* __restrict_
 }
 
 template <int KPT>
-static void launch_sort_small_t(const u32* keys, int n, u32* vals_out, const u32* inst_count, u32* emit_totals,
-                                const FrameHousekeeping& h, hipStream_t st) {
+static void launch_sort_small_t(const u32* keys, int n, u32* vals_out, const u32* inst_count, u64* emit_totals,
+                                const FrameHousekeeping& h, const u32* run_if, hipStream_t st) {
   constexpr size_t smem = sizeof(u32) * ((size_t)FS_W * 256 + 2 * (size_t)FS_T * KPT);
   static bool attr_set = false;  // (per instantiation) blocks above 64 KB of LDS need the opt-in
   if (!attr_set && smem > 64 * 1024) {
@@ -690,7 +705,7 @@ static void launch_sort_small_t(const u32* keys, int n, u32* vals_out, const u32
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  sort_small_kernel<KPT><<<1, FS_T, smem, st>>>(keys, n, vals_out, inst_count, emit_totals, h);
+  sort_small_kernel<KPT><<<1, FS_T, smem, st>>>(keys, n, vals_out, inst_count, emit_totals, h, run_if);
 }
 
 struct PassArgs {
@@ -706,10 +721,11 @@ struct PassArgs {
   uint8_t* flags;
   u32* ranges;
   const u32* inst_count;
-  u32* emit_totals;
+  u64* emit_totals;
   int nblk;
   int32_t* sync_error;
   int fault;
+  const u32* run_if;
 };
 
 template <int DB, int KPT, int T>
@@ -736,7 +752,8 @@ static void launch_pass_t(const PassArgs& a, hipStream_t st) {
   sort_pass_kernel<DB, KPT, T><<<a.nblk, T, smem, st>>>(a.kin, a.vin, a.n_host, a.n_dev, a.shift, a.ghist, a.status,
                                                         a.ticket, a.kout, a.vout, a.fsf, a.flags, a.ranges,
                                                         a.inst_count, a.emit_totals, timing, a.sync_error,
-                                                        sort_knobs().spin_limit.load(std::memory_order_relaxed), a.fault);
+                                                        sort_knobs().spin_limit.load(std::memory_order_relaxed), a.fault,
+                                                        a.run_if);
 }
 
 template <int DB, int T>
@@ -795,15 +812,16 @@ bool small_depth_sort_applicable(int64_t n) {
          (sort_knobs().fault.load(std::memory_order_relaxed) & 1) == 0;
 }
 void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, const uint32_t* inst_count,
-                             uint32_t* emit_totals, const FusedHouse* house, hipStream_t st) {
+                             uint32_t* emit_totals, const FusedHouse* house, const uint32_t* run_if, hipStream_t st) {
   const FrameHousekeeping h = housekeeping_of(house);
-  if (n <= 2 * FS_T) launch_sort_small_t<2>(keys, n, order_out, inst_count, emit_totals, h, st);
-  else if (n <= 4 * FS_T) launch_sort_small_t<4>(keys, n, order_out, inst_count, emit_totals, h, st);
-  else launch_sort_small_t<8>(keys, n, order_out, inst_count, emit_totals, h, st);
+  u64* et = reinterpret_cast<u64*>(emit_totals);
+  if (n <= 2 * FS_T) launch_sort_small_t<2>(keys, n, order_out, inst_count, et, h, run_if, st);
+  else if (n <= 4 * FS_T) launch_sort_small_t<4>(keys, n, order_out, inst_count, et, h, run_if, st);
+  else launch_sort_small_t<8>(keys, n, order_out, inst_count, et, h, run_if, st);
 }
 
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
-                      const FusedHouse* house, int threads, hipStream_t st) {
+                      const FusedHouse* house, int threads, hipStream_t st, const uint32_t* run_if) {
   int passes;
   const int db = fused_sort_digit_bits(bits, &passes);
   const FrameHousekeeping h = housekeeping_of(house);
@@ -815,15 +833,16 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
 #endif
   if (nb > OLSR_HIST_BLOCKS) nb = OLSR_HIST_BLOCKS;  // ... then a grid-stride loop: every block ends with one global atomic per non-empty bin,
                            // and same-address atomics serialise (~10-20 ns each), so few, fat blocks
-  if (T == 256) sort_hist_kernel<256><<<(int)nb, 256, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0);
-  else sort_hist_kernel<1024><<<(int)nb, 1024, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0);
+  if (T == 256) sort_hist_kernel<256><<<(int)nb, 256, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0, run_if);
+  else sort_hist_kernel<1024><<<(int)nb, 1024, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0, run_if);
 }
 
 // Sorts (key, val) pairs on the low `bits` bits of key, ceil(bits / 8) passes.  hist / status / tickets must have been
 // zeroed and hist filled by launch_sort_hist.  Returns 0 if the result ends in (key_a, val_a), 1 if in (key_b, val_b).
 int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host, const int32_t* n_dev, int bits,
                       bool vals_in_identity, const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
-                      const uint32_t* inst_count, uint32_t* emit_totals, int32_t* sync_error, int fault, hipStream_t st) {
+                      const uint32_t* inst_count, uint32_t* emit_totals, int32_t* sync_error, int fault, hipStream_t st,
+                      uint32_t* final_vals_out, const uint32_t* run_if) {
   if (n_host <= 0) return 0;
   int passes;
   const int db = fused_sort_digit_bits(bits, &passes);
@@ -834,9 +853,11 @@ int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host
     int fsf = 0;
     if (p == 0 && vals_in_identity) fsf |= FSF_IDENTITY;
     if (p == passes - 1) fsf |= FSF_NO_KEYS | (ranges ? FSF_RANGES : 0) | (emit_totals ? FSF_EMIT_TOTALS : 0);
+    // (final_vals_out: the last pass leaves the sorted values there instead of in the ping-pong buffer — the carried depth order)
     PassArgs a{kin, vin, n_host, n_dev, db * p, hist + 256 * p,
-               reinterpret_cast<u16*>(status) + (size_t)p * plan.nblk * NB, tickets + p, kout, vout, fsf, flags_clear,
-               ranges, inst_count, emit_totals, plan.nblk, sync_error, p == 0 ? fault : 0};
+               reinterpret_cast<u16*>(status) + (size_t)p * plan.nblk * NB, tickets + p, kout,
+               (p == passes - 1 && final_vals_out != nullptr) ? final_vals_out : vout, fsf, flags_clear,
+               ranges, inst_count, reinterpret_cast<u64*>(emit_totals), plan.nblk, sync_error, p == 0 ? fault : 0, run_if};
     switch (db) {
       case 4: launch_pass_k<4>(plan, a, st); break;
       case 5: launch_pass_k<5>(plan, a, st); break;

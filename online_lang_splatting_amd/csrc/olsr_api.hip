@@ -249,6 +249,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   const bool sync_mode = bp.capacity < 0;
   int64_t n_host = 0;
   BinningState b{};
+  uint32_t* carry = nullptr;  // the caller's carried depth order, when this frame uses it
   if (s.P > 0) {
     launch_preprocess(s, d, g, radii, n_touched, st);  // also zeroes the geometry buffer's synchronisation words
     STAGE("preprocess");
@@ -269,20 +270,27 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       house.host_seq = g_pinned.seq;
     }
     SortBuffers sb{g.key_a, g.key_b, g.val_a, g.val_b, g.radix_table, g.scan_partials};
+    const bool in_flight = (s.flags & OLSR_FLAG_FRAMES_IN_FLIGHT) != 0;
+    // Carried depth order (include/olsr.h): two launches of independent workgroups repair the order the previous frame of this
+    // view left in the caller's array; the sort below is enqueued behind them in any case and does its work only when the
+    // repair says it could not prove the result (carry_miss != 0) — the lists never depend on what the array held.
+    carry = (!sync_mode && !legacy && fused_sort_applicable(s.P, 32)) ? s.depth_order_carry : nullptr;
+    const uint32_t* run_if = carry ? g.carry_miss : nullptr;
+    if (carry)
+      launch_order_repair(s.P, carry, g.key_a, g.key_b, g.val_b, g.tiles_touched, g.carry_totals, g.carry_miss, in_flight, st);
     if (!legacy && small_depth_sort_applicable(s.P)) {
       // at most 8 192 Gaussians: histogram, bookkeeping and all four passes in ONE launch of one workgroup (k_sort.hip)
-      launch_small_depth_sort(g.key_a, s.P, g.depth_order, g.tiles_touched, g.emit_status, &house, st);
+      launch_small_depth_sort(g.key_a, s.P, carry ? carry : g.depth_order, g.tiles_touched, g.emit_status, &house, run_if, st);
       STAGE("depth_sort");
     } else {
-    const bool in_flight = (s.flags & OLSR_FLAG_FRAMES_IN_FLIGHT) != 0;
     const SortPlan depth_plan = sort_plan(s.P, false, 85, in_flight);
-    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, depth_plan.threads, st);
+    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, depth_plan.threads, st, run_if);
     // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
     if (!legacy && fused_sort_applicable(s.P, 32)) {
       // (values = Gaussian indices: the first pass takes them from the position, preprocess writes no index array)
       launch_sort_fused(sb, depth_plan, s.P, nullptr, 32, true, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
                         g.tiles_touched, g.emit_status, &g.counters[8],
-                        sort_knobs().fault.load(std::memory_order_relaxed) & 1, st);
+                        sort_knobs().fault.load(std::memory_order_relaxed) & 1, st, carry, run_if);
     } else {
       launch_radix_sort(sb, s.P, nullptr, 32, true, st);
       launch_emit_totals(g.depth_order, s.P, g.tiles_touched, g.emit_status, st);
@@ -342,7 +350,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     const int64_t bin_sync_words =
         (b.tile_status - b.sync_words) +
         (fused_tiles ? ((int64_t)tpasses * tile_plan.nblk * ((int64_t)1 << tdb) + 1) / 2 : 0);  // 16-bit words
-    launch_emit(s, d, g, b, bin_sync_words, n_host, st);
+    launch_emit(s, d, g, b, bin_sync_words, n_host, carry ? carry : g.depth_order, carry ? g.carry_totals : nullptr,
+                carry ? g.carry_miss : nullptr, st);
     STAGE("emit");
     if (n_host > 0) {
       // arrange the value ping-pong so that the last pass always lands in b.src
@@ -604,6 +613,7 @@ int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* ge
   const int ntiles = ((scene->width + tile - 1) / tile) * ((scene->height + tile - 1) / tile);
   olsr_scene sc = *scene;
   sc.tile_depth_cut = nullptr;  // (per-tile depth cut-offs belong to the sync-free entries: their verdict is a device status word)
+  sc.depth_order_carry = nullptr;  // (a caller-owned array: the reference-shaped entry has no place for one)
   return forward_impl(sc, geom, img, bp, out_color, out_language, out_depth, out_opacity, radii, n_touched,
                       num_rendered, nullptr, nullptr, (hipStream_t)hip_stream, nullptr,
                       order_hint_of(ntiles, (hipStream_t)hip_stream));
@@ -988,6 +998,9 @@ const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t 
   if (!std::strcmp(name, "emit_totals")) return g.emit_status;
   if (!std::strcmp(name, "inst_start")) return g.inst_start;
   if (!std::strcmp(name, "blended")) return g.blended;  // u8[P]: some pixel blended the Gaussian in this frame's forward
+  if (!std::strcmp(name, "carry_miss")) return g.carry_miss;  // u32: != 0 = this frame's carried depth order was not repairable
+  if (!std::strcmp(name, "carry_totals")) return g.carry_totals;
+  if (!std::strcmp(name, "sort_keys")) return g.key_a;  // u32[P] (valid after a forward whose carried order was repaired)
   return nullptr;
 }
 

@@ -37,8 +37,11 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 // fused scan of the per-Gaussian instance counts (depth order) + emission of the instances; also zeroes the first
 // bin_sync_words words of the binning buffer's synchronisation area
 // (n_host: the instance count, or the caller's capacity when the count is only known on the device)
+// order: the depth order to emit in (g.depth_order, or the carried one); alt_totals / alt_unless (may be null): the per-block
+// instance totals come from alt_totals instead of g.emit_status when *alt_unless == 0 (the carried order was repaired)
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
-                 int64_t bin_sync_words, int64_t n_host, hipStream_t st);
+                 int64_t bin_sync_words, int64_t n_host, const uint32_t* order, const uint32_t* alt_totals,
+                 const uint32_t* alt_unless, hipStream_t st);
 // exclusive scan of popcount(flags) over [0, n] -> rowbase[0..n] in one kernel; counters[6] = total live rows,
 // counters[7] = (total > row_capacity) or the forward's instance overflow
 // packed_ref15: rows per instance = packed survivor waves (flag bits 4-5) instead of forward slots (bits 0-3)
@@ -113,8 +116,11 @@ constexpr float HINT_VIEW_TOL = 0.03f;
 bool fused_sort_applicable(int64_t n_host, int bits);
 int fused_sort_digit_bits(int bits, int* passes_out);
 // digit totals of all passes (hist[pass][256], zeroed beforehand); optionally the frame's bookkeeping
+// run_if (may be null; also launch_sort_fused / launch_small_depth_sort): a device word — the kernels do their work only when it
+// is non-zero (the carried depth order could not be repaired, k_order_carry.hip); the frame's bookkeeping happens either way
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
-                      const FusedHouse* house, int threads /* 256 or 1024: SortPlan::threads */, hipStream_t st);
+                      const FusedHouse* house, int threads /* 256 or 1024: SortPlan::threads */, hipStream_t st,
+                      const uint32_t* run_if = nullptr);
 // stable sort on the low `bits` bits; status: [passes][plan.nblk][1 << digit bits] zeroed 16-bit words (plan = sort_plan(n_host, ...)), tickets:
 // one zeroed word per pass.  flags_clear (with vals_in_identity): byte i is cleared for every element; ranges: the
 // last pass derives per-key [start, end) (keys must then be tile ids).  Returns where the result ends (0: a, 1: b);
@@ -122,13 +128,21 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
 // instance count (inst_count[v]) to emit_totals[final position / EMIT_CHUNK] (zeroed beforehand).
 int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host, const int32_t* n_dev, int bits,
                       bool vals_in_identity, const uint32_t* hist, uint32_t* status, uint32_t* tickets, uint8_t* flags_clear, uint32_t* ranges,
-                      const uint32_t* inst_count, uint32_t* emit_totals, int32_t* sync_error, int fault, hipStream_t st);
+                      const uint32_t* inst_count, uint32_t* emit_totals, int32_t* sync_error, int fault, hipStream_t st,
+                      uint32_t* final_vals_out = nullptr, const uint32_t* run_if = nullptr);
 void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_launches);
 // the same totals for a depth order produced by the multi-kernel passes
 // the whole depth sort of n <= 8 192 Gaussians in one launch, incl. the frame's bookkeeping (k_sort.hip: sort_small_kernel)
 bool small_depth_sort_applicable(int64_t n);
 void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, const uint32_t* inst_count,
-                             uint32_t* emit_totals, const FusedHouse* house, hipStream_t st);
+                             uint32_t* emit_totals, const FusedHouse* house, const uint32_t* run_if, hipStream_t st);
+// k_order_carry.hip — the previous frame's depth order repaired under this frame's keys (olsr_scene.depth_order_carry):
+// carry [P] in: any content, out: the new order if *miss stays 0 (else a partial repair the radix passes then overwrite);
+// keys [P] by Gaussian; tmp_key / tmp_gid [P] scratch; totals: instances per emission block of EMIT_CHUNK ranks;
+// miss: a zeroed device word
+void launch_order_repair(int P, uint32_t* carry, const uint32_t* keys, uint32_t* tmp_key, uint32_t* tmp_gid,
+                         const uint32_t* inst_count, uint32_t* totals, uint32_t* miss, bool frames_in_flight,
+                         hipStream_t st);
 void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count, uint32_t* emit_totals, hipStream_t st);
 
 // k_render_fwd.hip

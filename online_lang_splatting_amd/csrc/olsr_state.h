@@ -119,6 +119,14 @@ inline size_t fused_status_words(long long n, int passes) {
 }
 // single-pass scans (emission offsets, row compaction): elements per 1024-thread block
 constexpr int EMIT_CHUNK = 1024;
+// Per block of EMIT_CHUNK depth ranks the sort (or the repair of a carried order) leaves ONE 64-bit total for the emission:
+// the instances the block's Gaussians emit (low 40 bits) and how many of them emit any (above).  The emission compacts the
+// emitting ranks (emit_offsets_kernel): with sort keys for every Gaussian (k_preprocess.hip) a view that sees a fifth of the
+// map has four silent ranks between two emitting ones.
+constexpr int EMIT_TOTAL_SHIFT = 40;
+__host__ __device__ inline unsigned long long emit_total_pack(uint32_t instances) {
+  return (unsigned long long)instances | ((unsigned long long)(instances != 0u) << EMIT_TOTAL_SHIFT);
+}
 #ifndef OLSR_ROWS_THREADS
 #define OLSR_ROWS_THREADS 1024  // threads of a row-compaction block (16 instances each)
 #endif
@@ -167,7 +175,8 @@ struct GeometryState {
                           //          spin bound (a status word corrupted mid-frame).  Reset by the frame's first kernel; the
                           //          forward reports it as num_rendered_dev[1] = 2, the backward writes zero gradients and
                           //          reports status_dev[1] = 2 / OLSR_ERR_DEVICE (include/olsr.h),
-                          //      9 = a tile with a depth cut-off did not saturate (OLSR_STATUS_CUT_MISS).  [10..15] reserved
+                          //      9 = a tile with a depth cut-off did not saturate (OLSR_STATUS_CUT_MISS),
+                          //      10 = Gaussians that emit instances (the length of the emission's compacted rank list).  [11..15] reserved
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
   uint4* big_list;        // [P] work lists {id, first instance, #instances} built by the emission: large footprints from
@@ -175,12 +184,14 @@ struct GeometryState {
   // ---- words the fused kernels synchronise through; zeroed by preprocess at the start of every forward
   uint32_t* sync_words;   // start of the zeroed region
   size_t sync_count;      // its length in 32-bit words
-  uint32_t* tickets;      // [16] dynamic block ids: 0-3 depth passes, 4 scan+emit
+  uint32_t* tickets;      // [16] dynamic block ids: 0-3 depth passes, 4 scan+emit; [12] = carry_miss (below)
   uint32_t* sort_hist;    // [4][256] digit totals of the four depth passes
   uint32_t* sort_status;  // [4][blocks][256] per-block digit counts of the depth passes (bit 31 = published)
-  uint32_t* emit_status;  // [ceil(P / EMIT_CHUNK)] x 64 bit: per-block instance totals of the fused scan + emission
+  uint32_t* emit_status;  // [ceil(P / EMIT_CHUNK)] x 64 bit: per-block totals for the emission (emit_total_pack above)
   uint32_t* part_rect;    // [ceil(P / 256)] preprocess' per-block sums: instances of the reference's rect binning
   uint32_t* part_count;   // [ceil(P / 256)] ... and instances this frame emits
+  uint32_t* carry_totals; // [ceil(P / EMIT_CHUNK) + 1] x 64 bit: the same totals for a REPAIRED carried depth order (k_order_carry.hip)
+  uint32_t* carry_miss;   // one of the zeroed words (tickets[12]): != 0 = the carried order could not be repaired, the radix passes run
   static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
     Carver c(buf);
     GeometryState g;
@@ -219,6 +230,8 @@ struct GeometryState {
     }
     g.part_rect = c.take<uint32_t>((P + 255) / 256 + 1);
     g.part_count = c.take<uint32_t>((P + 255) / 256 + 1);
+    g.carry_totals = c.take<uint32_t>(2 * ((P + EMIT_CHUNK - 1) / EMIT_CHUNK + 1));
+    g.carry_miss = g.tickets + 12;
     bytes = c.total();
     return g;
   }

@@ -513,7 +513,7 @@ class RasterWorkspace:
     """Allocation-free, sync-free forward+backward through the C-ABI (one view at a time)."""
 
     def __init__(self, P, W, H, F, M, capacity, device, tile=15, bwd_mode=_abi.BWD_REFERENCE, row_capacity=None,
-                 binning=_abi.BINNING_ELLIPSE, flags=0, depth_cut=False, rows_in_forward=None):
+                 binning=_abi.BINNING_ELLIPSE, flags=0, depth_cut=False, rows_in_forward=None, carry_order=False):
         self.P, self.W, self.H, self.F, self.M = int(P), int(W), int(H), int(F), int(M)
         self.capacity, self.tile, self.bwd_mode = int(capacity), int(tile), int(bwd_mode)
         self.binning_mode = int(binning)
@@ -555,6 +555,12 @@ class RasterWorkspace:
         # per-tile depth cut-offs (include/olsr.h): [0, tiles) the cut-offs in force, [tiles, 2 tiles) library scratch
         self._depth_cut_buf = torch.full((2 * ntiles,), float("inf"), **f32) if depth_cut else None
         self.depth_cut = self._depth_cut_buf[:ntiles] if depth_cut else None
+        # Carried depth order (include/olsr.h, csrc/k_order_carry.hip; opt-in, for sequences of nearly identical views of the
+        # same Gaussians): the forward repairs the order its previous frame left here instead of sorting from scratch (two
+        # launches instead of five dependent ones) and falls back to the radix passes on the device when it cannot prove
+        # the result — the lists never depend on the array's content, so it may be swapped (one array per VIEW: a caller that
+        # cycles through views assigns ws.depth_order_carry before set_scene, MappingStep does) or hold zeros.
+        self.depth_order_carry = torch.zeros(P, **i32) if carry_order else None
         self.grads = dict(dL_dmeans2D=torch.empty(P, 3, **f32), dL_dconic=torch.empty(P, 4, **f32),
                           dL_dopacity=torch.empty(P, 1, **f32), dL_dcolors=torch.empty(P, 3, **f32),
                           dL_dlanguage=torch.empty(P, F, **f32), dL_ddepths=torch.empty(P, 1, **f32),
@@ -593,7 +599,8 @@ class RasterWorkspace:
             colors_precomp=colors_precomp, language_precomp=language, opacities=opacities, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix, projmatrix=projmatrix,
             projmatrix_raw=projmatrix_raw, cam_pos=campos, tile_depth_cut=self._depth_cut_buf,
-            backward_row_capacity=self.row_capacity if self.rows_in_forward else 0)
+            backward_row_capacity=self.row_capacity if self.rows_in_forward else 0,
+            depth_order_carry=self.depth_order_carry)
 
     def forward(self):
         o = self.out
@@ -700,6 +707,12 @@ class RasterWorkspace:
         """OLSR_STATUS_* of the last forward (0 fine, 1 capacity overflow, 2 synchronisation error, 3 a depth cut-off was
         missed: repeat the forward) — synchronises."""
         return int(self.num_rendered.cpu()[1])
+
+    def carry_missed(self):
+        """True when the last forward could not repair its carried depth order and took the radix passes (the result is the
+        same either way) — synchronises; for tests and benchmarks."""
+        from . import _C
+        return bool(int(_C.state_field("geometry", self.geom, "carry_miss", P=self.P, F=self.F, dtype=torch.int32, count=1).cpu()[0]))
 
     def reset_depth_cut(self):
         if self.depth_cut is not None:

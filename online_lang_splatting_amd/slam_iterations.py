@@ -197,7 +197,7 @@ class MappingStep:
 
     def __init__(self, lanes: FrameLanes, params: Dict[str, torch.Tensor], bg: torch.Tensor, sh_degree: int,
                  cameras: Sequence[Dict], targets: Sequence, lrs: Dict[str, float], exposure=None,
-                 activations=_abi.ACT_ALL, fused_loss="auto", view_ids: Optional[Sequence] = None):
+                 activations=_abi.ACT_ALL, fused_loss="auto", view_ids: Optional[Sequence] = None, carry_order: bool = True):
         """targets[v] = (gt_image [3,H,W], gt_depth [H,W], gt_language [F,h,w] or None).
         fused_loss: True — the mapping loss is evaluated in the forward composite's epilogue (olsr_forward_async_loss); False —
         olsr_forward_async + olsr_mapping_loss (two kernels; the same cotangents bit for bit, the loss value to summation order);
@@ -207,7 +207,11 @@ class MappingStep:
         hides beside other lanes' composites (two-kernel 2 % faster); on a surface map the frame is latency-bound and the
         fused form saves a launch and an image round trip per view (5 % faster).
         view_ids: a stable id per camera (default: its position) keying the per-view tile-order hints, so that a sliding
-        keyframe window (cameras reassigned, grown or reordered between iterations) keeps every view's own order."""
+        keyframe window (cameras reassigned, grown or reordered between iterations) keeps every view's own order.
+        carry_order (round 6): every view also keeps its DEPTH order of the previous iteration (include/olsr.h "Carried depth
+        order"; 4 P bytes per view): an Adam step moves the Gaussians by a fraction of a millimetre, so the forward repairs that
+        order in two launches instead of sorting from scratch in five dependent ones, and falls back to the sort on the device
+        when it cannot prove the result — parameters are bit-identical either way (tests/test_gpu_order_carry.py)."""
         self.lanes, self.params, self.bg, self.sh_degree = lanes, params, bg, sh_degree
         self.cameras, self.lrs, self.exposure, self.act = cameras, lrs, exposure, activations
         self.view_ids = view_ids
@@ -232,6 +236,8 @@ class MappingStep:
         # (keyed by a stable view id and created lazily — ADVICE round 4: a list sized at construction broke when the window grew)
         self.view_hints: Dict = {}
         self._hint_proto = ws0.tile_order.clone()
+        self.carry_order = bool(carry_order)
+        self.view_orders: Dict = {}   # view id -> int32[P], the view's depth order of its last iteration (zeros: none yet)
 
     @property
     def targets(self):
@@ -300,9 +306,12 @@ class MappingStep:
             vid = self.view_ids[v] if self.view_ids is not None else v
             if vid not in self.view_hints:   # (created on the caller's stream, which the lanes are ordered behind)
                 self.view_hints[vid] = self._hint_proto.clone()
+                if self.carry_order:
+                    self.view_orders[vid] = torch.zeros(ws.P, dtype=torch.int32, device=dev)
                 stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 ws.tile_order = self.view_hints[vid]   # in: this view's order of the last iteration; out: this iteration's
+                ws.depth_order_carry = self.view_orders[vid] if self.carry_order else None
                 if self.fused:
                     ws.set_scene(bg=self.bg, sh_degree=self.sh_degree, activations=self.act, **cam, **self.params)
                     lo = ws.forward_loss(*self.targets[v], self.exposure, skip_images=True)

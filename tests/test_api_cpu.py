@@ -52,9 +52,10 @@ def test_struct_layout_matches_header():
     from online_lang_splatting_amd._abi import OlsrScene
     # 10 int32 + 4 float + 13 pointers + 2 int32 + 1 pointer (tile_depth_cut, round 4) + 1 int64 (backward_row_capacity,
     # round 5), no implicit padding
-    assert ctypes.sizeof(OlsrScene) == 10 * 4 + 4 * 4 + 13 * 8 + 2 * 4 + 8 + 8
+    assert ctypes.sizeof(OlsrScene) == 10 * 4 + 4 * 4 + 13 * 8 + 2 * 4 + 8 + 8 + 8
     assert OlsrScene.background.offset == 56 and OlsrScene.cam_pos.offset == 56 + 12 * 8
     assert OlsrScene.tile_depth_cut.offset == 56 + 13 * 8 + 8
+    assert OlsrScene.depth_order_carry.offset == 56 + 13 * 8 + 8 + 8 + 8
     from online_lang_splatting_amd._abi import OlsrGradBucket
     assert ctypes.sizeof(OlsrGradBucket) == 3 * 8 + 2 * 4 + 8 and OlsrGradBucket.row_mask.offset == 32
 

@@ -387,7 +387,8 @@ def test_one_launch_depth_sort_equals_the_radix_passes(hip, P):
             R, color, lang, radii, geom, binb, img, depth, opac, nt = hip.rasterize_language_gaussians(*a)
             order = hip.state_field("geometry", geom, "depth_order", P=P, F=3, dtype=torch.int32, count=P).clone()
             cnt = hip.state_field("geometry", geom, "counters", P=P, F=3, dtype=torch.int32, count=10).clone()
-            et = hip.state_field("geometry", geom, "emit_totals", P=P, F=3, dtype=torch.int32, count=(P + 1023) // 1024).clone()
+            # (one 64-bit total per block of 1024 ranks: instances | emitting Gaussians << 40)
+            et = hip.state_field("geometry", geom, "emit_totals", P=P, F=3, dtype=torch.int32, count=2 * ((P + 1023) // 1024)).clone()
             pl = hip.state_field("binning", binb, "point_list", R=R, F=3, dtype=torch.int32, count=R).clone() if R else None
             out[small] = (R, order, cnt, et, pl, color.clone(), lang.clone(), depth.clone(), nt.clone())
     finally:
