@@ -81,24 +81,26 @@ def algorithmic_bytes(P, R, N, C=3, F=15, M=1):
     return per
 
 
-PROFILE_TAG = "r5"  # the committed counter summaries of the current kernels: profiles/<tag>_pmc_{traffic,valu}.json
+# the committed counter summaries of the current kernels, per workload: profiles/<tag>_pmc_{traffic,valu}.json.  A counter is
+# attached to a line only when it was collected on THAT line's scene and config (the room map's
+# lines carried the volume's 264 MB); anything else reports null.
+PROFILE_TAGS = {("volume", 3): "r6", ("room", 3): "r6_room"}
 
 
-def _pmc_summary(kind):
-    """profiles/<PROFILE_TAG>_pmc_<kind>.json, else the alphabetically last summary (file times do not survive a copy)."""
-    import glob
-    tagged = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_{kind}.json")
-    if os.path.exists(tagged):
-        return tagged
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}.json")))
-    return files[-1] if files else None
+def _pmc_summary(kind, scene="volume", config=3):
+    """profiles/<tag of (scene, config)>_pmc_<kind>.json, or None: no counters were collected on this workload."""
+    tag = PROFILE_TAGS.get((scene, config))
+    if tag is None:
+        return None
+    tagged = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}.json")
+    return tagged if os.path.exists(tagged) else None
 
 
-def measured_traffic(kernel_stage, F):
-    """HBM bytes per launch of the stage's kernel from profiles/<PROFILE_TAG>_pmc_traffic.json (rocprofv3
+def measured_traffic(kernel_stage, F, scene="volume", config=3):
+    """HBM bytes per launch of the stage's kernel from the workload's profiles/<tag>_pmc_traffic.json (rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, corrected as MI355X_MICROARCH.md prescribes);
-    None when no summary has been committed."""
-    files = [_pmc_summary("traffic")]
+    None when no summary of THIS scene and config has been committed."""
+    files = [_pmc_summary("traffic", scene, config)]
     if not files[-1]:
         return None, None
     d = json.load(open(files[-1]))
@@ -109,10 +111,10 @@ def measured_traffic(kernel_stage, F):
     return None, None
 
 
-def measured_valu(kernel_stage, F):
-    """VALU wave-instructions per launch of the stage's kernel from profiles/<PROFILE_TAG>_pmc_valu.json
-    (rocprofv3 --pmc SQ_INSTS_VALU ... of this same command); None when no summary has been committed."""
-    files = [_pmc_summary("valu")]
+def measured_valu(kernel_stage, F, scene="volume", config=3):
+    """VALU wave-instructions per launch of the stage's kernel from the workload's profiles/<tag>_pmc_valu.json
+    (rocprofv3 --pmc SQ_INSTS_VALU ... of this same command); None when none of THIS scene and config has been committed."""
+    files = [_pmc_summary("valu", scene, config)]
     if not files[-1]:
         return None, None
     d = json.load(open(files[-1]))
@@ -283,7 +285,23 @@ def room_scene_leg(dev, dims, steps, seed=3):
                    "10-keyframe window + 2 random keyframes",
            "P": sc.P, "keyframes": rs.keyframes, "width": W, "height": H, "F": F, "views": len(camd),
            "scene_build_s": round(t_build, 2)}
-    lanes = FrameLanes(4, sc.P, W, H, F, M, cap, dev)
+    # (the lanes carry their view's depth order: the legs that repeat one view use it, the cycling legs — a lane's previous
+    #  frame is another view — and the tracking loop — a pose step moves the order by tens of thousands of ranks on a surface
+    #  map, scripts/probe/carry_hits.py — run without; MappingStep keeps one order per view by itself)
+    lanes = FrameLanes(4, sc.P, W, H, F, M, cap, dev, carry_order=True)
+
+    class no_carry:
+        def __init__(self, *lane_sets):
+            self.ws = [l_[0] for ls in lane_sets for l_ in ls]
+
+        def __enter__(self):
+            self.keep = [w_.depth_order_carry for w_ in self.ws]
+            for w_ in self.ws:
+                w_.depth_order_carry = None
+
+        def __exit__(self, *exc):
+            for w_, k_ in zip(self.ws, self.keep):
+                w_.depth_order_carry = k_
 
     def step(lane, cam_):
         ws_, bucket_, stream_ = lane
@@ -301,27 +319,37 @@ def room_scene_leg(dev, dims, steps, seed=3):
             step(pick_lane(), pick_cam(i))
         torch.cuda.synchronize(dev)
         return n / (time.perf_counter() - t0)
-    lane0 = FrameLanes(1, sc.P, W, H, F, M, cap, dev).lanes[0]   # (one frame in flight: without OLSR_FLAG_FRAMES_IN_FLIGHT)
+    lane0 = FrameLanes(1, sc.P, W, H, F, M, cap, dev, carry_order=True).lanes[0]   # (one frame in flight: without OLSR_FLAG_FRAMES_IN_FLIGHT)
     n = max(steps, 20)
-    out["isolated"] = {"value": round(rate(n, lambda: lane0, lambda i: camd[0]), 1), "unit": "frames/s", "frames_in_flight": 1}
+    out["isolated"] = {"value": round(rate(n, lambda: lane0, lambda i: camd[0]), 1), "unit": "frames/s", "frames_in_flight": 1,
+                       "carried_depth_order": True}
     out["four_in_flight"] = {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[0], warm=40), 1), "unit": "frames/s",
-                             "same_view_every_step": True}
-    out["four_in_flight_cycling_12_views"] = {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[i % len(camd)], warm=48), 1),
-                                              "unit": "frames/s", "same_view_every_step": False}
-    out["isolated_cycling_12_views"] = {"value": round(rate(n, lambda: lane0, lambda i: camd[i % len(camd)], warm=24), 1),
-                                        "unit": "frames/s"}
+                             "same_view_every_step": True, "carried_depth_order": True}
+    with no_carry(lanes.lanes, [lane0]):
+        out["isolated"]["without_carried_order"] = round(rate(n, lambda: lane0, lambda i: camd[0]), 1)
+        out["four_in_flight"]["without_carried_order"] = round(rate(2 * n, lanes.next_lane, lambda i: camd[0], warm=40), 1)
+        out["four_in_flight_cycling_12_views"] = {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[i % len(camd)], warm=48), 1),
+                                                  "unit": "frames/s", "same_view_every_step": False, "carried_depth_order": False}
+        out["isolated_cycling_12_views"] = {"value": round(rate(n, lambda: lane0, lambda i: camd[i % len(camd)], warm=24), 1),
+                                            "unit": "frames/s", "carried_depth_order": False}
+
     # stage times, one frame in flight (events between the stages)
-    for _ in range(3):
-        step(lane0, camd[0])
-    torch.cuda.synchronize(dev)
-    _lib.set_profiling(True)
-    for _ in range(10):
-        step(lane0, camd[0])
-    per = {}
-    for name, ms in _lib.stage_times():
-        per.setdefault(name, []).append(ms)
-    _lib.set_profiling(False)
-    out["stage_ms"] = {k: round(sum(v) / len(v), 4) for k, v in per.items()}
+    def stages():
+        for _ in range(3):
+            step(lane0, camd[0])
+        torch.cuda.synchronize(dev)
+        _lib.set_profiling(True)
+        for _ in range(10):
+            step(lane0, camd[0])
+        per = {}
+        for name, ms in _lib.stage_times():
+            per.setdefault(name, []).append(ms)
+        _lib.set_profiling(False)
+        return {k: round(sum(v) / len(v), 4) for k, v in per.items()}
+    with no_carry([lane0]):
+        out["stage_ms_without_carried_order"] = stages()
+    out["stage_ms"] = stages()
+    out["carried_order_missed_last_frame"] = bool(lane0[0].carry_missed())
     out["stage_ms_sum"] = round(sum(out["stage_ms"].values()), 4)
     ws0, b0 = lane0[0], lane0[1]
     st = workload_stats(ws0, sc.P, W, H, F)
@@ -374,6 +402,7 @@ def room_scene_leg(dev, dims, steps, seed=3):
     T0 = (dT.to(dev) @ T_gt).contiguous()
     gt_image, gt_depth = rs.targets[0][0].to(dev), rs.targets[0][1].to(dev)
     trk = {}
+    keep_carry, ws0.depth_order_carry = ws0.depth_order_carry, None   # (tracking: no carried order, see above)
     for fused in (True, False):
         pose.reset(T0)
         loop = TrackingLoop(ws0, g_dev, 0, pose, gt_image, gt_depth, language_cotangent="null", fused_loss=fused)
@@ -385,6 +414,7 @@ def room_scene_leg(dev, dims, steps, seed=3):
             loop.iteration()
         torch.cuda.synchronize(dev)
         trk["fused_loss" if fused else "two_kernel_loss"] = round(1e3 * (time.perf_counter() - t0) / 60, 4)
+    ws0.depth_order_carry = keep_carry
     out["tracking"] = {"ms_per_iteration": trk, "iterations": 60,
                        "pose_error_start": round(float((T0 - T_gt).abs().max()), 6),
                        "pose_error_after": round(float((pose.T_w2c - T_gt).abs().max()), 6)}
@@ -449,8 +479,8 @@ def room_scene_leg(dev, dims, steps, seed=3):
     g_fresh, g_dev = g_dev, g_tr          # (step() renders from g_dev)
     R1 = max(_sized_capacity(F, g_dev, c_, H, W, 0, dev, cfg0) for c_ in camd[:3])
     if int(1.3 * R1) + (1 << 16) > cap:
-        lanes = FrameLanes(4, sc.P, W, H, F, M, int(1.5 * R1) + (1 << 16), dev)
-        lane0 = FrameLanes(1, sc.P, W, H, F, M, int(1.5 * R1) + (1 << 16), dev).lanes[0]
+        lanes = FrameLanes(4, sc.P, W, H, F, M, int(1.5 * R1) + (1 << 16), dev, carry_order=True)
+        lane0 = FrameLanes(1, sc.P, W, H, F, M, int(1.5 * R1) + (1 << 16), dev, carry_order=True).lanes[0]
     tr = {"mapping_iterations": 150, "loss_first": round(loss0, 6), "loss_last": round(loss1, 6),
           "isolated": {"value": round(rate(n, lambda: lane0, lambda i: camd[0]), 1), "unit": "frames/s"},
           "four_in_flight": {"value": round(rate(2 * n, lanes.next_lane, lambda i: camd[0], warm=40), 1), "unit": "frames/s"}}
@@ -586,8 +616,11 @@ def bracket_legs(sc, g_dev, c0, cots, dev, steps, dims):
                              ("fwd_accum_weight", (15, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE), _abi.FLAG_FWD_ACCUM_WEIGHT)):
         tile, mode, binning = cfg
         R = _sized_capacity(F, g_dev, c0, H, W, sc.sh_degree, dev, cfg)
-        ws = RasterWorkspace(P, W, H, F, M, int(R * 1.1) + (1 << 16), dev, tile=tile, bwd_mode=mode, binning=binning,
-                             flags=flags)
+        # (rows: up to four per instance in the exact backward; a surface map blends nearly every listed pair — the room
+        #  scene's exact-mode leg overflowed the one-row-per-instance default and reported the rate of a frame that rendered nothing)
+        cap_ = int(R * 1.1) + (1 << 16)
+        ws = RasterWorkspace(P, W, H, F, M, cap_, dev, tile=tile, bwd_mode=mode, binning=binning, flags=flags,
+                             row_capacity=4 * cap_ if mode == _abi.BWD_EXACT or tile == 16 else 2 * cap_)
         bucket = GradientBucket(P, GradLayout(M, F), dev)
 
         def one():
@@ -981,6 +1014,10 @@ def main():
                     help="volume (default): SURVEY 8(d)'s i.i.d. Gaussians, the BASELINE workload; room: the surface-structured "
                          "map of scene.make_room_scene (a SLAM map by the reference's recipe) at the config's size, rank r "
                          "rendering keyframe r of the mapping window")
+    ap.add_argument("--carry-order", type=int, default=1, choices=[0, 1],
+                    help="1 (default): the lanes carry their view's depth order from frame to frame (olsr_scene.depth_order_carry: "
+                         "repaired in two launches, exact by a device-side fall-back to the radix passes); the legs whose camera "
+                         "changes every step run without, and the line reports the same-view rates without it as well")
     ap.add_argument("--setup-steps", type=int, default=40, help="untimed frames before the W warm-up steps (steady state)")
     ap.add_argument("--isolated-steps", type=int, default=30, help="steps of the single-stream re-measurement (0 = skip)")
     a = ap.parse_args()
@@ -1081,7 +1118,23 @@ def main():
     _C.BINNING = _abi.BINNING_ELLIPSE
     capacity = int(R * 1.25) + (1 << 16)
     fwd_flags = {"mfma": _abi.FLAG_FWD_ACCUM_MFMA, "weight": _abi.FLAG_FWD_ACCUM_WEIGHT}.get(a.fwd_accum, 0)
-    lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning, flags=fwd_flags)
+    carry = bool(a.carry_order)
+    lanes = FrameLanes(a.streams, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning, flags=fwd_flags,
+                       carry_order=carry)
+
+    class carried_order_off:
+        """the legs in which a lane's previous frame is another view (or that measure the plain sort): no carried order"""
+        def __init__(self, *lane_sets):
+            self.ws = [l_[0] for ls in lane_sets for l_ in ls]
+
+        def __enter__(self):
+            self.keep = [w_.depth_order_carry for w_ in self.ws]
+            for w_ in self.ws:
+                w_.depth_order_carry = None
+
+        def __exit__(self, *exc):
+            for w_, k_ in zip(self.ws, self.keep):
+                w_.depth_order_carry = k_
 
     pending = {}  # bucket id -> outstanding all-reduce handles of that lane's previous frame
     step_done = []  # one event per step of the current timed region, recorded on the step's stream
@@ -1253,25 +1306,46 @@ def main():
     iso = prof = nonco = None
     # ONE frame in flight is its own workspace: the lanes' workspaces carry OLSR_FLAG_FRAMES_IN_FLIGHT (four-wave radix blocks,
     # which get onto the CUs beside another lane's composite: + 2 % with four frames in flight, - 11 % with one)
-    iso_lane = FrameLanes(1, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning, flags=fwd_flags).lanes[0] \
+    iso_lane = FrameLanes(1, P, W, H, F, M, capacity, dev, tile=15, bwd_mode=mode, binning=binning, flags=fwd_flags,
+                          carry_order=carry).lanes[0] \
         if (a.isolated_steps > 0 and len(lanes) > 1) else lanes.lanes[0]
+    plain_sort = None   # the same-view rates WITHOUT the carried depth order (the five-launch sort every frame)
+    if carry and world == 1:
+        with carried_order_off(lanes.lanes):
+            for _ in range(2 * len(lanes)):
+                one_step(lanes.next_lane())
+            p4 = timed(a.steps, a.warmup, lanes.next_lane, events=False)
+        plain_sort = {"value": round(a.steps / p4[0], 3), "unit": "frames/s", "frames_in_flight_per_gpu": len(lanes)}
+        for _ in range(2 * len(lanes)):
+            one_step(lanes.next_lane())
     if a.isolated_steps > 0:
         for _ in range(8):
             one_step(iso_lane)
         iso = timed(a.isolated_steps, 3, lambda: iso_lane)
         prof = timed(a.isolated_steps, 3, lambda: iso_lane, profile=True)
+        if plain_sort is not None:
+            with carried_order_off([iso_lane]):
+                for _ in range(3):
+                    one_step(iso_lane)
+                p1 = timed(a.isolated_steps, 3, lambda: iso_lane)
+                p1p = timed(a.isolated_steps, 3, lambda: iso_lane, profile=True)
+            plain_sort["isolated_value"] = round(a.isolated_steps / p1[0], 3)
+            plain_sort["isolated_depth_sort_ms"] = round(p1p[1].get("depth_sort", 0.0), 4)
+            for _ in range(3):
+                one_step(iso_lane)
         if world == 1 and not a.no_extra_legs:
             # non-coherent frames: the camera changes EVERY step (eight arc views, yaw -14 .. +14 degrees), so a lane's
             # tile-order hint comes from another view and nothing of the previous frame can be reused
             view_cycle[0] = [device_inputs(sc, c_, dev)[1] for c_ in (arc_cameras(W, H, n=8) if room is None else room.cameras)]
             step_no[0] = 0
-            nc4 = timed(a.steps, a.warmup, lanes.next_lane, events=False)
-            nc1 = timed(a.isolated_steps, 3, lambda: iso_lane)
+            with carried_order_off(lanes.lanes, [iso_lane]):
+                nc4 = timed(a.steps, a.warmup, lanes.next_lane, events=False)
+                nc1 = timed(a.isolated_steps, 3, lambda: iso_lane)
             view_cycle[0] = None
             nonco = {"what": "the camera changes every step (8 arc views, yaw -14..+14 deg, 0.15 m apart): the tile-order hint "
                              "a lane carries belongs to another view",
                      "value": round(a.steps / nc4[0], 3), "unit": "frames/s", "frames_in_flight_per_gpu": len(lanes),
-                     "isolated_value": round(a.isolated_steps / nc1[0], 3),
+                     "isolated_value": round(a.isolated_steps / nc1[0], 3), "carried_depth_order": False,
                      "overflow": bool(any(l_[0].rendered()[1] for l_ in lanes.lanes))}
             # (back to the coherent steady state for the legs below)
             for _ in range(2 * len(lanes)):
@@ -1356,8 +1430,8 @@ def main():
             dom = max(comp, key=comp.get)
             t_s = av[dom] * 1e-3
             achieved = model[dom] / t_s / 1e9
-            traffic, traffic_src = measured_traffic(dom, F) if a.config == 3 else (None, None)
-            valu, valu_src = measured_valu(dom, F) if a.config == 3 else (None, None)
+            traffic, traffic_src = measured_traffic(dom, F, a.scene, a.config)
+            valu, valu_src = measured_valu(dom, F, a.scene, a.config)
             r = {"bound": "valu", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                  "traffic_source": traffic_src, "units": {"instances_processed": Rr, "pixels": N},
@@ -1406,8 +1480,13 @@ def main():
                                     f"{sc.P} Gaussians of {room.keyframes} keyframes, {W}x{H}, RGB+depth+{F} ") +
                                    f"language channels, forward+backward, tile 15, backward mode {a.mode}; "
                                    f"{a.setup_steps} untimed set-up frames precede the warm-up (allocations, tile-order "
-                                   "hints, clocks)",
+                                   "hints, clocks)" +
+                                   ("; every lane carries its view's depth order from its previous frame (repaired in two launches, "
+                                    "the radix passes as the device-side fall-back: lists bit-identical; `carried_depth_order`)"
+                                    if carry else ""),
                        "scene": a.scene,
+                       "carried_depth_order": {"on": carry, "same_view_rates_without": plain_sort,
+                                               "missed_last_frame": bool(ws0.carry_missed()) if carry else None},
                        "value_runs": {"runs": len(run_fps), "steps_per_run": a.steps,
                                       "timed_seconds_total": round(sum(r_[0] for r_ in runs), 3),
                                       "median": round(sorted(run_fps)[len(run_fps) // 2], 3),
@@ -1454,6 +1533,21 @@ def main():
             if a.config == 3 and room is None:
                 out["config4_substitute"] = config4_substitute(sc, g_dev, dev, dims)
                 out["config4_substitute"]["room_scene"] = room_scene_leg(dev, dims, a.isolated_steps)
+        # the driver keeps `config` and `roofline` of this line: the rates a caller sees, beside the headline's
+        out["config"]["isolated_fps"] = out["isolated"]["value"] if iso is not None else None
+        out["config"]["dropin_fps"] = out["dropin"]["value"] if "dropin" in out else None
+        out["config"]["non_coherent_fps"] = nonco["value"] if nonco is not None else None
+        out["config"]["frame_model_frac"] = frame["frac_of_8TBs_wall"]
+        if roof is not None:
+            roof["frame_model"] = {"frac": frame["frac_of_8TBs_wall"], "algorithmic_bytes": frame["algorithmic_bytes"]}
+        rs_ = out.get("config4_substitute", {}).get("room_scene")
+        if rs_:
+            out["config"]["room_scene"] = {"isolated_fps": rs_["isolated"]["value"], "four_in_flight_fps": rs_["four_in_flight"]["value"],
+                                           "four_in_flight_cycling_12_views_fps": rs_["four_in_flight_cycling_12_views"]["value"],
+                                           "tracking_ms": rs_["tracking"]["ms_per_iteration"],
+                                           "mapping_ms": {k: v["ms_per_iteration"] for k, v in rs_.get("mapping", {}).items()
+                                                          if isinstance(v, dict) and "ms_per_iteration" in v},
+                                           "stage_ms": rs_.get("stage_ms")}
         if world == 1 and not a.no_cpu_baseline:
             lane0 = iso_lane
             one_step(lane0)

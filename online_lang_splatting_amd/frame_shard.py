@@ -737,9 +737,23 @@ class FrameLanes:
             kw = dict(kw, flags=int(kw.get("flags", 0)) | _abi.FLAG_FRAMES_IN_FLIGHT)
         for i in range(max(1, int(n))):
             ws = RasterWorkspace(P, W, H, F, M, capacity, device, **kw)
-            stream = torch.cuda.current_stream(self.device) if i == 0 else torch.cuda.Stream(self.device)
+            stream = torch.cuda.current_stream(self.device) if i == 0 else self.lane_stream(self.device, i)
             self.lanes.append((ws, GradientBucket(P, GradLayout(M, F), device, track_rows=track_rows), stream))
         self._next = 0
+
+    # Lane i of EVERY FrameLanes of a process runs on the same HIP stream (round 6).  A process has four hardware queues to give
+    # (streams beyond them share queues, and a four-lane loop then runs 12 % slower until the process
+    # ends); objects that each created their own streams — a benchmark's second scene, a mapping step beside a headline loop —
+    # pushed later loops past that.  Sets of lanes are used one after the other, so sharing the streams orders nothing that
+    # was concurrent.
+    _lane_streams: Dict = {}
+
+    @classmethod
+    def lane_stream(cls, device, i):
+        key = (torch.device(device).index or 0, int(i))
+        if key not in cls._lane_streams:
+            cls._lane_streams[key] = torch.cuda.Stream(torch.device(device))
+        return cls._lane_streams[key]
 
     def __len__(self):
         return len(self.lanes)
