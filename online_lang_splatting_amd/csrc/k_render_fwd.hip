@@ -37,6 +37,11 @@ constexpr int FWD_BATCH = 128;
 #ifndef OLSR_FWD_WAVES
 #define OLSR_FWD_WAVES 7  // waves per SIMD the default accumulation is compiled for at F <= 16 (8: spills, measured slower)
 #endif
+#ifndef OLSR_FWD_LOSS1_WAVES
+#define OLSR_FWD_LOSS1_WAVES 6  // ... and the mapping-loss epilogue at F = 15 / 16: 7 left 8 - 12 bytes of scratch per lane in the
+                                // epilogue; 6 has none and measures the same (12-view mapping iteration, room 3.325 / 3.331 ms,
+                                // volume 6.41 / 6.44 ms, scripts/probe/mapping_time.py)
+#endif
 #ifndef OLSR_FWD_ACC2_WAVES
 #define OLSR_FWD_ACC2_WAVES 7  // waves per SIMD the weight-accumulation variant is compiled for
 #endif
@@ -66,7 +71,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // CUT:  the per-tile depth cut-off bookkeeping (include/olsr.h) — its own instantiation: carried as a run-time test it cost the
 //       plain kernel 4 % (0.1588 -> 0.1647 ms at config 3, two more live scalars across the entry loop).
 template <int TILE, int F, int ACC, int LOSS, bool CUT>
-__global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FWD_ACC2_WAVES : OLSR_FWD_WAVES)) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
+__global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FWD_ACC2_WAVES : ((LOSS == 1 && F >= 15) ? OLSR_FWD_LOSS1_WAVES : OLSR_FWD_WAVES))) : (ACC == 1 ? 4 : 5))) void render_fwd_kernel(
     const u32* ranges, u32* ranges_rw, const u32* __restrict__ inst_gid, const u32* __restrict__ src, int W, int H,
     int gx, int ntiles, const float* __restrict__ means2D, const float* __restrict__ conic_opacity,
     const float* __restrict__ depths, const float* __restrict__ colors, const float* __restrict__ lang,
@@ -315,10 +320,23 @@ __global__ __launch_bounds__(256, (F <= 16 ? (ACC == 1 ? 5 : (ACC == 2 ? OLSR_FW
             if constexpr (TILE == 15) rec |= ((contrib_m & cls_m0) ? 0x100u : 0u) | ((contrib_m & cls_m1) ? 0x200u : 0u);
             if (lane0) reinterpret_cast<uint16_t*>(s_hit)[4 * jj + w] = (uint16_t)rec;
           }
+#ifndef OLSR_FWD_INNER_BREAK
+          // (no exit between the two entries of a pair: once every pixel of the wave is saturated `live` is empty, the second
+          //  entry blends nothing, records nothing and changes no T — and the loop leaves below.  The break that stood here
+          //  cost every blending entry ~12 scalar instructions of the structuriser's exit encoding.  The cut-off variant needs
+          //  the entry at which the wave saturated.)
+          if constexpr (CUT) {
+            if (done_m == ~0ull) {
+              my_stop = base + jj;
+              break;
+            }
+          }
+#else
           if (done_m == ~0ull) {
             if constexpr (CUT) my_stop = base + jj;
             break;
           }
+#endif
         }
         if (done_m == ~0ull) break;
       }

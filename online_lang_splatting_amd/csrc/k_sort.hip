@@ -318,7 +318,10 @@ __device__ __forceinline__ void lds_store(u32* p, u32 v) { *reinterpret_cast<vol
 constexpr int FSF_IDENTITY = 1, FSF_NO_KEYS = 2, FSF_RANGES = 4, FSF_EMIT_TOTALS = 8;
 
 template <int DB, int KPT, int T>
-__global__ __launch_bounds__(T, (T == 1024 ? (KPT <= 8 ? 8 : 4) : (KPT <= 8 ? 8 : 6))) __attribute__((amdgpu_num_sgpr(80))) void sort_pass_kernel(const u32* __restrict__ keys_in,
+// (waves per SIMD the register allocation aims for: a sixteen-wave block of four or more keys per thread holds 52 - 150 KB of LDS,
+//  so at most one or two of them share a CU — 4 waves per SIMD and 128 VGPRs; round 5 asked for 8 there and paid with 6 - 28
+//  spilled VGPRs per lane on the shapes sort_plan picks for 1 M - 4 M keys: config 5's depth sort)
+__global__ __launch_bounds__(T, (T == 1024 ? (KPT <= 2 ? 8 : 4) : (KPT <= 8 ? 8 : 6))) __attribute__((amdgpu_num_sgpr(80))) void sort_pass_kernel(const u32* __restrict__ keys_in,
                                                          const u32* __restrict__ vals_in, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int shift,
                                                          const u32* __restrict__ ghist, u16* status, u32* ticket,

@@ -192,8 +192,16 @@ __device__ __forceinline__ float lane_read(float v, int lane) {
 // scale by 2^n.  The oracle clamps to [-87, 88] so 2^n is a normal number; here only the lower clamp is
 // kept (one v_max_f32): both composites discard the result whenever power > 0 (CR/forward.cu:457-458), so
 // arguments above 88 are never consumed, and for every consumed argument the bits equal the oracle's.
+// max(x, -87) as ONE v_max_f32.  __builtin_fmaxf costs two: the compiler puts a canonicalising v_max_f32 x, x in front, because
+// maxNum must quiet a signalling NaN operand and it cannot see that x is an arithmetic result; the instruction itself, in the
+// IEEE mode kernels run in, returns the other operand for any NaN.  Same bits for every input that is not a signalling NaN.
+__device__ __forceinline__ float max_m87(float x) {
+  float r;
+  asm("v_max_f32 %0, 0xc2ae0000, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ float pinned_expf(float x) {
-  x = __builtin_fmaxf(x, -87.0f);
+  x = max_m87(x);
   float n = __builtin_rintf(x * 1.44269504088896341f);
   float r = __builtin_fmaf(n, -0.693359375f, x);
   r = __builtin_fmaf(n, 2.12194440e-4f, r);
@@ -211,8 +219,8 @@ __device__ __forceinline__ float pinned_expf(float x) {
 // the same routine on two values at once (packed fp32: every component is the IEEE operation of pinned_expf)
 typedef float v2f_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f_ pinned_expf2(v2f_ x) {
-  x.x = __builtin_fmaxf(x.x, -87.0f);
-  x.y = __builtin_fmaxf(x.y, -87.0f);
+  x.x = max_m87(x.x);
+  x.y = max_m87(x.y);
   const v2f_ t = x * v2f_{1.44269504088896341f, 1.44269504088896341f};
   const v2f_ n = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
   v2f_ r = __builtin_elementwise_fma(n, v2f_{-0.693359375f, -0.693359375f}, x);

@@ -197,7 +197,7 @@ class MappingStep:
 
     def __init__(self, lanes: FrameLanes, params: Dict[str, torch.Tensor], bg: torch.Tensor, sh_degree: int,
                  cameras: Sequence[Dict], targets: Sequence, lrs: Dict[str, float], exposure=None,
-                 activations=_abi.ACT_ALL, fused_loss="auto", view_ids: Optional[Sequence] = None, carry_order: bool = True):
+                 activations=_abi.ACT_ALL, fused_loss="auto", view_ids: Optional[Sequence] = None, carry_order: Optional[bool] = None):
         """targets[v] = (gt_image [3,H,W], gt_depth [H,W], gt_language [F,h,w] or None).
         fused_loss: True — the mapping loss is evaluated in the forward composite's epilogue (olsr_forward_async_loss); False —
         olsr_forward_async + olsr_mapping_loss (two kernels; the same cotangents bit for bit, the loss value to summation order);
@@ -211,7 +211,11 @@ class MappingStep:
         carry_order (round 6): every view also keeps its DEPTH order of the previous iteration (include/olsr.h "Carried depth
         order"; 4 P bytes per view): an Adam step moves the Gaussians by a fraction of a millimetre, so the forward repairs that
         order in two launches instead of sorting from scratch in five dependent ones, and falls back to the sort on the device
-        when it cannot prove the result — parameters are bit-identical either way (tests/test_gpu_order_carry.py)."""
+        when it cannot prove the result — parameters are bit-identical either way (tests/test_gpu_order_carry.py).
+        None (default) = on with ONE lane only: measured (scripts/probe/mapping_time.py, 12 views, 500 k Gaussians) it takes
+        2.5 % off the iteration on the room map and 1.8 % on the volume with one view in flight (4.77 -> 4.65 ms, 8.62 -> 8.46 ms),
+        nothing with two, and costs 0.5 % with four — other lanes' composites already hide the sort's dependent launches, and
+        the repair's own work is then extra."""
         self.lanes, self.params, self.bg, self.sh_degree = lanes, params, bg, sh_degree
         self.cameras, self.lrs, self.exposure, self.act = cameras, lrs, exposure, activations
         self.view_ids = view_ids
@@ -236,7 +240,7 @@ class MappingStep:
         # (keyed by a stable view id and created lazily — ADVICE round 4: a list sized at construction broke when the window grew)
         self.view_hints: Dict = {}
         self._hint_proto = ws0.tile_order.clone()
-        self.carry_order = bool(carry_order)
+        self.carry_order = (len(lanes) == 1) if carry_order is None else bool(carry_order)
         self.view_orders: Dict = {}   # view id -> int32[P], the view's depth order of its last iteration (zeros: none yet)
 
     @property
@@ -332,12 +336,14 @@ class MappingStep:
         from .frame_shard import GradientBucket
         multi = GradientBucket._multi()
         mark("lane_sum:begin", main)
-        for b in used[1:]:
+        for i, b in enumerate(used[1:], 1):
             if multi:   # an exchange follows: it needs the total in one place (only the rows b's row mask flags move)
                 total.add_bucket(b)
-            else:       # one process: only the small densification statistics are summed, Adam adds the gradient rows itself
+            elif i < 8:  # one process: only the small densification statistics are summed, Adam adds the gradient rows itself
                 total.densify.add_(b.densify)
                 torch.maximum(total.max_radii, b.max_radii, out=total.max_radii)
+            # (lanes beyond the eighth are folded into the first bucket below by add_bucket, which sums their statistics
+            #  and radii as well — adding them here too counted them twice: ADVICE round 5, medium)
         mark("lane_sum:end", main)
         total.all_reduce()
         mark("adam:begin", main)

@@ -144,11 +144,16 @@ def test_mapping_step_measures_its_loss_form_and_keeps_per_view_hints_across_a_s
     for nl, lanes_ in ((9, lanes9), (3, FrameLanes(3, sc.P, W, H, F, 1, 300_000, dev))):
         p = {k: v.clone() for k, v in start.items()}
         st = MappingStep(lanes_, p, sc.bg.to(dev), 0, views9, tg9, lrs, exposure=torch.zeros(2, device=dev), fused_loss=True)
-        st.iteration()
+        tot = st.iteration()
         torch.cuda.synchronize()
-        res[nl] = p
+        res[nl] = (p, tot.densify.clone(), tot.max_radii.clone())
     for k in start:   # (the sum over nine views associates differently with nine lanes than with three: to rounding)
-        assert torch.allclose(res[9][k], res[3][k], rtol=1e-4, atol=1e-6), k
+        assert torch.allclose(res[9][0][k], res[3][0][k], rtol=1e-4, atol=1e-6), k
+    # the densification statistics of the step (xyz_gradient_accum, denom, max_radii2D): every lane counted ONCE, also the ones
+    # beyond the eight the Adam kernel sums (the fold of lanes 9+ used to add their statistics a second time)
+    assert torch.equal(res[9][1][:, 1], res[3][1][:, 1])   # denom: an integer count per Gaussian
+    assert torch.allclose(res[9][1][:, 0], res[3][1][:, 0], rtol=1e-5, atol=1e-9)
+    assert torch.equal(res[9][2], res[3][2])
 
 
 def test_tracking_loop_can_leave_the_final_images_behind(hip, oracle):
