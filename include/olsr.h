@@ -665,6 +665,28 @@ void olsr_debug_sort_small(int enable);
  * cost four tiny launches per frame.  NULL switches it off. */
 void olsr_debug_composite_stamps(unsigned long long *device_buffer, int capacity);
 
+/* Test instrument (round 6; never on a product path): the composite backward — CR/backward.cu:932-1201 (language_render_cuda),
+ * 706-930 (renderCUDA), 684-702 (render_cuda_reduce_sum) — restated on the GPU in the reference's OWN association: its per-lane
+ * state and expressions in source order, the 225-lane integer-halving tree through shared memory in the tree's own pairing
+ * (OLSR_BWD_REFERENCE; lane order in double for OLSR_BWD_EXACT, like the oracle), one row per instance the tile does not skip,
+ * a Gaussian's rows added one after the other in sorted-list order.  It runs on the state buffers a forward left (either
+ * entry; num_rendered as for olsr_backward) and writes the composite-level gradients only: dL_dmeans2D [P,3], dL_dconic [P,4],
+ * dL_dopacity [P], dL_dcolors [P,3], dL_dlanguage [P,F], dL_ddepths [P].  These EQUAL the CPU oracle's bit for bit
+ * (tests/test_gpu_bwd_ordered.py); the product's fast kernel, which re-associates the same sums, is compared with this one on the
+ * GPU at sizes the oracle needs minutes for.  scene->bwd_mode and tile select the variant; a NULL language / depth cotangent
+ * counts as zeros.  scratch: olsr_debug_backward_ordered_scratch_bytes(num_rendered, F) bytes.  Tens of milliseconds per frame.
+ * condition != 0: the outputs are not the gradients but their CONDITION A — the same sums with every product replaced by the
+ * product of magnitudes and every difference by the sum of magnitudes.  To first order any re-association of the sums and
+ * any few-ulp variation of the value path moves an element by at most K x 2^-24 x A, K of the order of the operations a term
+ * went through; the tests hold the fast kernel to that, element by element ("it differs by rounding only"). */
+size_t olsr_debug_backward_ordered_scratch_bytes(int64_t num_rendered, int32_t F);
+int olsr_debug_backward_ordered(const olsr_scene *scene, const void *geometry_buffer, int32_t num_rendered,
+                                const void *binning_buffer, const void *image_buffer,
+                                const float *dL_dout_color, const float *dL_dout_language, const float *dL_dout_depth,
+                                void *scratch,
+                                float *dL_dmeans2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
+                                float *dL_dlanguage, float *dL_ddepths, int32_t condition, void *hip_stream);
+
 /* Test / experiment knob: threads per workgroup of the radix passes and their histogram kernels.  0 (default): the call
  * decides — 1024, or 256 for a scene that carries OLSR_FLAG_FRAMES_IN_FLIGHT; 256 / 1024: forced for every later forward.
  * Any other argument only reads the value back.  Same lists bit for bit.  Process-wide; seeded once from OLSR_SORT_THREADS.

@@ -30,6 +30,7 @@ UNITS = [
     ("k_render_fwd.hip", "k_render_fwd_loss.o", ["-DOLSR_FWD_TU_LOSS=1"]),
     ("k_render_bwd.hip", "k_render_bwd_ref.o", ["-DOLSR_BWD_TU_MODE=0"]),
     ("k_render_bwd.hip", "k_render_bwd_exact.o", ["-DOLSR_BWD_TU_MODE=1"]),
+    ("k_render_bwd_ordered.hip", "k_render_bwd_ordered.o", []),
     ("k_preprocess_bwd.hip", "k_preprocess_bwd.o", []),
     ("k_accumulate.hip", "k_accumulate.o", []),
     ("k_loss.hip", "k_loss.o", []),

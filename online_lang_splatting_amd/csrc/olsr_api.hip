@@ -1089,6 +1089,43 @@ int olsr_debug_sort_plan(int64_t n, int n_is_capacity, int32_t* keys_per_thread,
   return fused_sort_applicable(n, 32) ? 1 : 0;
 }
 
+size_t olsr_debug_backward_ordered_scratch_bytes(int64_t num_rendered, int32_t F) {
+  if (num_rendered < 0 || !supported_F(F)) return 0;
+  return align_up((size_t)num_rendered * (size_t)grad_row(F) * sizeof(float)) + align_up((size_t)num_rendered) + 2 * ALIGN;
+}
+
+int olsr_debug_backward_ordered(const olsr_scene* scene, const void* geometry_buffer, int32_t num_rendered,
+                                const void* binning_buffer, const void* image_buffer, const float* dL_dout_color,
+                                const float* dL_dout_language, const float* dL_dout_depth, void* scratch, float* dL_dmeans2D,
+                                float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dlanguage,
+                                float* dL_ddepths, int32_t condition, void* hip_stream) {
+  int rc = check_scene(scene, true);
+  if (rc != OLSR_OK) return rc;
+  const olsr_scene& s = *scene;
+  if (s.bwd_mode != OLSR_BWD_REFERENCE && s.bwd_mode != OLSR_BWD_EXACT)
+    return fail(OLSR_ERR_ARG, "bwd_mode must be OLSR_BWD_REFERENCE or OLSR_BWD_EXACT");
+  if (s.P <= 0) return OLSR_OK;
+  if (!geometry_buffer || !binning_buffer || !image_buffer || num_rendered < 0 || !scratch || !dL_dout_color || !dL_dmeans2D ||
+      !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_ddepths || (s.F > 0 && !dL_dlanguage))
+    return fail(OLSR_ERR_ARG, "ordered backward: state buffers, scratch, dL_dout_color and the six outputs are required");
+  const FrameDims d = frame_dims(s);
+  size_t gb, ib, bb;
+  const GeometryState g = GeometryState::carve(const_cast<void*>(geometry_buffer), (size_t)s.P, grad_row(s.F), gb);
+  const ImageState im = ImageState::carve(const_cast<void*>(image_buffer), (size_t)d.W * d.H, (size_t)d.ntiles, ib);
+  const BinningState b = BinningState::carve(const_cast<void*>(binning_buffer), (size_t)num_rendered, bb);
+  float* rows = (float*)(((uintptr_t)scratch + ALIGN - 1) / ALIGN * ALIGN);
+  uint8_t* used = (uint8_t*)rows + align_up((size_t)num_rendered * (size_t)grad_row(s.F) * sizeof(float));
+  launch_render_backward_ordered(s, d, g, b, im, num_rendered, dL_dout_color, dL_dout_language, dL_dout_depth, rows, used,
+                                 dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dlanguage, dL_ddepths, condition != 0,
+                                 (hipStream_t)hip_stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OLSR_ERR_DEVICE, std::string("ordered backward launch: ") + hipGetErrorString(e));
+  (void)gb;
+  (void)ib;
+  (void)bb;
+  return OLSR_OK;
+}
+
 const char* olsr_last_error(void) { return g_err.c_str(); }
 const char* olsr_version(void) { return "olsr 0.1 (gfx950)"; }
 

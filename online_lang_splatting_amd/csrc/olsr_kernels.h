@@ -162,6 +162,13 @@ void launch_render_backward_exact(const olsr_scene& s, int F_rows, const FrameDi
                                   const BinningState& b, const ImageState& im, const float* dL_dcolor,
                                   const float* dL_dlanguage, const float* dL_ddepth, float* rows, hipStream_t st);
 
+// k_render_bwd_ordered.hip — test instrument: the composite backward in the reference's own association (olsr_debug_backward_ordered)
+void launch_render_backward_ordered(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
+                                    const ImageState& im, int64_t num_rendered, const float* dL_dcolor,
+                                    const float* dL_dlanguage, const float* dL_ddepth, float* rows, uint8_t* used,
+                                    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
+                                    float* dL_dlanguage_out, float* dL_ddepths, bool condition, hipStream_t st);
+
 // k_preprocess_bwd.hip
 struct GradOut {
   float *dL_dmeans2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_dlanguage, *dL_ddepths, *dL_dmeans3D, *dL_dcov3D,

@@ -130,3 +130,86 @@ def assert_elementwise(a, b, name, worst_bound, log=None, min_fraction=ELEM_MIN_
     assert r["frac_within"] >= min_fraction or n_out <= allow_outliers, "element-wise criterion: " + line
     assert r["worst"] <= worst_bound, f"worst element above {worst_bound:g}: " + line
     return r
+
+
+COMPOSITE_KEYS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dlanguage", "dL_ddepths")
+
+
+def ordered_backward(hip, sc, fwd, seed, tile, mode, dev=None, cotangents=None, condition=False, **kw):
+    """Composite-level gradients of the ORDERED kernel (olsr_debug_backward_ordered: the composite backward in the reference's own
+    association, csrc/k_render_bwd_ordered.hip) on the state buffers `fwd` (run_backend's forward dict of the product);
+    condition=True: their condition A instead (the same sums over magnitudes).  **kw as run_backend / fwd_args take them."""
+    from online_lang_splatting_amd import _abi
+    from online_lang_splatting_amd._lib import check, lib
+    import ctypes as C
+    dev = torch.device(dev or "cuda:0")
+    F = max(sc.F, 0)
+    a = fwd_args(sc, dev, **kw)
+    off = 1 if F > 0 else 0
+    bg, means3D, colors = a[0], a[1], a[2]
+    language = a[3] if F > 0 else None
+    opacity, scales, rotations, scale_modifier, cov3D = a[3 + off], a[4 + off], a[5 + off], a[6 + off], a[7 + off]
+    view, proj, proj_raw, tanx, tany, H, W, sh, degree, campos = a[8 + off:18 + off]
+    s, keep = hip._scene(F, bg, means3D, colors, language, opacity, scales, rotations, scale_modifier, cov3D, view, proj,
+                         proj_raw, tanx, tany, H, W, sh, degree, campos, False, False,
+                         cfg=(tile, mode, _abi.BINNING_ELLIPSE))
+    dc, dl, dd = cotangents if cotangents is not None else sc.cotangents(seed)
+    dc, dl, dd = [None if t is None else t.to(dev).contiguous() for t in (dc, dl, dd)]
+    P, R = sc.P, int(fwd["R"])
+    f32 = dict(dtype=torch.float32, device=dev)
+    L = lib()
+    scratch = torch.empty(L.olsr_debug_backward_ordered_scratch_bytes(R, F), dtype=torch.uint8, device=dev)
+    g = dict(dL_dmeans2D=torch.empty(P, 3, **f32), dL_dconic=torch.empty(P, 2, 2, **f32), dL_dopacity=torch.empty(P, 1, **f32),
+             dL_dcolors=torch.empty(P, 3, **f32), dL_dlanguage=torch.empty(P, F, **f32), dL_ddepths=torch.empty(P, 1, **f32))
+    p = lambda t: t.data_ptr() if t is not None and t.numel() > 0 else None  # noqa: E731
+    check(L.olsr_debug_backward_ordered(
+        C.byref(s), fwd["geom"].data_ptr(), R, fwd["binning"].data_ptr(), fwd["img"].data_ptr(), p(dc), p(dl), p(dd),
+        scratch.data_ptr(), p(g["dL_dmeans2D"]), p(g["dL_dconic"]), p(g["dL_dopacity"]), p(g["dL_dcolors"]),
+        p(g["dL_dlanguage"]), p(g["dL_ddepths"]), 1 if condition else 0,
+        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    torch.cuda.synchronize(dev)
+    return g
+
+
+def same_bits(a, b):
+    a, b = a.detach().cpu().float().reshape(-1), b.detach().cpu().float().reshape(-1)
+    return bool(((a == b) | (a.isnan() & b.isnan())).all())
+
+
+def assert_ordered_equals_oracle(go, gord, where=""):
+    for k in COMPOSITE_KEYS:
+        if go[k].numel():
+            a, b = gord[k].cpu().reshape(-1), go[k].reshape(-1)
+            if not same_bits(a, b):
+                bad = (a != b) & ~(a.isnan() & b.isnan())
+                i = int(bad.nonzero()[0])
+                raise AssertionError(f"{where}{k}: {int(bad.sum())} of {a.numel()} elements differ from the oracle, first at {i}: "
+                                     f"{float(a[i])!r} vs {float(b[i])!r}")
+
+
+
+
+def assert_rounding_only(gfast, gord, gcond, k_bound=None, log=None, name=""):
+    """The fast composite backward differs from the reference's association BY ROUNDING ONLY: every element of every
+    composite-level gradient lies within K x 2^-24 x A of the ordered kernel's, A = the element's condition (the same sums
+    over magnitudes, ordered_backward(condition=True)).  Returns / logs the largest K per tensor; k_bound asserts it."""
+    eps = 2.0 ** -24
+    worst = {}
+    for k in COMPOSITE_KEYS:
+        if not gord[k].numel():
+            continue
+        a, b, c = (t.detach().double().cpu().reshape(-1) for t in (gfast[k], gord[k], gcond[k]))
+        d = (a - b).abs()
+        assert bool(torch.isfinite(d).all()), k
+        # (an element whose condition is zero has no term at all: both kernels must give exactly zero there)
+        zero = c == 0
+        assert bool((d[zero] == 0).all()), f"{name}{k}: a difference where no term contributes"
+        K = (d[~zero] / (eps * c[~zero])).max().item() if bool((~zero).any()) else 0.0
+        worst[k] = K
+        if log is not None:
+            log.append(dict(name=f"{name}rounding_only:{k}", K_max=K, n=int(a.numel())))
+    line = "rounding-only K: " + " ".join(f"{k[3:]}={v:.1f}" for k, v in worst.items())
+    print(line)
+    if k_bound is not None:
+        assert all(v <= k_bound for v in worst.values()), line
+    return worst
