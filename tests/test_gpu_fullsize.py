@@ -25,9 +25,15 @@ from test_gpu_parity import _check
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the worst single element, in the relative units of parity_common.elementwise_report (1e-4 == within tolerance):
-# end to end (tensors behind the per-Gaussian chain; measured worst 4.7e-3, config 5 view 2) and — through _check's
-# composite_worst_bound = 2e-4 — at composite level (measured worst 8.1e-5)
+# Round 6: the backward is closed without a tolerance of its own.  (i) The composite backward in the reference's own
+# association, on the GPU (olsr_debug_backward_ordered), EQUALS the oracle's composite-level gradients bit for bit at every
+# full config; (ii) the product's fast kernel differs from it by ROUNDING ONLY — every element of every composite-level tensor
+# within K x 2^-24 x its condition (the same sums over magnitudes), K <= 36 measured here (bound 64; config 3's one dL_dconic
+# element at 1.1e-4 of its value sits at K = 3.4: three terms of order 1e8 cancel); (iii) the per-Gaussian chain behind them is
+# exact on identical inputs.  What remains below is the north-star criterion itself and a sanity bound on the worst single
+# element behind the chain, in the relative units of parity_common.elementwise_report (1e-4 == within tolerance): the chain
+# amplifies composite-level rounding behind the inverse of the 2D covariance (measured worst 4.7e-3, config 5 view 2; 1.1e-4
+# at composite level, through _check's composite_worst_bound = 2e-4).
 WORST_BOUND = 1e-2
 
 
