@@ -48,8 +48,9 @@ extern "C" {
  * never hangs on that and never writes out of bounds, but the tile lists are garbage: the forward's images must not be used,
  * the backward writes zero gradients.  The synchronising olsr_backward (scratch_alloc != NULL) returns OLSR_ERR_DEVICE; for
  * olsr_forward and for an olsr_backward without status_dev (the reference-shaped bindings) the frame's last kernel raises a
- * flag in mapped host memory and the FIRST olsr_forward / olsr_backward after the GPU got there returns OLSR_ERR_DEVICE
- * (once), the way an asynchronous HIP error surfaces. */
+ * flag in mapped host memory and the FIRST olsr_forward / olsr_backward ON THE SAME DEVICE AND STREAM after the GPU got there
+ * returns OLSR_ERR_DEVICE (once), the way an asynchronous HIP error surfaces (round 6: the flag is keyed by device and stream —
+ * up to 63 pairs, further ones share one word —, so a broken frame on one stream does not fail healthy calls on another). */
 #define OLSR_STATUS_OK 0
 #define OLSR_STATUS_OVERFLOW 1
 #define OLSR_STATUS_SYNC_ERROR 2
@@ -338,6 +339,10 @@ int64_t olsr_live_rows(int32_t token, int32_t packed_survivor_waves);
  * Returns the row count or -1 (then size by the bound).  The drop-in bindings call it when the bound would cost more than
  * 64 MB of scratch (OLSR_ROWS_WAIT_US, read once at load, default 5000; 0: never wait). */
 int64_t olsr_live_rows_wait(int32_t token, int32_t packed_survivor_waves, int32_t timeout_us);
+/* 1 when the ring slot of `token` already belongs to a LATER forward (more than 255 forwards were issued before this
+ * backward): the count will never be readable, so a caller sizes its scratch by the bound at once instead of guessing and
+ * then waiting for a count that cannot arrive. */
+int32_t olsr_live_rows_overwritten(int32_t token);
 /* The bindings' policy in one call: rows to size the backward scratch of (token, R instances, F) with. */
 int64_t olsr_backward_rows(int32_t token, int32_t packed_survivor_waves, int64_t num_rendered, int32_t F);
 int olsr_backward(const olsr_scene *scene, const int32_t *radii,

@@ -276,7 +276,9 @@ def _backward(F, bg, means3D, radii, colors, language, scales, rotations, scale_
         guessed = False
         if rows < 0 or rows > bound:
             ratio = _ROWS_PER_INSTANCE[1 if packed else 0]
-            if rows_token > 0 and ratio > 0 and R > 0 and L.olsr_backward_scratch_bytes(bound, F) > (64 << 20):
+            if L.olsr_live_rows_overwritten(int(rows_token)):
+                rows = bound   # (the slot belongs to a later forward: no count will ever arrive)
+            elif rows_token > 0 and ratio > 0 and R > 0 and L.olsr_backward_scratch_bytes(bound, F) > (64 << 20):
                 rows = int(1.5 * ratio * R) + 65536          # (a multiple of 128 Ki rows: a stable size for the caching allocator)
                 rows, guessed = min(bound, (rows + 131071) // 131072 * 131072), True
             else:

@@ -884,6 +884,7 @@ __device__ __forceinline__ void row_compaction_block(const RowCompactionArgs& ra
       // (a frame whose depth cut-offs hid contributions — counters[9], OLSR_STATUS_CUT_MISS — hands out no gradients either;
       //  the backward's last kernel reports it as status 3)
       counters[7] = (ov != 0 || counters[9] != 0) ? 1 : 0;
+      counters[11] = rows_stamp_of(row_capacity);  // "compacted for a scratch of this many rows" (olsr_device.h: frame_unusable)
       if (status_dev) {
         status_dev[0] = (int32_t)L;
         status_dev[1] = ov;
@@ -1051,7 +1052,11 @@ __device__ __forceinline__ void tile_order_block(const TileOrderArgs& ta, const 
   if (order_copy != nullptr && hint_slot != nullptr) order_copy += (size_t)hint_slot[0] * (size_t)ntiles;
   dilate_depth_cuts(cd, (int)((by * 8 + bx) * 256 + threadIdx.x),
                     (int)(8 * ny * 256));
-  // the forward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
+  // the forward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here.
+  // (When this launch also compacts the backward's rows — forward_tail_kernel —, an error raised by THOSE blocks, a look-back
+  //  of the compaction that gives up, may come after this read: it is then reported by the backward of the frame, through
+  //  tau_final_kernel, like any error of a backward-side compaction; a forward that is never followed by a backward uses no
+  //  rows, so nothing of what it returned depends on them.  ADVICE round 5.)
   if (bx == 0 && by == 0 && threadIdx.x == 0 && counters[8] != 0) {
     if (num_rendered_dev != nullptr) num_rendered_dev[1] = 2;
     if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float*
                                                                     float* __restrict__ gacc,
                                                                     const uint4* __restrict__ big_list, int P,
                                                                     const u32* __restrict__ rowbase,
-                                                                    const int32_t* __restrict__ counters) {
+                                                                    const int32_t* __restrict__ counters, int rows_stamp) {
   constexpr int ROW = grad_row(F);
   constexpr int NVAL = 10 + F;
   constexpr int NP = next_pow2_(NVAL);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(RR_THREADS) void row_reduce_big_kernel(const float*
   const int wave = (int)(blockIdx.x * (RR_THREADS / 64) + (threadIdx.x >> 6));
   const int nwaves = (int)(gridDim.x * (RR_THREADS / 64));
   const int nbig = counters[5], count = nbig + counters[4];  // front list, then the medium list from the back
-  if (wave >= count || frame_unusable(counters)) return;
+  if (wave >= count || frame_unusable(counters, rows_stamp)) return;
   auto item_at = [&](int i) { return big_list[i < nbig ? i : P - 1 - (i - nbig)]; };
   // Most listed Gaussians lie behind the saturation depth of every tile they cover and have NO row (config 3: 65 k listed,
   // a few thousand with rows): such an item ends after its look-up — no butterfly, no gacc row (preprocess_bwd_kernel looks
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     float* __restrict__ dL_dtau, float* __restrict__ tau_partials, float* __restrict__ bucket_flat,
     float* __restrict__ bucket_densify, int32_t* __restrict__ bucket_max_radii, int bucket_assign, int act,
     const float* __restrict__ opacities_raw, int F_out, u64* __restrict__ bucket_row_mask, float* gacc_park,
-    u32* __restrict__ act_list, u32* __restrict__ act_count, const uint8_t* __restrict__ blended) {
+    u32* __restrict__ act_list, u32* __restrict__ act_count, const uint8_t* __restrict__ blended, int rows_stamp) {
   // F: language channels of the partial-gradient rows; F_out: the scene's (width of dL_dlanguage and of the bucket's
   // language columns).  F == 0 < F_out: the backward ran without a language cotangent, those gradients are zero.
   constexpr int ROW = grad_row(F);
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
     //  rows: all zeros, and the dependent look-ups below — emission index, two ends of its run of rows — are not made for it)
     const u32 ntiles_g = (vis && blended[idx] != 0) ? tiles_touched[idx] : 0u;
     if (ntiles_g > OLSR_MID_FOOTPRINT) {
-      if (!frame_unusable(counters)) {  // summed by row_reduce_big_kernel
+      if (!frame_unusable(counters, rows_stamp)) {  // summed by row_reduce_big_kernel
         // (looked up since the chain below is skipped without rows: a large footprint behind the saturation depth has none)
         const u32 u0 = inst_start[idx];
         has_rows = rowbase[u0 + ntiles_g] != rowbase[u0];
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(PB_THREADS) void preprocess_bwd_kernel(
           if (4 * v4 + 3 < NVAL) acc[4 * v4 + 3] = has_rows ? x.w : 0.f;
         }
       }
-    } else if (ntiles_g > 0 && !frame_unusable(counters)) {
+    } else if (ntiles_g > 0 && !frame_unusable(counters, rows_stamp)) {
       // the Gaussian's partial-gradient rows are one dense run (emission order): sum them here, in ascending
       // (tile, wave) order — no intermediate per-Gaussian buffer
       const u32 u0 = inst_start[idx];
@@ -932,9 +932,12 @@ __global__ __launch_bounds__(TAU_T) void tau_final_kernel(const float* __restric
   // rows compacted by the forward's last launch (olsr_scene.backward_row_capacity): what launch_row_compaction would have
   // told the caller — {live rows, row / instance overflow}; a cut-off miss (counters[9], folded into counters[7]) is
   // reported as 3 below
+  // (status_rows = the stamp the rows must carry, olsr_device.h: rows_stamp_of; a forward that did not compact them for this
+  //  scratch leaves the backward without rows: zero gradients, reported as an overflow of zero rows)
   if (threadIdx.x == 0 && status_rows != 0 && status_dev != nullptr) {
-    status_dev[0] = counters[6];
-    status_dev[1] = (counters[7] != 0 && counters[9] == 0) ? 1 : 0;
+    const bool stale = counters[11] != status_rows;
+    status_dev[0] = stale ? 0 : counters[6];
+    status_dev[1] = stale ? 1 : ((counters[7] != 0 && counters[9] == 0) ? 1 : 0);
   }
   // the backward's last kernel: a synchronisation error of this frame (olsr_state.h, counters[8]) reaches the caller here
   if (threadIdx.x == 0 && counters[8] != 0) {
@@ -973,7 +976,8 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
   const float* cov3D_ptr = s.cov3D_precomp ? s.cov3D_precomp : g.cov3D;
   // (persistent grid: at most one wave per 4 Gaussians — the lists never hold more than a fraction of them)
   const int rr_blocks = std::min(RR_BIG_BLOCKS, std::max(256, s.P / 16));
-  row_reduce_big_kernel<F><<<rr_blocks, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, s.P, b.rowbase, g.counters);
+  row_reduce_big_kernel<F><<<rr_blocks, RR_THREADS, 0, st>>>(rows, g.gacc, g.big_list, s.P, b.rowbase, g.counters,
+                                                             rows_stamp_of(s.backward_row_capacity));
   const int F_out = s.F;
   const size_t bucket_lds = o.bucket_flat ? sizeof(float) * PB_THREADS * (size_t)(11 + 3 * s.M + F_out) : 0;
 #define OLSR_PB_ARGS                                                                                                      \
@@ -989,7 +993,7 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
     int32_t* total = &g.counters[10];
     preprocess_bwd_kernel<F, true><<<nb, PB_THREADS, bucket_lds, st>>>(
         OLSR_PB_ARGS, nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii, o.bucket_assign, s.activations,
-        s.opacities, F_out, o.bucket_row_mask, g.gacc, act_list, act_count, g.blended);
+        s.opacities, F_out, o.bucket_row_mask, g.gacc, act_list, act_count, g.blended, rows_stamp_of(s.backward_row_capacity));
     pb_compact_kernel<<<1, PC_THREADS, 0, st>>>(nb, act_count, act_list, compact, total);
     n_partials = std::min(nb, 256);
     pb_chain_kernel<<<n_partials, CH_THREADS, 0, st>>>(
@@ -1001,15 +1005,16 @@ static void launch_pb_t(const olsr_scene& s, const FrameDims& d, const GeometryS
 #else
   preprocess_bwd_kernel<F, false><<<nb, PB_THREADS, bucket_lds, st>>>(
       OLSR_PB_ARGS, o.dL_dtau_sum ? tau_partials : nullptr, o.bucket_flat, o.bucket_densify, o.bucket_max_radii,
-      o.bucket_assign, s.activations, s.opacities, F_out, o.bucket_row_mask, nullptr, nullptr, nullptr, g.blended);
+      o.bucket_assign, s.activations, s.opacities, F_out, o.bucket_row_mask, nullptr, nullptr, nullptr, g.blended,
+      rows_stamp_of(s.backward_row_capacity));
 #endif
 #undef OLSR_PB_ARGS
   if (o.dL_dtau_sum)
     tau_final_kernel<<<1, TAU_T, 0, st>>>(tau_partials, n_partials, o.dL_dtau_sum, g.counters, o.status_dev, o.sticky_error,
-                                          o.status_rows ? 1 : 0);
+                                          o.status_rows ? rows_stamp_of(s.backward_row_capacity) : 0);
   else if (o.status_dev || o.sticky_error)
     tau_final_kernel<<<1, 64, 0, st>>>(tau_partials, 0, nullptr, g.counters, o.status_dev, o.sticky_error,
-                                       o.status_rows ? 1 : 0);
+                                       o.status_rows ? rows_stamp_of(s.backward_row_capacity) : 0);
 }
 
 void launch_preprocess_backward(const olsr_scene& s, int F_rows, const FrameDims& d, const GeometryState& g,

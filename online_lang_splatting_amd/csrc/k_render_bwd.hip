@@ -116,7 +116,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
     const float* __restrict__ means2D, const float* __restrict__ conic_opacity, const float* __restrict__ colors,
     const float* __restrict__ lang, const float* __restrict__ depths, const float* __restrict__ final_Ts,
     const u32* __restrict__ n_contrib, const float* __restrict__ dL_dpixels, const float* __restrict__ dL_dpixels_lang,
-    const float* __restrict__ dL_dpixels_depth, float* __restrict__ rows) {
+    const float* __restrict__ dL_dpixels_depth, float* __restrict__ rows, int rows_stamp) {
 #ifdef OLSR_COMPOSITE_VGPR_FLOOR
   asm volatile("; vgpr floor" ::: OLSR_COMPOSITE_VGPR_FLOOR);  // (experiment: fewer resident waves, room for other frames' kernels)
 #endif
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(PACKED ? 128 : 256, (PACKED && F <= 16) ? OLSR_BWD_
   const int bx = tile_id % gx, by = tile_id / gx;
   const u32 r0 = ranges[2 * tile_id], r1 = ranges[2 * tile_id + 1];
   if (r1 <= r0) return;
-  if (frame_unusable(counters)) return;  // row scratch too small / synchronisation error (reported to the caller): write nothing
+  if (frame_unusable(counters, rows_stamp)) return;  // row scratch too small / synchronisation error / rows compacted for another scratch (reported to the caller): write nothing
   const size_t HW = (size_t)H * W;
 
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -547,7 +547,8 @@ static void launch_bwd_t(const olsr_scene& s, const FrameDims& d, const Geometry
   render_bwd_kernel<TILE, F, MODE, PACKED><<<d.ntiles, PACKED ? 128 : 256, 0, st>>>(
       im.ranges, b.inst_gid, b.src, b.flags, b.rowbase, g.counters, im.tile_order, d.W, d.H, d.gx, d.ntiles,
       s.background,
-      g.means2D, g.conic_opacity, colors, s.language_precomp, g.depths, im.final_T, im.n_contrib, dc, dl, dd, rows);
+      g.means2D, g.conic_opacity, colors, s.language_precomp, g.depths, im.final_T, im.n_contrib, dc, dl, dd, rows,
+      rows_stamp_of(s.backward_row_capacity));
 }
 
 // F_rows: the language channels the rows carry — s.F, or 0 when the caller handed no language cotangent (the

@@ -176,6 +176,7 @@ __device__ __forceinline__ void frame_housekeeping(const FrameHousekeeping& hous
     house.counters[7] = 0;
     house.counters[8] = 0;  // synchronisation error of this frame (olsr_state.h)
     house.counters[9] = 0;  // a tile with a depth cut-off did not saturate (include/olsr.h, OLSR_STATUS_CUT_MISS)
+    house.counters[11] = 0;  // "the rows of this frame were compacted for a scratch of N rows" (set by the row compaction)
     if (house.live_rows) {
       house.live_rows[0] = 0;
       house.live_rows[1] = 0;

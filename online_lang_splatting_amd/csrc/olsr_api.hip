@@ -192,18 +192,44 @@ __global__ void hint_init_kernel(uint32_t* base, int ntiles) {
 // The sync-free entries report it through their status words; for the reference-shaped, synchronising API the last kernel of
 // a forward / backward also raises a flag in mapped host memory, and the FIRST library call after the GPU got there fails
 // with OLSR_ERR_DEVICE — the way an asynchronous HIP error surfaces.  Returns true (and clears the flag) if one is pending.
-bool take_sticky_sync_error() {
+// Round 6: the flag is keyed by (device, stream) — one of STICKY_SLOTS mapped host
+// words behind the rows ring, handed out in first-come order under a mutex; a call looks at the word of ITS device and stream
+// only, so the error of a frame issued on one stream no longer fails an unrelated call on another.  When more (device,
+// stream) pairs than slots have been seen, the last slot is shared by the rest (attribution degrades to "one of those").
+constexpr int STICKY_SLOTS = 64;
+struct StickyKeys {
+  std::mutex m;
+  int n = 0;
+  int dev[STICKY_SLOTS];
+  hipStream_t st[STICKY_SLOTS];
+} g_sticky_keys;
+int sticky_slot_of(hipStream_t st) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_sticky_keys.m);
+  for (int i = 0; i < g_sticky_keys.n; ++i)
+    if (g_sticky_keys.dev[i] == dev && g_sticky_keys.st[i] == st) return i;
+  if (g_sticky_keys.n < STICKY_SLOTS - 1) {
+    g_sticky_keys.dev[g_sticky_keys.n] = dev;
+    g_sticky_keys.st[g_sticky_keys.n] = st;
+    return g_sticky_keys.n++;
+  }
+  return STICKY_SLOTS - 1;
+}
+bool take_sticky_sync_error(hipStream_t st) {
   int32_t* ring = g_rows.p.load(std::memory_order_acquire);
   if (!ring) return false;
-  return __atomic_exchange_n(&ring[4 * ROWS_RING], 0, __ATOMIC_ACQ_REL) != 0;
+  return __atomic_exchange_n(&ring[4 * ROWS_RING + sticky_slot_of(st)], 0, __ATOMIC_ACQ_REL) != 0;
 }
-int32_t* sticky_sync_error_dev() { return g_rows.p.load(std::memory_order_acquire) ? g_rows.dp + 4 * ROWS_RING : nullptr; }
+int32_t* sticky_sync_error_dev(hipStream_t st) {
+  return g_rows.p.load(std::memory_order_acquire) ? g_rows.dp + 4 * ROWS_RING + sticky_slot_of(st) : nullptr;
+}
 const char* const STICKY_MSG =
-    "device-side synchronisation error in an earlier frame of this process: a look-back of its radix sort / row compaction "
-    "never received a predecessor's counts (state buffer corrupted mid-frame?); that frame's images are invalid and its "
-    "gradients are zeros.  (The flag is process-wide, like an asynchronous HIP error: the frame it belongs to was issued "
-    "through the reference-shaped entry on ANY thread or stream of this process, not necessarily by this call; callers that "
-    "need the error attributed use the sync-free entries, whose status words are per frame.)";
+    "device-side synchronisation error in an earlier frame issued on this device and stream: a look-back of its radix sort / "
+    "row compaction never received a predecessor's counts (state buffer corrupted mid-frame?); that frame's images are "
+    "invalid and its gradients are zeros.  (Reported like an asynchronous HIP error, by the first reference-shaped call on "
+    "the same device and stream after the GPU got there; callers that need the error attributed to a frame use the sync-free "
+    "entries, whose status words are per frame.)";
 
 // Diagnostic (olsr_debug_composite_stamps): one-thread kernels in front of and behind every composite launch write the
 // device's wall clock (100 MHz, common to all XCDs) into a caller's buffer — when did each composite become eligible, when had
@@ -375,10 +401,11 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       std::lock_guard<std::mutex> lk(g_rows.init);
       if (!g_rows.p.load(std::memory_order_relaxed)) {
         int32_t* hp = nullptr;
-        // (+ 4 words behind the ring: [0] = the sticky synchronisation-error flag, see take_sticky_sync_error)
-        HIP_TRY(hipHostMalloc((void**)&hp, (ROWS_RING * 4 + 4) * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        // (+ STICKY_SLOTS words behind the ring: the sticky synchronisation-error flags, one per (device, stream) —
+        //  take_sticky_sync_error)
+        HIP_TRY(hipHostMalloc((void**)&hp, (ROWS_RING * 4 + STICKY_SLOTS) * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipHostGetDevicePointer((void**)&g_rows.dp, hp, 0));
-        std::memset(hp, 0, (ROWS_RING * 4 + 4) * sizeof(int32_t));
+        std::memset(hp, 0, (ROWS_RING * 4 + STICKY_SLOTS) * sizeof(int32_t));
         g_rows.p.store(hp, std::memory_order_release);
       }
     }
@@ -390,7 +417,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     g_last_token = tok;
     g_rows_call.dev = g_rows.dp + 4 * (tok % ROWS_RING);
     g_rows_call.seq = tok;
-    g_rows_call.sticky = g_rows.dp + 4 * ROWS_RING;
+    g_rows_call.sticky = g_rows.dp + 4 * ROWS_RING + sticky_slot_of(st);
   }
   if (view_hints != nullptr && s.P > 0) {  // (the synchronising entry; the slot was picked by the depth sort's histogram kernel)
     g_rows_call.hint_slot = view_hints;
@@ -536,6 +563,13 @@ int64_t olsr_live_rows(int32_t token, int32_t packed_survivor_waves) {
   return (__atomic_load_n(&slot[2], __ATOMIC_ACQUIRE) == token) ? v : -1;  // (not overwritten meanwhile)
 }
 
+int32_t olsr_live_rows_overwritten(int32_t token) {
+  int32_t* ring = g_rows.p.load(std::memory_order_acquire);
+  if (token <= 0 || !ring) return 0;
+  const int32_t seen = __atomic_load_n(&ring[4 * (token % ROWS_RING) + 2], __ATOMIC_ACQUIRE);
+  return (seen > token && seen - token < (1 << 30)) ? 1 : 0;
+}
+
 int64_t olsr_live_rows_wait(int32_t token, int32_t packed_survivor_waves, int32_t timeout_us) {
   int64_t v = olsr_live_rows(token, packed_survivor_waves);
   int32_t* ring = g_rows.p.load(std::memory_order_acquire);
@@ -600,7 +634,7 @@ int olsr_forward(const olsr_scene* scene, olsr_alloc_fn geometry_alloc, void* ge
   if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(OLSR_ERR_ARG, "allocation callbacks are required");
   // (before the allocation callbacks run: a call that fails for an EARLIER frame's error must not have resized the caller's
   //  buffers — ADVICE round 4)
-  if (take_sticky_sync_error()) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
+  if (take_sticky_sync_error((hipStream_t)hip_stream)) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
   void* geom = geometry_alloc(geometry_user, olsr_geometry_bytes(scene->P, scene->F));
   if (!geom) return fail(OLSR_ERR_ALLOC, "geometry allocation callback returned NULL");
   void* img = image_alloc(image_user, olsr_image_bytes(scene->width, scene->height, scene->tile));
@@ -691,7 +725,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   hipStream_t st = (hipStream_t)hip_stream;
   if (s.bwd_mode != OLSR_BWD_REFERENCE && s.bwd_mode != OLSR_BWD_EXACT)
     return fail(OLSR_ERR_ARG, "bwd_mode must be OLSR_BWD_REFERENCE or OLSR_BWD_EXACT");
-  if (take_sticky_sync_error()) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
+  if (take_sticky_sync_error(st)) return fail(OLSR_ERR_DEVICE, STICKY_MSG);
   mark("begin", st);
   if (s.P == 0) {
     if (dL_dtau_sum) HIP_TRY(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), st));
@@ -769,7 +803,7 @@ int olsr_backward(const olsr_scene* scene, const int32_t* radii, void* geometry_
   o.status_rows = rows_compacted;
   // (a caller that passes status_dev reads the report there; one that does not — the reference-shaped bindings — gets it
   //  from the library's next call)
-  o.sticky_error = status_dev ? nullptr : sticky_sync_error_dev();
+  o.sticky_error = status_dev ? nullptr : sticky_sync_error_dev(st);
   launch_preprocess_backward(s, F_rows, d, g, b, rows, radii, o, g.tau_partials, st);
   STAGE("preprocess_backward");
   (void)gb;

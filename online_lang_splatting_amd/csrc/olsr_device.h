@@ -17,7 +17,17 @@ namespace olsr {
 // look-back ran into its spin bound (counters[8], olsr_state.h) — every gradient is then zero.
 // (The cut-off miss, counters[9], is folded into counters[7] by the backward's first kernel instead of being tested here: one
 //  more scalar load in this predicate moved render_bwd_kernel<15,32,...> from 0.502 to 0.52 ms, round 4.)
-__device__ __forceinline__ bool frame_unusable(const int32_t* counters) { return (counters[7] | counters[8]) != 0; }
+// rows_stamp (0 = no statement): the backward was told that the FORWARD compacted the gradient rows for a scratch of a given
+// capacity (olsr_scene.backward_row_capacity).  The compaction leaves rows_stamp_of(that capacity) in counters[11], the
+// frame's first kernel clears it: a backward whose expectation does not match — the forward ran without the announcement, or
+// with another capacity, so rowbase / counters[6] / counters[7] are stale or sized for another scratch — reads and writes
+// nothing through them, hands out zero gradients and reports an overflow.
+__host__ __device__ __forceinline__ int32_t rows_stamp_of(long long row_capacity) {
+  return row_capacity > 0 ? (int32_t)((row_capacity & 0x3FFFFFFFll) + 1) : 0;
+}
+__device__ __forceinline__ bool frame_unusable(const int32_t* counters, int32_t rows_stamp = 0) {
+  return (counters[7] | counters[8]) != 0 || (rows_stamp != 0 && counters[11] != rows_stamp);
+}
 
 
 typedef unsigned int u32;

@@ -201,7 +201,9 @@ std::vector<Tensor> backward(int F, const Tensor &bg, const Tensor &means3D, con
   bool guessed = false;
   if (rows < 0 || rows > bound) {
     const float ratio = g_rows_per_instance[packed ? 1 : 0].load(std::memory_order_relaxed);
-    if (rows_token > 0 && ratio > 0.f && R > 0 && olsr_backward_scratch_bytes(bound, F) > (static_cast<size_t>(64) << 20)) {
+    if (olsr_live_rows_overwritten(rows_token)) {
+      rows = bound;  // (the slot belongs to a later forward: no count will ever arrive — no guess, no wait, no second backward)
+    } else if (rows_token > 0 && ratio > 0.f && R > 0 && olsr_backward_scratch_bytes(bound, F) > (static_cast<size_t>(64) << 20)) {
       // (rounded up to a multiple of 128 Ki rows — 14 MB at F = 15: a size that changed a little from frame to frame, with the
       //  decaying ratio, made the caching allocator cut a new block every frame, and every few frames that is a hipMalloc)
       rows = static_cast<int64_t>(1.5 * static_cast<double>(ratio) * R) + 65536;

@@ -64,6 +64,28 @@ def _cotangent(g, shape, like):
     return g if g is not None else torch.zeros(shape, dtype=torch.float32, device=like.device)
 
 
+def _cpu_deep_copy(args):
+    """cpu_deep_copy_tuple, DGR/diff_gaussian_rasterization/__init__.py:17-19"""
+    return tuple(a.cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _debug_call(debug, fn, args, kwargs, dump, what):
+    """raster_settings.debug of the RGB rasterizer (DGR/diff_gaussian_rasterization/__init__.py:121-130, 173-183): the arguments
+    are copied to the CPU before the call "before they can be corrupted", and an exception leaves them behind as
+    snapshot_fw.dump / snapshot_bw.dump in the working directory before it is re-raised.  (The reference's LANGUAGE rasterizer
+    has the same lines commented out, :270-281, 357-368: it writes no dump, and neither does this one.)"""
+    if not debug:
+        return fn(*args, **kwargs)
+    cpu_args = _cpu_deep_copy(args)
+    try:
+        return fn(*args, **kwargs)
+    except Exception:
+        torch.save(cpu_args, dump)
+        print(f"\nAn error occured in {what}. " + ("Please forward snapshot_fw.dump for debugging." if what == "forward"
+                                                   else "Writing snapshot_bw.dump for debugging.\n"))
+        raise
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """RGB + depth + opacity rasterization (reference :79-202)."""
 
@@ -72,10 +94,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings):
         rs = raster_settings
         cfg = _C.current_config()  # tile / backward mode / binning of THIS forward, reused by its backward
-        (num_rendered, color, radii, geom, binning, img, depth, opacity, n_touched) = _C.rasterize_gaussians(
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            *_settings_args(rs), rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered,
-            rs.debug)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                *_settings_args(rs), rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        (num_rendered, color, radii, geom, binning, img, depth, opacity, n_touched) = _debug_call(
+            rs.debug, _C.rasterize_gaussians, args, {}, "snapshot_fw.dump", "forward")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.olsr_cfg = cfg
@@ -92,11 +114,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         H, W = rs.image_height, rs.image_width
         grad_out_color = _cotangent(grad_out_color, (3, H, W), means3D)
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                *_settings_args(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
+                binning, img, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, _grad_tau, tau_sum) = _C.rasterize_gaussians_backward(
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            *_settings_args(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-            binning, img, rs.debug, cfg=ctx.olsr_cfg, with_tau_sum=True, rows_token=ctx.olsr_rows_token)
+         grad_rotations, _grad_tau, tau_sum) = _debug_call(
+            rs.debug, _C.rasterize_gaussians_backward, args,
+            dict(cfg=ctx.olsr_cfg, with_tau_sum=True, rows_token=ctx.olsr_rows_token), "snapshot_bw.dump", "backward")
         grad_theta, grad_rho = _split_tau(tau_sum, *ctx.olsr_pose_shapes)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, grad_theta, grad_rho, None)

@@ -179,11 +179,22 @@ class TrackingLoop:
         return issued
 
     def render_final(self) -> Dict[str, torch.Tensor]:
-        """The images of the CURRENT pose (after the last pose step): one plain forward into ws.out — what the reference's front
-        end holds in render_pkg after its tracking loop, for add_new_keyframe / GUI / evaluation.  No loss, no pose step."""
+        """The images of the CURRENT pose (after the last pose step): one plain forward into ws.out, for add_new_keyframe / GUI /
+        evaluation.  No loss, no pose step.  Which pose: the reference's front end keeps the render_pkg of its LAST ITERATION,
+        i.e. of the pose BEFORE the last step (utils/slam_frontend.py:216-243) — iteration(write_images=True) on the final
+        iteration, and run(write_final_images=True) without depth cut-offs, leave exactly those; render_final(), and
+        run(write_final_images=True) WITH depth cut-offs (whose iterations write no images), leave the images one step later,
+        of the pose the loop ends with.  The two differ by one optimiser step of a converged loop."""
         ws = self.ws
-        ws.set_scene(sh_degree=self.sh_degree, **self.pose.camera(), **self.g)
-        return ws.forward()
+        # (never through the depth cut-offs — ADVICE round 5: a CUT_MISS frame would leave depth / opacity / colour with missing
+        #  contributions, and nothing downstream of these images looks at the forward's status.  The cut-off array itself is
+        #  left as the last iteration left it.)
+        keep_cut, ws._depth_cut_buf = ws._depth_cut_buf, None
+        try:
+            ws.set_scene(sh_degree=self.sh_degree, **self.pose.camera(), **self.g)
+            return ws.forward()
+        finally:
+            ws._depth_cut_buf = keep_cut
 
     def steps_done(self) -> int:
         """Optimiser steps taken since PoseState.reset (device count; with depth cut-offs an iteration whose frame missed

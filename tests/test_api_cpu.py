@@ -110,6 +110,27 @@ def test_python_api_surface_and_exceptions():
                                False)
 
 
+def test_debug_settings_leave_a_snapshot_behind_on_failure(tmp_path, monkeypatch):
+    """raster_settings.debug = True: a failing forward of the RGB rasterizer writes its CPU-copied arguments to
+    snapshot_fw.dump before re-raising (DGR/diff_gaussian_rasterization/__init__.py:121-130); the language rasterizer does not
+    (the reference has those lines commented out, :270-281)."""
+    import diff_gaussian_rasterization as D
+    from online_lang_splatting_amd import GaussianRasterizationSettings, LanguageGaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    rs = GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), torch.eye(4), 0,
+                                       torch.zeros(3), False, True)
+    P = 4
+    m, m2, o = torch.full((P, 3), 2.0), torch.zeros(P, 3), torch.ones(P, 1)
+    sh, sc, rot = torch.zeros(P, 1, 3), torch.ones(P, 3), torch.zeros(P, 4)
+    with pytest.raises(RuntimeError, match="GPU"):   # (CPU tensors: the product has no CPU path, so the call fails)
+        LanguageGaussianRasterizer(rs)(m, m2, o, shs=sh, scales=sc, rotations=rot, language_precomp=torch.zeros(P, 15))
+    assert not (tmp_path / "snapshot_fw.dump").exists()
+    with pytest.raises(RuntimeError, match="GPU"):
+        D.GaussianRasterizer(rs)(m, m2, o, shs=sh, scales=sc, rotations=rot)
+    dump = torch.load(tmp_path / "snapshot_fw.dump")
+    assert isinstance(dump, tuple) and torch.equal(dump[1], m) and dump[-1] is True   # (bg, means3D, ..., prefiltered, debug)
+
+
 def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "online_lang_splatting_amd")
     for dirpath, _dirs, files in os.walk(pkg):

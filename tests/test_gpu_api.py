@@ -978,6 +978,35 @@ def test_rows_compacted_by_the_forwards_last_launch(hip, tile, mode):
     finally:
         ws.row_capacity += 1
     assert lib().olsr_last_error() is not None
+    # ... and the FORWARD must really have compacted them for that scratch: a forward issued without the
+    # announcement, then a backward that claims it — stale rowbase / counters — hands out zero gradients and says so, and so does
+    # a backward that announces another capacity than the forward compacted for
+    def backward_with_scene_capacity(w, cap):
+        w._scene.backward_row_capacity = cap
+        return w.backward(*cot)
+    plain = res[False][2]                      # (rows_in_forward=False: its forward announces nothing)
+    plain.forward()
+    gz = backward_with_scene_capacity(plain, plain.row_capacity)
+    torch.cuda.synchronize()
+    assert int(plain.bwd_status.cpu()[1]) == 1 and all(float(v.abs().max()) == 0.0 for v in gz.values())
+    plain._scene.backward_row_capacity = 0
+    g_ok = plain.backward(*cot)                # the honest backward on the same forward is healthy
+    assert plain.backward_status() == res[False][1] and float(g_ok["dL_dmeans3D"].abs().max()) > 0
+    ws.forward()                               # compacted for ws.row_capacity ...
+    keep_cap, keep_scratch = ws.row_capacity, ws.scratch
+    ws.row_capacity += 4096                    # ... but the backward announces (and brings) a larger scratch
+    ws.scratch = torch.empty(lib().olsr_backward_scratch_bytes(ws.row_capacity, ws.F), dtype=torch.uint8, device=dev)
+    try:
+        gz = backward_with_scene_capacity(ws, ws.row_capacity)
+        torch.cuda.synchronize()
+        assert int(ws.bwd_status.cpu()[1]) == 1 and all(float(v.abs().max()) == 0.0 for v in gz.values())
+    finally:
+        ws.row_capacity, ws.scratch = keep_cap, keep_scratch
+        ws._scene.backward_row_capacity = keep_cap
+    ws.forward()
+    g_ok = ws.backward(*cot)
+    for k in res[True][0]:
+        assert torch.equal(res[True][0][k], g_ok[k]), k
 
 
 @pytest.mark.parametrize("which,bit", [("depth sort", 1), ("tile sort", 2)])
@@ -1010,9 +1039,17 @@ def test_lost_digit_counts_in_a_radix_pass_are_reported(hip, which, bit):
         g2 = hip.rasterize_language_gaussians_backward(*b)   # (may be issued before the GPU has reached the error)
         torch.cuda.synchronize()
         assert float(g2[4].abs().max()) == 0.0                 # dL_dmeans3D: zeros, not garbage
-        # ... and the first library call after the GPU got there fails, the way an asynchronous HIP error surfaces
+        # the pending error belongs to THIS device and stream (round 6): a healthy call on another stream is not failed by it
+        L.olsr_debug_sync_fault(0, 0)
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):
+            r_side = hip.rasterize_language_gaussians(*a)
+        side.synchronize()
+        assert r_side[0] > 0
+        # ... and the first library call on the stream of the broken frame fails, the way an asynchronous HIP error surfaces
         with pytest.raises(RuntimeError, match="synchronisation error"):
             hip.rasterize_language_gaussians(*a)
+        hip.rasterize_language_gaussians(*a)                     # (reported once)
     finally:
         L.olsr_debug_sync_fault(0, 0)
         L.olsr_debug_sort_knobs(0, -1, -1)
