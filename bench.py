@@ -1014,6 +1014,10 @@ def main():
                     help="volume (default): SURVEY 8(d)'s i.i.d. Gaussians, the BASELINE workload; room: the surface-structured "
                          "map of scene.make_room_scene (a SLAM map by the reference's recipe) at the config's size, rank r "
                          "rendering keyframe r of the mapping window")
+    ap.add_argument("--exchange-via", default="torch", choices=["rccl", "torch"],
+                    help="N > 1 over RCCL: who issues the step's collectives - torch (default): torch.distributed, on its own stream "
+                         "beside the lane's next forward; rccl: RCCL's C API directly on the lane's stream (rccl_direct.py) - no hop, "
+                         "but the collective then serialises with the lane: measured SLOWER, profiles/r6_exchange_via.json")
     ap.add_argument("--carry-order", type=int, default=1, choices=[0, 1],
                     help="1 (default): the lanes carry their view's depth order from frame to frame (olsr_scene.depth_order_carry: "
                          "repaired in two launches, exact by a device-side fall-back to the radix passes); the legs whose camera "
@@ -1064,8 +1068,18 @@ def main():
             from online_lang_splatting_amd.frame_shard import GradientBucket
             GradientBucket.exchange_single_rank = True
             GradientBucket.capped_torch_formulation = os.environ.get("OLSR_BENCH_EXCHANGE_TORCH") == "1"
+        # --exchange-via rccl: the step's collectives through RCCL's C API on the lane's own stream (rccl_direct.py) instead of
+        # torch.distributed's hop to the process group's stream and back (built, measured, slower)
+        if backend == "nccl" and a.exchange_via == "rccl":
+            from online_lang_splatting_amd.frame_shard import GradientBucket
+            from online_lang_splatting_amd.rccl_direct import DirectComm
+            GradientBucket.direct_comm = DirectComm.from_process_group(device=torch.device("cuda", local_rank))
+            exchange_via = "rccl C API on the lane's stream"
+        else:
+            exchange_via = "torch.distributed"
     else:
         dist = None
+        exchange_via = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
@@ -1503,7 +1517,7 @@ def main():
                        "rccl_ranks": world if backend == "nccl" else 0, "backend": backend,
                        "exchange": chosen[0] if dist is not None else None,
                        "exchange_requested": a.exchange if dist is not None else None,
-                       "exchange_forced_single_rank": forced,
+                       "exchange_forced_single_rank": forced, "exchange_via": exchange_via,
                        "exchange_bytes_per_step": None if dist is None else
                        lanes.lanes[0][1].exchange_bytes(chosen[0], sparse_cap[0]),
                        "exchange_detail": exch_detail,

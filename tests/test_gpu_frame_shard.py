@@ -221,6 +221,29 @@ def _rccl_worker(rank, world, port, ret):
         torch.cuda.synchronize()
         ret["weak_forms_identity"] = bool(torch.equal(b.flat, before))
         ret["capped_status"] = status.tolist()
+        # ... and the same three forms through RCCL's C API on the caller's stream (rccl_direct.DirectComm): a communicator of its
+        # own, bootstrapped through this process group; identities in a group of one rank, every dtype / op the exchanges use
+        from online_lang_splatting_amd.rccl_direct import DirectComm
+        dc = DirectComm.from_process_group()
+        GradientBucket.direct_comm = dc
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):   # (on whatever stream is current: no hop)
+                b.all_reduce()
+                status_d = b.sparse_all_reduce_capped(4096)
+                b.reduce_scatter_all_gather(0, 1)
+                x = torch.arange(1024, dtype=torch.float32, device=dev)
+                dc.all_reduce(x, "sum")
+                y = torch.arange(1024, dtype=torch.int32, device=dev)
+                dc.all_reduce(y, "max")
+            side.synchronize()
+            ret["direct_identity"] = bool(torch.equal(b.flat, before)) and status_d.cpu().tolist() == status.tolist() and \
+                bool(torch.equal(x, torch.arange(1024, dtype=torch.float32, device=dev))) and \
+                bool(torch.equal(y, torch.arange(1024, dtype=torch.int32, device=dev)))
+        finally:
+            GradientBucket.direct_comm = None
+            dc.destroy()
         ret["nonzero_rows"] = int((before != 0).any(1).sum())
         ret["backend"] = dist.get_backend()
         ret["same_bucket"] = all(torch.equal(out[m][0], out["all_reduce"][0]) for m in out)
@@ -240,5 +263,5 @@ def test_every_exchange_collective_runs_on_rccl_single_rank(hip):
     mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
     r = dict(ret)
     assert r["backend"] == "nccl"
-    assert r["same_bucket"] and r["same_params"] and r["moved"] and r["weak_forms_identity"]
+    assert r["same_bucket"] and r["same_params"] and r["moved"] and r["weak_forms_identity"] and r["direct_identity"]
     assert r["capped_status"] == [r["nonzero_rows"], int(r["nonzero_rows"] > 4096)] and r["nonzero_rows"] > 0
