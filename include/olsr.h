@@ -663,6 +663,13 @@ void olsr_debug_sort_knobs(int keys_per_thread, int resident_blocks, int legacy)
  * olsr_debug_sort_knobs also selects the pass kernels. */
 void olsr_debug_sort_small(int enable);
 
+/* Visible-set compaction of the depth sort (round 6): the sort orders only the Gaussians that emit instances — the histogram
+ * kernel, which reads every key anyway, writes their (key, index) densely in index order and counts digits of those only; the
+ * passes sort that many keys.  Same lists bit for bit.  enable = 0 sorts every Gaussian as rounds 1-5 did (tests compare the
+ * two), 1 restores the default, negative leaves it.  Process-wide; seeded once from OLSR_SORT_COMPACT.  Not used with a carried
+ * depth order (whose domain is every Gaussian), by the one-launch sort of <= 8 192 Gaussians, nor beyond 2 M Gaussians. */
+void olsr_debug_sort_compact(int enable);
+
 /* Diagnostic: while a device buffer of 2 x capacity uint64 is set, every forward / backward composite launch of this process
  * is bracketed by two one-thread kernels on its stream that write {device wall clock (100 MHz), stream << 8 | kind} — kind 0 / 1:
  * in front of / behind the forward composite (+ its tile-order kernel), 2 / 3: the backward composite — into consecutive

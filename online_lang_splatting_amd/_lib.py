@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OLSR_LIB") or os.path.join(_HERE, "libolsr.so")
 EXPORTS = (
     "olsr_geometry_bytes", "olsr_image_bytes", "olsr_binning_bytes", "olsr_backward_scratch_bytes", "olsr_last_forward_token", "olsr_live_rows", "olsr_forward", "olsr_forward_async", "olsr_forward_async_loss", "olsr_fused_loss_scratch_bytes",
     "olsr_backward", "olsr_accumulate_gradients", "olsr_sparse_exchange_mask", "olsr_sparse_exchange_scratch_ints", "olsr_sparse_exchange_pack", "olsr_sparse_exchange_unpack", "olsr_mapping_loss", "olsr_mapping_loss_scratch_bytes", "olsr_tracking_loss", "olsr_pose_step", "olsr_pose_step_gated", "olsr_knn_mean_dist2", "olsr_knn_scratch_bytes", "olsr_adam_step", "olsr_adam_step_sum", "olsr_adam_step_masked", "olsr_bucket_add", "olsr_mark_visible", "olsr_geometry_field", "olsr_binning_field", "olsr_image_field",
-    "olsr_set_profiling", "olsr_get_stage_times", "olsr_debug_sort_timing", "olsr_debug_sort_plan", "olsr_debug_sort_knobs", "olsr_debug_sort_small", "olsr_debug_sort_threads", "olsr_debug_composite_stamps", "olsr_debug_sync_fault", "olsr_debug_backward_ordered", "olsr_debug_backward_ordered_scratch_bytes", "olsr_live_rows_wait", "olsr_live_rows_overwritten", "olsr_backward_rows", "olsr_last_error", "olsr_version",
+    "olsr_set_profiling", "olsr_get_stage_times", "olsr_debug_sort_timing", "olsr_debug_sort_plan", "olsr_debug_sort_knobs", "olsr_debug_sort_small", "olsr_debug_sort_compact", "olsr_debug_sort_threads", "olsr_debug_composite_stamps", "olsr_debug_sync_fault", "olsr_debug_backward_ordered", "olsr_debug_backward_ordered_scratch_bytes", "olsr_live_rows_wait", "olsr_live_rows_overwritten", "olsr_backward_rows", "olsr_last_error", "olsr_version",
 )
 
 _lib = None
@@ -98,6 +98,7 @@ def lib():
     L.olsr_debug_sort_knobs.argtypes = [C.c_int, C.c_int, C.c_int]
     L.olsr_debug_sort_knobs.restype = None
     L.olsr_debug_sort_small.argtypes, L.olsr_debug_sort_small.restype = [C.c_int], None
+    L.olsr_debug_sort_compact.argtypes, L.olsr_debug_sort_compact.restype = [C.c_int], None
     L.olsr_debug_sort_threads.argtypes, L.olsr_debug_sort_threads.restype = [C.c_int], C.c_int
     L.olsr_debug_composite_stamps.argtypes, L.olsr_debug_composite_stamps.restype = [vp, C.c_int], None
     L.olsr_debug_sync_fault.argtypes = [C.c_int, C.c_int]

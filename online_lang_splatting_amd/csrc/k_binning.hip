@@ -428,7 +428,8 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
     int P, const u32* __restrict__ order, const u32* __restrict__ inst_count, int32_t* __restrict__ counters,
     const u64* __restrict__ block_totals_sort, uint4* __restrict__ bin_sync, int bin_sync_quads,
     u32* __restrict__ c_off, u32* __restrict__ c_gid, u32* __restrict__ win_start, u32* __restrict__ inst_start,
-    uint4* __restrict__ big_list, u32 eb_shift, const u64* __restrict__ alt_totals, const u32* __restrict__ alt_unless) {
+    uint4* __restrict__ big_list, u32 eb_shift, const u64* __restrict__ alt_totals, const u32* __restrict__ alt_unless,
+    const int32_t* __restrict__ n_order_dev) {
   __shared__ u64 s_wsum[EO_T / 64 + 1];
   __shared__ u32 s_lsum[EO_T / 64 + 1];
   __shared__ u32 s_lbase;
@@ -447,6 +448,11 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
   const u32 b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r0 = (int)(b * EMIT_CHUNK + threadIdx.x * EO_PER);  // this thread's four consecutive depth ranks
+  // (P_true sizes the Gaussian-indexed arrays; the ORDER holds n_order entries — all P, or only the Gaussians that emit when
+  //  the depth sort compacted its input, k_sort.hip.  Blocks beyond them have nothing to do: uniform.)
+  const int P_true = P;
+  if (n_order_dev != nullptr) P = min(P, *n_order_dev);
+  if ((int)(b * EMIT_CHUNK) >= P && !(b == 0 && P == 0)) return;
   u32 g[EO_PER], n[EO_PER];
   if (r0 + EO_PER <= P) {
     const uint4 q = *reinterpret_cast<const uint4*>(order + r0);  // (the order array is 256-byte aligned)
@@ -515,8 +521,8 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
       ++ci;
     }
   }
-  // (the last thread of the last block has seen every rank: the number of emitting Gaussians)
-  if (b == gridDim.x - 1 && threadIdx.x == EO_T - 1) counters[10] = (int32_t)ci;
+  // (the thread that holds the last rank has seen every rank: the number of emitting Gaussians)
+  if ((r0 <= P - 1 && P - 1 < r0 + EO_PER) || (P == 0 && b == 0 && threadIdx.x == 0)) counters[10] = (int32_t)ci;
   // the two work lists of the backward's row sums: big footprints from the front, medium ones from the back
   u32 slot = block_list_base(nbig, &counters[5], s_lsum, &s_lbase);
 #pragma unroll
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(EO_T) void emit_offsets_kernel(
   u32 mslot = block_list_base(nmid, &counters[4], s_lsum, &s_lbase);
 #pragma unroll
   for (int k = 0; k < EO_PER; ++k)
-    if (n[k] > OLSR_MID_FOOTPRINT && n[k] <= EMIT_BIG) big_list[(u32)P - 1u - (mslot++)] = make_uint4(g[k], off[k], n[k], 0u);
+    if (n[k] > OLSR_MID_FOOTPRINT && n[k] <= EMIT_BIG) big_list[(u32)P_true - 1u - (mslot++)] = make_uint4(g[k], off[k], n[k], 0u);
 }
 
 // exclusive scan of v over the EB_T threads of the block; *total = the sum (two barriers; s_w: [EB_T / 64])
@@ -724,7 +730,7 @@ void launch_emit_totals(const uint32_t* order, int P, const uint32_t* inst_count
 template <int TILE>
 static void launch_emit_t(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                           int64_t bin_sync_words, int64_t n_host, const u32* order, const u32* alt_totals,
-                          const u32* alt_unless, hipStream_t st) {
+                          const u32* alt_unless, const int32_t* n_order_dev, hipStream_t st) {
   const int nb = (s.P + EMIT_THREADS - 1) / EMIT_THREADS;
   const int ellipse = (s.binning == OLSR_BINNING_ELLIPSE);
   const u32* totals = g.emit_status;  // per-block instance totals, accumulated by the depth sort's last pass
@@ -741,7 +747,7 @@ static void launch_emit_t(const olsr_scene& s, const FrameDims& d, const Geometr
   emit_offsets_kernel<<<nb, EO_T, 0, st>>>(s.P, order, g.tiles_touched, g.counters, reinterpret_cast<const u64*>(totals), bsync,
                                            quads, rank_off, rank_gid, win_start, g.inst_start, g.big_list,
                                            (u32)__builtin_ctz((unsigned)eb_out), reinterpret_cast<const u64*>(alt_totals),
-                                           alt_unless);
+                                           alt_unless, n_order_dev);
   const int64_t nblk = (n_host + eb_out - 1) / eb_out;
   if (nblk > 0)
     emit_balanced_kernel<TILE><<<(int)nblk, EB_T, 0, st>>>(rank_gid, rank_off, win_start, g.emit_rec,
@@ -751,10 +757,10 @@ static void launch_emit_t(const olsr_scene& s, const FrameDims& d, const Geometr
 
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                  int64_t bin_sync_words, int64_t n_host, const uint32_t* order, const uint32_t* alt_totals,
-                 const uint32_t* alt_unless, hipStream_t st) {
+                 const uint32_t* alt_unless, const int32_t* n_order_dev, hipStream_t st) {
   if (s.P <= 0) return;
-  if (d.tile == 15) launch_emit_t<15>(s, d, g, b, bin_sync_words, n_host, order, alt_totals, alt_unless, st);
-  else launch_emit_t<16>(s, d, g, b, bin_sync_words, n_host, order, alt_totals, alt_unless, st);
+  if (d.tile == 15) launch_emit_t<15>(s, d, g, b, bin_sync_words, n_host, order, alt_totals, alt_unless, n_order_dev, st);
+  else launch_emit_t<16>(s, d, g, b, bin_sync_words, n_host, order, alt_totals, alt_unless, n_order_dev, st);
 }
 
 // ------------------------------------------------------------------------------- row compaction

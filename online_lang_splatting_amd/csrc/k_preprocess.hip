@@ -290,8 +290,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
     float* __restrict__ conic_opacity, int gx, int gy, u32* __restrict__ tiles_touched, float4* __restrict__ emit_rec,
     u32* __restrict__ sort_key, u32* __restrict__ sort_val, int32_t* __restrict__ n_touched, int prefiltered,
     int ellipse, int act, u32* __restrict__ rect_partials, u32* __restrict__ count_partials,
-    uint4* __restrict__ sync_words, int sync_quads, const float* __restrict__ depth_cut, uint8_t* __restrict__ blended) {
-  __shared__ u32 s_area[4], s_cnt[4];
+    uint4* __restrict__ sync_words, int sync_quads, const float* __restrict__ depth_cut, uint8_t* __restrict__ blended,
+    u32* __restrict__ vis_partials) {
+  __shared__ u32 s_area[4], s_cnt[4], s_vis[4];
   __shared__ PreWaveLds s_rows[4];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   // the words the frame's fused kernels synchronise through (tickets, digit histograms, published block counts):
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
                                 count, pend);
   if (ellipse) count += count_pending_rows<TILE>(pend, s_rows[threadIdx.x >> 6], W, H, gx, depth_cut);
   if (idx < P) tiles_touched[idx] = count;
+  const u32 nvis = (u32)__popcll(ballot(idx < P && count > 0u));  // Gaussians of this wave that emit instances
   // instances of the reference's rect binning (its num_rendered) and instances this frame emits: one partial per
   // block each, summed by the next kernel (7.8 k same-address atomics would cost more than the whole kernel)
 #pragma unroll
@@ -319,11 +321,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(
   if ((threadIdx.x & 63) == 0) {
     s_area[threadIdx.x >> 6] = area;
     s_cnt[threadIdx.x >> 6] = count;
+    s_vis[threadIdx.x >> 6] = nvis;
   }
   __syncthreads();
   if (threadIdx.x == 0 && (int)(blockIdx.x * blockDim.x) < P) {  // (blocks beyond P only zero sync words)
     rect_partials[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
     count_partials[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    vis_partials[blockIdx.x] = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
   }
 }
 
@@ -338,7 +342,7 @@ void launch_preprocess(const olsr_scene& s, const FrameDims& d, const GeometrySt
       d.focal_y, radii, g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, d.gx, d.gy, g.tiles_touched,            \
       g.emit_rec, g.key_a, g.val_a, n_touched, s.prefiltered, (int)(s.binning == OLSR_BINNING_ELLIPSE),      \
       s.activations | (s.flags << 16), g.part_rect, g.part_count, reinterpret_cast<uint4*>(g.sync_words), sync_quads,      \
-      ((s.binning == OLSR_BINNING_ELLIPSE) ? s.tile_depth_cut : nullptr), g.blended
+      ((s.binning == OLSR_BINNING_ELLIPSE) ? s.tile_depth_cut : nullptr), g.blended, g.part_vis
   if (d.tile == 15)
     preprocess_kernel<15><<<nb, 256, 0, st>>>(OLSR_PRE_ARGS);
   else

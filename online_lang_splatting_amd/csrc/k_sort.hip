@@ -193,13 +193,31 @@ __device__ __forceinline__ void frame_housekeeping(const FrameHousekeeping& hous
   }
 }
 
+// Visible-set compaction (round 6): the depth sort orders only the Gaussians that EMIT instances.
+// The histogram kernel reads every key anyway; it now also reads the per-Gaussian instance counts, writes the (key, index) of
+// the emitting Gaussians densely, IN INDEX ORDER — a wave's 256 consecutive keys are exactly one block of preprocess, whose
+// count of emitting Gaussians (part_vis) gives the wave its base after one scan of <= 8 192 partials in LDS — and counts
+// digits of those only.  The passes then sort n_out keys (known on the device; their grids stay sized for P, blocks beyond
+// return at once).  A view that sees a fifth of the map — the room map — sorts 99 k keys instead of 500 k.  No extra launch,
+// no look-back: the prefix comes from a finished kernel.
+constexpr int COMPACT_MAX_PARTS = 8192;  // 2 M Gaussians (32 KB of LDS for the prefix); beyond: no compaction
+struct CompactArgs {
+  const u32* inst_count = nullptr;  // [P] instances per Gaussian; null: no compaction
+  const u32* part_vis = nullptr;    // [nparts] emitting Gaussians per 256
+  int nparts = 0;
+  u32* out_keys = nullptr;          // [P]
+  u32* out_gid = nullptr;           // [P]
+  int32_t* n_out = nullptr;         // the number of emitting Gaussians
+};
+
 template <int T>
 __global__ __launch_bounds__(T) void sort_hist_kernel(const u32* __restrict__ keys, int64_t n_host,
                                                          const int32_t* __restrict__ n_dev, int passes, int db,
                                                          u32* __restrict__ hist, FrameHousekeeping house,
-                                                         int do_house, const u32* __restrict__ run_if) {
+                                                         int do_house, const u32* __restrict__ run_if, CompactArgs ca) {
   __shared__ u32 h[4][256];
   __shared__ u32 s_red[2][T / 64];
+  extern __shared__ u32 s_pref[];  // [nparts] (compaction only): emitting Gaussians in front of every block of 256
   const int tid = threadIdx.x;
   // run_if (may be null): the sort is only needed when *run_if != 0 — the carried depth order could not be repaired
   // (k_order_carry.hip).  The frame's bookkeeping of block 0 happens either way.
@@ -211,6 +229,21 @@ __global__ __launch_bounds__(T) void sort_hist_kernel(const u32* __restrict__ ke
     return;
   }
   for (int i = tid; i < 4 * 256; i += T) (&h[0][0])[i] = 0;
+  const bool compact = ca.inst_count != nullptr;
+  if (compact) {
+    // exclusive prefix of part_vis over the blocks of 256 Gaussians: every thread a contiguous share, one block scan
+    const int per = (ca.nparts + T - 1) / T;
+    const int p0 = tid * per, p1 = min(p0 + per, ca.nparts);
+    u32 mine = 0;
+    for (int i = p0; i < p1; ++i) mine += ca.part_vis[i];
+    __shared__ u32 s_scan[2 * (T / 64)];
+    u32 run = fs_block_excl_scan<T / 64>(mine, s_scan);
+    for (int i = p0; i < p1; ++i) {
+      s_pref[i] = run;
+      run += ca.part_vis[i];
+    }
+    if (blockIdx.x == 0 && p0 < ca.nparts && p1 == ca.nparts) *ca.n_out = (int32_t)run;  // (the thread that holds the last share)
+  }
   __syncthreads();
   const int64_t n = fs_bounded_n(n_host, n_dev);
   const u32 mask = (1u << db) - 1u;
@@ -218,15 +251,44 @@ __global__ __launch_bounds__(T) void sort_hist_kernel(const u32* __restrict__ ke
   constexpr int HU = 4;  // independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
   for (int64_t i00 = ((int64_t)blockIdx.x * T + tid) * 4; i00 < n; i00 += stride * HU) {
     u32 k[HU][4];
+    u32 emits[HU];  // bit j: key j of slice u belongs to a Gaussian that emits instances (all ones without compaction)
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       const int64_t i0 = i00 + (int64_t)u * stride;
+      emits[u] = 0xFu;
       if (i0 + 4 <= n) {
         const uint4 q = *reinterpret_cast<const uint4*>(keys + i0);
         k[u][0] = q.x; k[u][1] = q.y; k[u][2] = q.z; k[u][3] = q.w;
+        if (compact) {
+          const uint4 c = *reinterpret_cast<const uint4*>(ca.inst_count + i0);
+          emits[u] = (c.x ? 1u : 0u) | (c.y ? 2u : 0u) | (c.z ? 4u : 0u) | (c.w ? 8u : 0u);
+        }
       } else {
+        if (compact) emits[u] = 0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k[u][j] = (i0 + j < n) ? keys[i0 + j] : 0u;
+        for (int j = 0; j < 4; ++j) {
+          k[u][j] = (i0 + j < n) ? keys[i0 + j] : 0u;
+          if (compact && i0 + j < n && ca.inst_count[i0 + j] != 0u) emits[u] |= 1u << j;
+        }
+      }
+    }
+    if (compact) {
+      // the wave's 64 x 4 consecutive keys are ONE block of 256 Gaussians of preprocess: its emitting ones go, in index order,
+      // behind those of all earlier blocks
+#pragma unroll
+      for (int u = 0; u < HU; ++u) {
+        const int64_t i0 = i00 + (int64_t)u * stride;
+        const int64_t wave0 = i0 - 4 * (int64_t)(tid & 63);  // (wave-uniform; a multiple of 256)
+        if (wave0 >= n) continue;
+        const u32 c = (u32)__builtin_popcount(emits[u]);
+        u32 pos = s_pref[(int)(wave0 >> 8)] + fs_wave_incl_scan(c) - c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (emits[u] & (1u << j)) {
+            ca.out_keys[pos] = k[u][j];
+            ca.out_gid[pos] = (u32)(i0 + j);
+            ++pos;
+          }
       }
     }
 #pragma unroll
@@ -236,7 +298,7 @@ __global__ __launch_bounds__(T) void sort_hist_kernel(const u32* __restrict__ ke
       if ((int64_t)blockIdx.x * T * 4 + (i00 - ((int64_t)blockIdx.x * T + tid) * 4) + (int64_t)u * stride >= n) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool valid = i0 + j < n;
+        const bool valid = i0 + j < n && ((emits[u] >> j) & 1u) != 0u;
         for (int p = 0; p < passes; ++p) {
           const u32 dg = (k[u][j] >> (db * p)) & mask;
           // the high digits of depth keys (sign, exponent) and of tile ids are nearly constant across a wave: 64
@@ -824,8 +886,13 @@ void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, c
   else launch_sort_small_t<8>(keys, n, order_out, inst_count, et, h, run_if, st);
 }
 
+bool depth_sort_compaction_applicable(int64_t P) {
+  return P > 0 && (P + 255) / 256 <= COMPACT_MAX_PARTS && sort_knobs().compact.load(std::memory_order_relaxed) != 0;
+}
+
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
-                      const FusedHouse* house, int threads, hipStream_t st, const uint32_t* run_if) {
+                      const FusedHouse* house, int threads, hipStream_t st, const uint32_t* run_if,
+                      const SortCompaction* compaction) {
   int passes;
   const int db = fused_sort_digit_bits(bits, &passes);
   const FrameHousekeeping h = housekeeping_of(house);
@@ -837,8 +904,19 @@ void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev
 #endif
   if (nb > OLSR_HIST_BLOCKS) nb = OLSR_HIST_BLOCKS;  // ... then a grid-stride loop: every block ends with one global atomic per non-empty bin,
                            // and same-address atomics serialise (~10-20 ns each), so few, fat blocks
-  if (T == 256) sort_hist_kernel<256><<<(int)nb, 256, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0, run_if);
-  else sort_hist_kernel<1024><<<(int)nb, 1024, 0, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0, run_if);
+  CompactArgs ca{};
+  size_t smem = 0;
+  if (compaction != nullptr) {
+    ca.inst_count = compaction->inst_count;
+    ca.part_vis = compaction->part_vis;
+    ca.nparts = (int)((n_host + 255) / 256);
+    ca.out_keys = compaction->out_keys;
+    ca.out_gid = compaction->out_gid;
+    ca.n_out = compaction->n_out;
+    smem = sizeof(u32) * (size_t)ca.nparts;
+  }
+  if (T == 256) sort_hist_kernel<256><<<(int)nb, 256, smem, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0, run_if, ca);
+  else sort_hist_kernel<1024><<<(int)nb, 1024, smem, st>>>(keys, n_host, n_dev, passes, db, hist, h, house ? 1 : 0, run_if, ca);
 }
 
 // Sorts (key, val) pairs on the low `bits` bits of key, ceil(bits / 8) passes.  hist / status / tickets must have been

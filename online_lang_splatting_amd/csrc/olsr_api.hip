@@ -276,6 +276,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
   int64_t n_host = 0;
   BinningState b{};
   uint32_t* carry = nullptr;  // the caller's carried depth order, when this frame uses it
+  uint32_t* order = nullptr;  // where the depth order lies when neither g.depth_order nor the carried array holds it
+  const int32_t* n_order_dev = nullptr;  // its length on the device when the sort compacted its input (else: P)
   if (s.P > 0) {
     launch_preprocess(s, d, g, radii, n_touched, st);  // also zeroes the geometry buffer's synchronisation words
     STAGE("preprocess");
@@ -310,9 +312,23 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
       STAGE("depth_sort");
     } else {
     const SortPlan depth_plan = sort_plan(s.P, false, 85, in_flight);
-    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, depth_plan.threads, st, run_if);
+    const bool fused_depth = !legacy && fused_sort_applicable(s.P, 32);
+    // Visible-set compaction (k_sort.hip): without a carried order — whose domain is every Gaussian — the histogram kernel
+    // hands the passes only the Gaussians that emit instances, (key, index) densely in key_b / val_b; the order they leave,
+    // n_order = counters[12] entries long, goes to the backward's (idle) per-Gaussian scratch: the emission uses the sort's
+    // own buffers for its rank lists.
+    const bool compacted = fused_depth && carry == nullptr && depth_sort_compaction_applicable(s.P);
+    SortCompaction cmp{g.tiles_touched, g.part_vis, g.key_b, g.val_b, &g.counters[12]};
+    launch_sort_hist(g.key_a, s.P, nullptr, 32, g.sort_hist, &house, depth_plan.threads, st, run_if, compacted ? &cmp : nullptr);
     // (the last pass also leaves the instance total of every block of 1024 depth ranks behind, for the emission)
-    if (!legacy && fused_sort_applicable(s.P, 32)) {
+    if (compacted) {
+      SortBuffers sbc{g.key_b, g.key_a, g.val_b, g.val_a, g.radix_table, g.scan_partials};
+      order = reinterpret_cast<uint32_t*>(g.gacc);
+      n_order_dev = &g.counters[12];
+      launch_sort_fused(sbc, depth_plan, s.P, n_order_dev, 32, false, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
+                        g.tiles_touched, g.emit_status, &g.counters[8],
+                        sort_knobs().fault.load(std::memory_order_relaxed) & 1, st, order, nullptr);
+    } else if (fused_depth) {
       // (values = Gaussian indices: the first pass takes them from the position, preprocess writes no index array)
       launch_sort_fused(sb, depth_plan, s.P, nullptr, 32, true, g.sort_hist, g.sort_status, g.tickets, nullptr, nullptr,
                         g.tiles_touched, g.emit_status, &g.counters[8],
@@ -376,8 +392,8 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     const int64_t bin_sync_words =
         (b.tile_status - b.sync_words) +
         (fused_tiles ? ((int64_t)tpasses * tile_plan.nblk * ((int64_t)1 << tdb) + 1) / 2 : 0);  // 16-bit words
-    launch_emit(s, d, g, b, bin_sync_words, n_host, carry ? carry : g.depth_order, carry ? g.carry_totals : nullptr,
-                carry ? g.carry_miss : nullptr, st);
+    launch_emit(s, d, g, b, bin_sync_words, n_host, carry ? carry : (order ? order : g.depth_order),
+                carry ? g.carry_totals : nullptr, carry ? g.carry_miss : nullptr, n_order_dev, st);
     STAGE("emit");
     if (n_host > 0) {
       // arrange the value ping-pong so that the last pass always lands in b.src
@@ -545,6 +561,7 @@ struct SortKnobsFromEnv {
     sort_knobs().resident = num("OLSR_SORT_RESIDENT");
     sort_knobs().legacy = num("OLSR_SORT_LEGACY") == 1 ? 1 : 0;
     if (std::getenv("OLSR_SORT_SMALL")) sort_knobs().small_sort = num("OLSR_SORT_SMALL") != 0 ? 1 : 0;
+    if (std::getenv("OLSR_SORT_COMPACT")) sort_knobs().compact = num("OLSR_SORT_COMPACT") != 0 ? 1 : 0;
     if (num("OLSR_SORT_THREADS") == 1024 || num("OLSR_SORT_THREADS") == 256) sort_knobs().threads = num("OLSR_SORT_THREADS");
   }
 } g_sort_knobs_from_env;
@@ -1027,7 +1044,8 @@ const void* olsr_geometry_field(const void* geometry_buffer, int32_t P, int32_t 
   if (!std::strcmp(name, "rgb")) return g.rgb;
   if (!std::strcmp(name, "clamped")) return g.clamped;
   if (!std::strcmp(name, "tiles_touched")) return g.tiles_touched;
-  if (!std::strcmp(name, "depth_order")) return g.depth_order;
+  if (!std::strcmp(name, "depth_order")) return g.depth_order;  // (the sort's own buffer: every Gaussian, compaction off)
+  if (!std::strcmp(name, "depth_order_compacted")) return g.gacc;  // u32[counters[12]]: the emitting Gaussians in depth order
   if (!std::strcmp(name, "counters")) return g.counters;
   if (!std::strcmp(name, "emit_totals")) return g.emit_status;
   if (!std::strcmp(name, "inst_start")) return g.inst_start;
@@ -1110,6 +1128,10 @@ void olsr_debug_composite_stamps(unsigned long long* device_buffer, int capacity
 int olsr_debug_sort_threads(int threads) {
   if (threads == 0 || threads == 256 || threads == 1024) sort_knobs().threads = threads;
   return sort_knobs().threads.load();
+}
+
+void olsr_debug_sort_compact(int enable) {
+  if (enable >= 0) sort_knobs().compact.store(enable ? 1 : 0, std::memory_order_relaxed);
 }
 
 void olsr_debug_sort_small(int enable) {

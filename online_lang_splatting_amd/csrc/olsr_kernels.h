@@ -39,9 +39,10 @@ int launch_radix_sort(const SortBuffers& b, int64_t n_host, const int32_t* n_dev
 // (n_host: the instance count, or the caller's capacity when the count is only known on the device)
 // order: the depth order to emit in (g.depth_order, or the carried one); alt_totals / alt_unless (may be null): the per-block
 // instance totals come from alt_totals instead of g.emit_status when *alt_unless == 0 (the carried order was repaired)
+// n_order_dev (may be null = P): the number of entries of `order` when the depth sort compacted its input
 void launch_emit(const olsr_scene& s, const FrameDims& d, const GeometryState& g, const BinningState& b,
                  int64_t bin_sync_words, int64_t n_host, const uint32_t* order, const uint32_t* alt_totals,
-                 const uint32_t* alt_unless, hipStream_t st);
+                 const uint32_t* alt_unless, const int32_t* n_order_dev, hipStream_t st);
 // exclusive scan of popcount(flags) over [0, n] -> rowbase[0..n] in one kernel; counters[6] = total live rows,
 // counters[7] = (total > row_capacity) or the forward's instance overflow
 // packed_ref15: rows per instance = packed survivor waves (flag bits 4-5) instead of forward slots (bits 0-3)
@@ -118,9 +119,20 @@ int fused_sort_digit_bits(int bits, int* passes_out);
 // digit totals of all passes (hist[pass][256], zeroed beforehand); optionally the frame's bookkeeping
 // run_if (may be null; also launch_sort_fused / launch_small_depth_sort): a device word — the kernels do their work only when it
 // is non-zero (the carried depth order could not be repaired, k_order_carry.hip); the frame's bookkeeping happens either way
+// compaction (may be null; depth sort only): the kernel also writes the (key, index) of the Gaussians that emit instances
+// (inst_count != 0) densely, in index order, into out_keys / out_gid, their number into *n_out, and counts digits of those
+// only — the passes then sort out_keys / out_gid with n_dev = n_out (k_sort.hip: "Visible-set compaction")
+struct SortCompaction {
+  const uint32_t* inst_count;
+  const uint32_t* part_vis;  // per block of 256 Gaussians: how many emit (preprocess)
+  uint32_t* out_keys;
+  uint32_t* out_gid;
+  int32_t* n_out;
+};
+bool depth_sort_compaction_applicable(int64_t P);
 void launch_sort_hist(const uint32_t* keys, int64_t n_host, const int32_t* n_dev, int bits, uint32_t* hist,
                       const FusedHouse* house, int threads /* 256 or 1024: SortPlan::threads */, hipStream_t st,
-                      const uint32_t* run_if = nullptr);
+                      const uint32_t* run_if = nullptr, const SortCompaction* compaction = nullptr);
 // stable sort on the low `bits` bits; status: [passes][plan.nblk][1 << digit bits] zeroed 16-bit words (plan = sort_plan(n_host, ...)), tickets:
 // one zeroed word per pass.  flags_clear (with vals_in_identity): byte i is cleared for every element; ranges: the
 // last pass derives per-key [start, end) (keys must then be tile ids).  Returns where the result ends (0: a, 1: b);

@@ -54,6 +54,8 @@ struct SortKnobs {
   // trace of four frames in flight: 15 us passes stretched to 147 us).  Four-wave blocks with sixteen keys per thread get on
   // sooner: + 2 % frames/s with four frames in flight — and - 11 % with one (the depth sort 69 -> 108 us), hence per call.
   std::atomic<int> threads{0};
+  std::atomic<int> compact{1};     // the depth sort orders only the Gaussians that emit instances (k_sort.hip); OLSR_SORT_COMPACT=0 /
+                                   // olsr_debug_sort_compact(0): every Gaussian, as rounds 1-5 did
   std::atomic<int> small_sort{1};  // the one-launch depth sort of <= 8 192 Gaussians (k_sort.hip); OLSR_SORT_SMALL=0 / olsr_debug_sort_small(0): off
   // test hooks (olsr_debug_sync_fault): fault bit 0 / 1 = the block holding ticket 0 of the first depth / tile pass never
   // publishes its digit counts (what a status word corrupted mid-frame looks like to its successors); spin_limit = polls a
@@ -176,7 +178,9 @@ struct GeometryState {
                           //          forward reports it as num_rendered_dev[1] = 2, the backward writes zero gradients and
                           //          reports status_dev[1] = 2 / OLSR_ERR_DEVICE (include/olsr.h),
                           //      9 = a tile with a depth cut-off did not saturate (OLSR_STATUS_CUT_MISS),
-                          //      10 = Gaussians that emit instances (the length of the emission's compacted rank list).  [11..15] reserved
+                          //      10 = Gaussians that emit instances (the length of the emission's compacted rank list),
+                          //      11 = the rows were compacted for a scratch of this capacity (olsr_device.h: rows_stamp_of),
+                          //      12 = Gaussians the depth sort ordered (the emitting ones) when it compacted its input.  [13..15] reserved
   float* tau_partials;    // [6 * ceil(P/128)] scratch of the backward's deterministic dL_dtau reduction
   float* gacc;            // [P][grad_row(F)] backward scratch: per-Gaussian sum of its instance rows
   uint4* big_list;        // [P] work lists {id, first instance, #instances} built by the emission: large footprints from
@@ -190,6 +194,7 @@ struct GeometryState {
   uint32_t* emit_status;  // [ceil(P / EMIT_CHUNK)] x 64 bit: per-block totals for the emission (emit_total_pack above)
   uint32_t* part_rect;    // [ceil(P / 256)] preprocess' per-block sums: instances of the reference's rect binning
   uint32_t* part_count;   // [ceil(P / 256)] ... and instances this frame emits
+  uint32_t* part_vis;     // [ceil(P / 256)] ... and Gaussians that emit any (the depth sort orders only those, k_sort.hip)
   uint32_t* carry_totals; // [ceil(P / EMIT_CHUNK) + 1] x 64 bit: the same totals for a REPAIRED carried depth order (k_order_carry.hip)
   uint32_t* carry_miss;   // one of the zeroed words (tickets[12]): != 0 = the carried order could not be repaired, the radix passes run
   static GeometryState carve(void* buf, size_t P, int grad_row_floats, size_t& bytes) {
@@ -230,6 +235,7 @@ struct GeometryState {
     }
     g.part_rect = c.take<uint32_t>((P + 255) / 256 + 1);
     g.part_count = c.take<uint32_t>((P + 255) / 256 + 1);
+    g.part_vis = c.take<uint32_t>((P + 255) / 256 + 1);
     g.carry_totals = c.take<uint32_t>(2 * ((P + EMIT_CHUNK - 1) / EMIT_CHUNK + 1));
     g.carry_miss = g.tickets + 12;
     bytes = c.total();

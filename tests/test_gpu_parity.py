@@ -395,6 +395,7 @@ def test_one_launch_depth_sort_equals_the_radix_passes(hip, P):
     a = fwd_args(sc, dev)
     out = {}
     try:
+        lib().olsr_debug_sort_compact(0)   # (the pass kernels' order of EVERY Gaussian is what is compared with the small sort's)
         for small in (1, 0):
             lib().olsr_debug_sort_small(small)
             R, color, lang, radii, geom, binb, img, depth, opac, nt = hip.rasterize_language_gaussians(*a)
@@ -406,10 +407,49 @@ def test_one_launch_depth_sort_equals_the_radix_passes(hip, P):
             out[small] = (R, order, cnt, et, pl, color.clone(), lang.clone(), depth.clone(), nt.clone())
     finally:
         lib().olsr_debug_sort_small(1)
+        lib().olsr_debug_sort_compact(1)
     assert out[1][0] == out[0][0]
     for x, y in zip(out[1][1:], out[0][1:]):
         assert (x is None and y is None) or torch.equal(x, y)
     assert sorted(out[1][1].tolist()) == list(range(P))
+
+
+@pytest.mark.parametrize("P,frac", [(8193, 0.5), (10000, 0.0), (10000, 1.0), (30000, 0.3), (70001, 0.8), (262144, 0.2)])
+def test_visible_set_compaction_of_the_depth_sort_changes_nothing(hip, P, frac):
+    """Round 6: the depth sort orders only the Gaussians that emit instances (the histogram kernel compacts them in index
+    order).  With a share `frac` of the Gaussians pushed behind the camera — whole blocks of 256 of them, ragged tails, none,
+    all — the compacted order equals the emitting subsequence of the uncompacted one, and counters, emission totals, lists,
+    images and n_touched are bit-identical."""
+    from online_lang_splatting_amd._lib import lib
+    dev = torch.device(DEV)
+    sc = make_scene(P, 200, 150, 3, seed=500 + P % 89)
+    g = torch.Generator().manual_seed(P)
+    hide = torch.rand(P, generator=g) < frac
+    hide[: min(P, 700)] = frac > 0            # (whole leading blocks without a single emitting Gaussian)
+    sc.means3D[hide, 2] = -1.0
+    sc.means3D[::5, 2] = sc.means3D[4, 2]     # ties in quantity
+    a = fwd_args(sc, dev)
+    out = {}
+    try:
+        for comp in (1, 0):
+            lib().olsr_debug_sort_compact(comp)
+            R, color, lang, radii, geom, binb, img, depth, opac, nt = hip.rasterize_language_gaussians(*a)
+            cnt = hip.state_field("geometry", geom, "counters", P=P, F=3, dtype=torch.int32, count=13).clone()
+            tt = hip.state_field("geometry", geom, "tiles_touched", P=P, F=3, dtype=torch.int32, count=P).clone()
+            if comp:
+                n_ord = int(cnt[12])
+                order = hip.state_field("geometry", geom, "depth_order_compacted", P=P, F=3, dtype=torch.int32, count=max(n_ord, 1))[:n_ord].clone()
+            else:
+                full = hip.state_field("geometry", geom, "depth_order", P=P, F=3, dtype=torch.int32, count=P).clone()
+                order = full[tt[full.long()] > 0]
+            pl = hip.state_field("binning", binb, "point_list", R=R, F=3, dtype=torch.int32, count=R).clone() if R else None
+            out[comp] = (R, order, cnt[:11], pl, color.clone(), lang.clone(), depth.clone(), nt.clone(), radii.clone())
+    finally:
+        lib().olsr_debug_sort_compact(1)
+    assert out[1][0] == out[0][0]
+    assert int((tt > 0).sum()) == out[1][1].numel()
+    for x, y in zip(out[1][1:], out[0][1:]):
+        assert (x is None and y is None) or torch.equal(x, y)
 
 
 @pytest.mark.parametrize("threads", [256, 1024])
