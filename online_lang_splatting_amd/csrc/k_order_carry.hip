@@ -27,6 +27,8 @@
 // them, the right run's elements expect the whole left run; one LDS read settles that case, and an element that did move
 // pays 2 log2(distance) reads.  Stable (left < right on ties), so even an input with repeated indices comes out as a
 // rearrangement of itself and the strictness test sees the repeat.
+#include <cstdlib>
+
 #include "olsr_device.h"
 #include "olsr_kernels.h"
 
@@ -216,7 +218,15 @@ void launch_order_repair(int P, uint32_t* carry, const uint32_t* keys, uint32_t*
   const int nb = (P + OC_W / 2 + OC_W - 1) / OC_W;  // windows [j W - W / 2, j W + W / 2) that reach below P
   // (four-wave workgroups beside another frame's composite, sixteen waves alone: the same choice as the radix passes,
   //  OLSR_FLAG_FRAMES_IN_FLIGHT)
-  if (frames_in_flight) {
+  static const int forced = [] {  // (experiment knob, read once: OLSR_CARRY_THREADS=256 / 512 / 1024)
+    const char* e = std::getenv("OLSR_CARRY_THREADS");
+    return e ? std::atoi(e) : 0;
+  }();
+  const int T = forced ? forced : (frames_in_flight ? 256 : 1024);
+  if (T == 512) {
+    order_repair_a_kernel<512><<<na, 512, 0, st>>>(P, carry, keys, tmp_key, tmp_gid, miss);
+    order_repair_b_kernel<512><<<nb, 512, 0, st>>>(P, tmp_key, tmp_gid, carry, inst_count, reinterpret_cast<u64*>(totals), miss);
+  } else if (T == 256) {
     order_repair_a_kernel<256><<<na, 256, 0, st>>>(P, carry, keys, tmp_key, tmp_gid, miss);
     order_repair_b_kernel<256><<<nb, 256, 0, st>>>(P, tmp_key, tmp_gid, carry, inst_count, reinterpret_cast<u64*>(totals), miss);
   } else {

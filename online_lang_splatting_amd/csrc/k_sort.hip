@@ -871,9 +871,14 @@ static FrameHousekeeping housekeeping_of(const FusedHouse* house) {
 }
 
 // the depth sort of at most SMALL_SORT_MAX (8 192) Gaussians in one launch (sort_small_kernel); false: not applicable
-bool small_depth_sort_applicable(int64_t n) {
+// as_fallback: behind the repair of a carried depth order (k_order_carry.hip) the sort runs only when the repair missed, and
+// what counts on every other frame is how many launches return at once: ONE for the one-launch sort against five for the
+// histogram and the passes.  There the one-launch sort takes up to 16 384 Gaussians (sixteen keys per thread: ~63 us when it
+// does run, against ~48 us for the passes — on the rare frame; BASELINE config 1, 10 k Gaussians: 28 -> 20 us on the others).
+constexpr int SMALL_SORT_MAX_FALLBACK = 16384;
+bool small_depth_sort_applicable(int64_t n, bool as_fallback) {
   // (a pinned keys-per-thread or the depth sort's fault hook ask for the pass kernels)
-  return n > 0 && n <= SMALL_SORT_MAX && sort_plan_forced_kpt() == 0 &&
+  return n > 0 && n <= (as_fallback ? SMALL_SORT_MAX_FALLBACK : SMALL_SORT_MAX) && sort_plan_forced_kpt() == 0 &&
          sort_knobs().small_sort.load(std::memory_order_relaxed) != 0 &&
          (sort_knobs().fault.load(std::memory_order_relaxed) & 1) == 0;
 }
@@ -883,7 +888,8 @@ void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, c
   u64* et = reinterpret_cast<u64*>(emit_totals);
   if (n <= 2 * FS_T) launch_sort_small_t<2>(keys, n, order_out, inst_count, et, h, run_if, st);
   else if (n <= 4 * FS_T) launch_sort_small_t<4>(keys, n, order_out, inst_count, et, h, run_if, st);
-  else launch_sort_small_t<8>(keys, n, order_out, inst_count, et, h, run_if, st);
+  else if (n <= 8 * FS_T) launch_sort_small_t<8>(keys, n, order_out, inst_count, et, h, run_if, st);
+  else launch_sort_small_t<16>(keys, n, order_out, inst_count, et, h, run_if, st);
 }
 
 bool depth_sort_compaction_applicable(int64_t P) {

@@ -306,7 +306,7 @@ int forward_impl(const olsr_scene& s, void* geom_buf, void* img_buf, const Binni
     const uint32_t* run_if = carry ? g.carry_miss : nullptr;
     if (carry)
       launch_order_repair(s.P, carry, g.key_a, g.key_b, g.val_b, g.tiles_touched, g.carry_totals, g.carry_miss, in_flight, st);
-    if (!legacy && small_depth_sort_applicable(s.P)) {
+    if (!legacy && small_depth_sort_applicable(s.P, carry != nullptr)) {
       // at most 8 192 Gaussians: histogram, bookkeeping and all four passes in ONE launch of one workgroup (k_sort.hip)
       launch_small_depth_sort(g.key_a, s.P, carry ? carry : g.depth_order, g.tiles_touched, g.emit_status, &house, run_if, st);
       STAGE("depth_sort");

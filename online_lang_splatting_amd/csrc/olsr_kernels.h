@@ -145,7 +145,7 @@ int launch_sort_fused(const SortBuffers& b, const SortPlan& plan, int64_t n_host
 void debug_set_sort_timing(unsigned long long* buf, int max_blocks, int max_launches);
 // the same totals for a depth order produced by the multi-kernel passes
 // the whole depth sort of n <= 8 192 Gaussians in one launch, incl. the frame's bookkeeping (k_sort.hip: sort_small_kernel)
-bool small_depth_sort_applicable(int64_t n);
+bool small_depth_sort_applicable(int64_t n, bool as_fallback = false);
 void launch_small_depth_sort(const uint32_t* keys, int n, uint32_t* order_out, const uint32_t* inst_count,
                              uint32_t* emit_totals, const FusedHouse* house, const uint32_t* run_if, hipStream_t st);
 // k_order_carry.hip — the previous frame's depth order repaired under this frame's keys (olsr_scene.depth_order_carry):
