@@ -104,6 +104,8 @@ def measured_traffic(kernel_stage, F, scene="volume", config=3):
     if not files[-1]:
         return None, None
     d = json.load(open(files[-1]))
+    if d.get("scene", scene) != scene or d.get("config", config) != config:   # (the summary says what it was collected on)
+        return None, None
     prefix = {"render_forward": "render_fwd_kernel", "render_backward": "render_bwd_kernel"}[kernel_stage]
     for k, v in d["kernels"].items():
         if k.startswith(prefix) and f", {F}" in k:
@@ -118,6 +120,8 @@ def measured_valu(kernel_stage, F, scene="volume", config=3):
     if not files[-1]:
         return None, None
     d = json.load(open(files[-1]))
+    if d.get("scene", scene) != scene or d.get("config", config) != config:
+        return None, None
     prefix = {"render_forward": "render_fwd_kernel", "render_backward": "render_bwd_kernel"}[kernel_stage]
     for k, v in d["kernels"].items():
         if k.startswith(prefix) and f", {F}" in k:

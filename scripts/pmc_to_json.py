@@ -9,6 +9,9 @@ import collections, csv, json, os, re, shutil, sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"   # (on the GPU box: gpurun_out/<tag>/summary, copied into profiles/ afterwards)
+# the workload the counters were collected on: bench.py attaches them only to lines of this scene and config
+scene = sys.argv[3] if len(sys.argv) > 3 else "volume"
+config = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 os.makedirs(dst, exist_ok=True)
 
 
@@ -32,16 +35,18 @@ for r in csv.DictReader(open(os.path.join(src, "stats", "s_kernel_stats.csv"))):
                                    pct=float(r["Percentage"]))
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    if not re.search(r"render_|row_|preprocess|radix|sort_pass|emit|scan|tile_|tau_final|finalize|depth_", k):
+    if not re.search(r"render_|row_|preprocess|radix|sort_pass|sort_hist|order_repair|emit|scan|tile_|tau_final|forward_tail|finalize|depth_", k):
         continue
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out[k] = dict(FETCH_SIZE_KiB=round(f, 1), WRITE_SIZE_KiB=round(w, 1),
                   traffic_bytes=int((2 * f + w) * 1024), avg_us=round(stats.get(k, {}).get("avg_us", 0.0), 2))
-json.dump(dict(tag=tag, formula="(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch (MI355X_MICROARCH.md HBM section)",
+json.dump(dict(tag=tag, scene=scene, config=config, formula="(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch (MI355X_MICROARCH.md HBM section)",
                kernels=out), open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "stats", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "stats1", "s_kernel_stats.csv")):
     shutil.copy(os.path.join(src, "stats1", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_1_in_flight.csv"))
+if os.path.exists(os.path.join(src, "stats1p", "s_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "stats1p", "s_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_1_in_flight_plain_sort.csv"))
 for name in ("bench", "bench_cfg1", "bench_cfg2", "bench_cfg5", "bench_room"):
     if os.path.exists(os.path.join(src, name + ".json")) and os.path.getsize(os.path.join(src, name + ".json")):
         shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{tag}_{name}.json"))
@@ -67,7 +72,9 @@ if ex:
               open(os.path.join(dst, f"{tag}_exchange_overhead.json"), "w"), indent=1)
 # ---- SQ passes: what bounds the kernels (VALU issue).  Durations from the one-frame-in-flight trace.
 stats1 = {}
-p1 = os.path.join(src, "stats1", "s_kernel_stats.csv")
+p1 = os.path.join(src, "stats1p", "s_kernel_stats.csv")
+if not os.path.exists(p1):
+    p1 = os.path.join(src, "stats1", "s_kernel_stats.csv")
 if os.path.exists(p1):
     for r in csv.DictReader(open(p1)):
         stats1[short(r["Name"])] = float(r["AverageNs"]) / 1e3
@@ -82,7 +89,7 @@ for sub in ("sq_a", "sq_b"):
             sq[k][c] = v
 valu = {}
 for k, d in sq.items():
-    if not re.search(r"render_|preprocess|radix|sort_pass|emit|scan|row_", k) or "SQ_INSTS_VALU" not in d:
+    if not re.search(r"render_|preprocess|radix|sort_pass|sort_hist|order_repair|emit|scan|row_", k) or "SQ_INSTS_VALU" not in d:
         continue
     e = {c: int(v) for c, v in d.items()}
     us = stats1.get(k) or stats.get(k, {}).get("avg_us")
@@ -104,7 +111,7 @@ for k, d in sq.items():
         e["wait_inst_lds_over_wave_cycles"] = round(d.get("SQ_WAIT_INST_LDS", 0) / d["SQ_WAVE_CYCLES"], 4)
     valu[k] = e
 if valu:
-    json.dump(dict(tag=tag, note="means per launch over the dispatches of one rocprofv3 --pmc run each (sq_a: SQ_INSTS_VALU "
+    json.dump(dict(tag=tag, scene=scene, config=config, note="means per launch over the dispatches of one rocprofv3 --pmc run each (sq_a: SQ_INSTS_VALU "
                    "SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS; sq_b: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY "
                    "SQ_WAIT_INST_LDS), one frame in flight; SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles",
                    kernels=valu), open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w"), indent=1)
