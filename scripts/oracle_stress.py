@@ -18,7 +18,9 @@ t0 = time.time()
 fails = 0
 notes = 0
 chain_ok = 0
-for k in range(N):
+rounding_only = 0
+only = [int(x) for x in os.environ.get("OLSR_STRESS_ONLY", "").split(",") if x]   # (re-run single scenes of a campaign)
+for k in (only or range(N)):
     sc, tile, mode, kw, desc = random_scene(k, seed0, generation)
     try:
         T._check(hip, oracle, sc, seed=k, tile=tile, mode=mode, **kw)
@@ -40,13 +42,30 @@ for k in range(N):
                 chain_ok += 1
                 print("CHAIN-SENSITIVITY " + note + " | per element: " + str(e2)[:160], flush=True)
             except AssertionError as e3:
-                fails += 1
-                print("FAIL " + note + " | per element: " + str(e2)[:160] + " | chain: " + str(e3)[:200], flush=True)
+                # Round 6: an element of a composite-level tensor outside the 1e-4 band.  Is it rounding?  The reference's own
+                # association on the GPU (olsr_debug_backward_ordered) must equal the oracle, and the fast kernel must lie within
+                # K x 2^-24 x the element's condition of it (tests/parity_common.py: assert_rounding_only, K <= 64): then the
+                # element is a sum whose terms cancel to 1e-4 of their magnitudes, and no association could do better.
+                try:
+                    import torch
+                    from parity_common import assert_ordered_equals_oracle, assert_rounding_only, ordered_backward, run_backend
+                    fo, go = run_backend(oracle, sc, None, k, tile, mode, **kw)
+                    fr, gr = run_backend(hip, sc, torch.device("cuda:0"), k, tile, mode, binning=_abi.BINNING_RECT, **kw)
+                    gord = ordered_backward(hip, sc, fr, k, tile, mode, **kw)
+                    assert_ordered_equals_oracle(go, gord)
+                    Ks = assert_rounding_only(gr, gord, ordered_backward(hip, sc, fr, k, tile, mode, condition=True, **kw), k_bound=64.0)
+                    oracle.release(fo["geom"])
+                    rounding_only += 1
+                    print(f"ROUNDING-ONLY (K <= {max(Ks.values()):.1f}) " + note, flush=True)
+                except AssertionError as e4:
+                    fails += 1
+                    print("FAIL " + note + " | per element: " + str(e2)[:160] + " | chain: " + str(e3)[:200] + " | rounding: " + str(e4)[:200], flush=True)
     finally:
         hip.TILE, hip.BWD_MODE, hip.BINNING = 15, _abi.BWD_REFERENCE, _abi.BINNING_ELLIPSE
         oracle.TILE, oracle.BWD_MODE = 15, 0
     if (k + 1) % 25 == 0:
         print(f"{k + 1}/{N} scenes, {fails} failures, {notes} notes, {chain_ok} chain-sensitivity, {time.time() - t0:.0f} s", flush=True)
-print(f"done: {N} scenes, {fails} failures, {notes} max-norm notes, {chain_ok} scenes where only the per-Gaussian chain's "
+print(f"done: {N} scenes, {fails} failures, {rounding_only} scenes with a composite-level element outside 1e-4 that is rounding only "
+      f"(ordered kernel == oracle, fast kernel within K <= 64 of the element's condition), {notes} max-norm notes, {chain_ok} scenes where only the per-Gaussian chain's "
       f"input sensitivity shows (composite-level gradients and the chain on identical inputs both within the criterion)")
 sys.exit(1 if fails else 0)
